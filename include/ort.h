@@ -1,0 +1,176 @@
+/* ort.h — C ABI of libort_hip.so: the MI355X (gfx950) per-ray hot path of
+ * lewisfish/OpticalRayTrace (emit -> bottle -> plano-convex -> doublet -> image
+ * plane -> NA-filtered binning), behind plain C types.
+ *
+ * The reference has no FFI for this path: it sits inside `program raytrace`
+ * behind Fortran module procedures.  Each entry point below names the reference
+ * interface it replaces; INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative ORT_E_* code; nothing
+ *    throws or aborts across the ABI; ort_last_error() gives a message;
+ *  - the caller owns every host buffer; device memory is owned by the context;
+ *  - one context per device; calls on one context are serialised by the caller;
+ *  - ray bundles are structure-of-arrays fp64 [6][n]: x, y, z, dx, dy, dz
+ *    (component c of ray i at c*n + i) — the coalesced HBM layout;
+ *  - the image is int32 [2][401][401], layer 0 = ring (phase 1), layer 1 =
+ *    point (phase 2), bin (xp, yp) of a layer at (xp+200) + 401*(yp+200):
+ *    the storage order of `image(-200:200,-200:200,2)` (src/main.f90:35);
+ *  - there is NO CPU fallback: without a HIP device every call fails.
+ */
+#ifndef ORT_H
+#define ORT_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORT_ABI_VERSION 1
+#define ORT_MAX_SURFACES 12
+#define ORT_IMAGE_N 401
+#define ORT_IMAGE_BINS (2 * 401 * 401)
+#define ORT_NUM_COUNTERS 8
+
+/* error codes */
+#define ORT_OK 0
+#define ORT_E_INVALID (-1)   /* bad argument */
+#define ORT_E_NODEVICE (-2)  /* no HIP device / device index out of range */
+#define ORT_E_HIP (-3)       /* a HIP runtime call failed */
+#define ORT_E_NOMEM (-4)
+
+/* surface kinds of the staged surface list */
+#define ORT_SURF_PLANE 0     /* move to z = cz, aperture test, Fresnel at N=(0,0,-1)  (src/lens.f90:446-459) */
+#define ORT_SURF_SPHERE 1    /* intersect_sphere + move + normal + Fresnel            (src/lens.f90:462-479, :568-628) */
+#define ORT_SURF_CYLINDER 2  /* x-axis cylinder in y-z                                (src/lens.f90:255-297, :303-348) */
+#define ORT_SURF_ELLIPSE 3   /* x-axis elliptic cylinder, semi-axes radius (z), radius_b (y) (src/surfaces.f90:133-176) */
+#define ORT_SURF_IRIS 4      /* test-only plane: r at z = cz must be <= aperture; position restored (src/lens.f90:551-565, :632-644) */
+#define ORT_SURF_IMAGE 5     /* move to z = cz, then makeImage2D                      (src/optics_system.f90:48-49, src/imageMod.f90:19-58) */
+
+/* surface flags */
+#define ORT_F_SKIP_ON_REFLECT 1u /* a Fresnel reflection ends the ray (every surface but the plano flat face, src/lens.f90:458-459) */
+#define ORT_F_MISS_IS_HELP3 2u   /* a miss here is the reference's `error stop "Help3"` (src/lens.f90:617): counted, not fatal */
+#define ORT_F_BOTTLE 4u          /* losses at this surface are bottle losses (src/main.f90:150-151) */
+
+/* One optical surface as staged into LDS (80 B). */
+typedef struct ort_surface {
+    double cx, cy, cz;   /* centre (sphere / cylinder / ellipse) or plane z in cz */
+    double radius;       /* sphere / cylinder radius; ellipse semi-axis along z */
+    double radius_b;     /* ellipse semi-axis along y (unused otherwise) */
+    double n1, n2;       /* refractive index before / after the surface */
+    double eta;          /* n1 / n2, rounded once on the host (IEEE division: same bits as on the device) */
+    double aperture;     /* reject when sqrt(x^2+y^2) > aperture after the move; < 0: no test */
+    int32_t kind;        /* ORT_SURF_* */
+    uint32_t flags;      /* ORT_F_* */
+} ort_surface;
+
+/* Everything the kernels need for both phases; built by the host from the
+ * reference's settings/.params files (src/setupMod.f90:57-133, src/lens.f90:73-227,
+ * src/main.f90:51-81, :113-116). */
+typedef struct ort_system {
+    int32_t abi_version;          /* ORT_ABI_VERSION */
+    int32_t n_surfaces[2];        /* [0] phase 1 (ring), [1] phase 2 (point) */
+    int32_t ring_ellipse;         /* bottle%ellipse for the ring emitter (src/sourceMod.f90:276) */
+    ort_surface surfaces[2][ORT_MAX_SURFACES];
+    /* point emitter, src/sourceMod.f90:12-47 */
+    double cos_theta_max;
+    /* ring emitter, src/sourceMod.f90:250-300 */
+    double ring_r1, ring_r2;      /* squared annulus radii (src/main.f90:68-70) */
+    double ring_lens_r2;          /* (L2%radius + 10e-3)^2 */
+    double ring_lens_z;           /* L2%fb */
+    double ring_bottle_ra, ring_bottle_rb, ring_bottle_z;
+    /* image, src/imageMod.f90:19-58 */
+    double bin_width;             /* image_diameter / 401. */
+    double na_angle;              /* asin(0.22) */
+    double twopi;                 /* 2.*4.*atan(1.) (src/constants.f90:5) */
+} ort_system;
+
+/* per-ray status written by ort_trace_rays */
+#define ORT_ST_BINNED 0
+#define ORT_ST_NA_REJECT 1
+#define ORT_ST_OFF_GRID 2
+#define ORT_ST_LOST_BOTTLE 3
+#define ORT_ST_LOST_TELESCOPE 4
+#define ORT_ST_HELP3 5
+
+/* counters[ORT_NUM_COUNTERS] */
+#define ORT_C_LOST_RING 0     /* rcount, src/main.f90:40, optics_system.f90:32,42 */
+#define ORT_C_LOST_POINT 1    /* pcount, src/main.f90:41,151 */
+#define ORT_C_ISECT_RING 2    /* ray-surface intersections evaluated (the metric's unit of work) */
+#define ORT_C_ISECT_POINT 3
+#define ORT_C_BINNED_RING 4
+#define ORT_C_BINNED_POINT 5
+#define ORT_C_HELP3_RING 6
+#define ORT_C_HELP3_POINT 7
+
+typedef struct ort_ctx ort_ctx;
+
+/* Library / device probing. */
+int ort_abi_version(void);
+const char *ort_last_error(void);
+int ort_device_count(int *count);
+
+/* Context = one device's image accumulator + counters + staged system.
+ * Replaces the allocation and zeroing in src/main.f90:35-41 and the lens
+ * objects handed to the loop (src/main.f90:43). `stream` is a hipStream_t
+ * passed as void* (NULL = the context creates its own). */
+int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out);
+int ort_destroy(ort_ctx *ctx);
+int ort_set_system(ort_ctx *ctx, const ort_system *sys);
+int ort_reset(ort_ctx *ctx);                       /* image = 0, counters = 0 (src/main.f90:39-41) */
+
+/* The hot loop.  Replaces one OpenMP `do i = 1, nphotons` loop of
+ * src/main.f90:90-109 (phase 1, ring) or :127-162 (phase 2, point) over the
+ * global ray indices [first_ray, first_ray + n_rays): emit, trace, bin into the
+ * context's device image and counters.  Draws are ORT-RNG-v1 keyed on
+ * (seed, phase, global ray index, draw index), so any partition of the index
+ * range over calls, contexts or GPUs accumulates the same image.
+ * Asynchronous on the context's stream. */
+int ort_trace(ort_ctx *ctx, int phase, uint64_t first_ray, uint64_t n_rays, uint64_t seed);
+
+/* Same loop with the ray bundle resident in HBM (device pointer, SoA fp64
+ * [6][n]) instead of emitted in-kernel: replaces the loop body after the emitter
+ * call (src/main.f90:104-108, :145-161).  Ray i consumes draws
+ * draw_base, draw_base+1, ... of key (seed, phase, first_ray + i).
+ * ort_emit fills such a bundle with the phase's source
+ * (ring src/sourceMod.f90:250, point :12), using draws 0..draw_base-1. */
+int ort_emit(ort_ctx *ctx, int phase, uint64_t first_ray, uint64_t n_rays, uint64_t seed,
+             double *d_pos_dir);
+int ort_trace_resident(ort_ctx *ctx, int phase, uint64_t first_ray, uint64_t n_rays,
+                       uint64_t seed, int draw_base, const double *d_pos_dir);
+
+/* Parity / debug entry on HOST buffers, no side effect on the image or the
+ * counters.  pos_dir_in NULL => emit in-kernel.  u NULL => keyed draws as in
+ * ort_trace; else u is [nu][n] (draw k of ray i at k*n + i, first used draw is
+ * draw_base).  Any output may be NULL.  Outputs: final pos/dir, the emitted
+ * pos/dir, status (ORT_ST_*), bin (xp at i, yp at n+i; -9999 when not binned),
+ * intersections evaluated, draws consumed.  Synchronous. */
+int ort_trace_rays(ort_ctx *ctx, int phase, int64_t n,
+                   const double *pos_dir_in, int nu, const double *u, int draw_base,
+                   uint64_t seed, uint64_t first_ray,
+                   double *pos_dir_out, double *emitted_out, int32_t *status,
+                   int32_t *bin_xy, int32_t *n_isect, int32_t *n_draws);
+
+/* Accumulator access.  ort_read replaces reading `image`, `rcount`, `pcount`
+ * after the loops (src/main.f90:175-185); synchronises the stream.
+ * ort_device_image / ort_device_counters expose the device buffers (int32
+ * [ORT_IMAGE_BINS], uint64 [ORT_NUM_COUNTERS]) so the host can sum them across
+ * GPUs with RCCL in place (torch.distributed all_reduce) — the multi-GPU
+ * equivalent of the OpenMP atomic image + reduction (src/main.f90:88,
+ * src/imageMod.f90:55). */
+int ort_read(ort_ctx *ctx, int32_t *image, uint64_t *counters);
+int ort_device_image(ort_ctx *ctx, void **d_image);
+int ort_device_counters(ort_ctx *ctx, void **d_counters);
+int ort_synchronize(ort_ctx *ctx);
+
+/* Timing of the last launch of each kernel kind on the context's own stream
+ * (HIP events recorded around the launch): ms, or <0 if none.  kind: 0 fused
+ * trace, 1 resident trace, 2 emit. */
+int ort_last_kernel_ms(ort_ctx *ctx, int kind, float *ms);
+int ort_set_timing(ort_ctx *ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

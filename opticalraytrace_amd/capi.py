@@ -1,0 +1,260 @@
+"""ctypes binding of libort_hip.so (include/ort.h) — the thin host/device boundary.
+
+There is no CPU fallback: if the HIP library is missing or no device is present
+every call raises.  The library is built in-tree by `__graft_entry__.build()` or
+`make -C opticalraytrace_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .system import MAX_SURFACES, OpticalSystem, TWOPI
+
+ABI_VERSION = 1
+IMAGE_N = 401
+IMAGE_BINS = 2 * IMAGE_N * IMAGE_N
+NUM_COUNTERS = 8
+
+ST_BINNED, ST_NA_REJECT, ST_OFF_GRID, ST_LOST_BOTTLE, ST_LOST_TELESCOPE, ST_HELP3 = range(6)
+(C_LOST_RING, C_LOST_POINT, C_ISECT_RING, C_ISECT_POINT,
+ C_BINNED_RING, C_BINNED_POINT, C_HELP3_RING, C_HELP3_POINT) = range(8)
+
+_ERRORS = {-1: "ORT_E_INVALID", -2: "ORT_E_NODEVICE", -3: "ORT_E_HIP", -4: "ORT_E_NOMEM"}
+
+
+class OrtError(RuntimeError):
+    pass
+
+
+class OrtSurface(C.Structure):
+    _fields_ = [("cx", C.c_double), ("cy", C.c_double), ("cz", C.c_double),
+                ("radius", C.c_double), ("radius_b", C.c_double),
+                ("n1", C.c_double), ("n2", C.c_double), ("eta", C.c_double),
+                ("aperture", C.c_double), ("kind", C.c_int32), ("flags", C.c_uint32)]
+
+
+class OrtSystem(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("n_surfaces", C.c_int32 * 2),
+                ("ring_ellipse", C.c_int32),
+                ("surfaces", (OrtSurface * MAX_SURFACES) * 2),
+                ("cos_theta_max", C.c_double),
+                ("ring_r1", C.c_double), ("ring_r2", C.c_double),
+                ("ring_lens_r2", C.c_double), ("ring_lens_z", C.c_double),
+                ("ring_bottle_ra", C.c_double), ("ring_bottle_rb", C.c_double),
+                ("ring_bottle_z", C.c_double),
+                ("bin_width", C.c_double), ("na_angle", C.c_double), ("twopi", C.c_double)]
+
+
+def pack_system(osys: OpticalSystem) -> OrtSystem:
+    """OpticalSystem -> the POD the kernels stage into LDS (include/ort.h `ort_system`)."""
+    cs = OrtSystem()
+    cs.abi_version = ABI_VERSION
+    for ph in (1, 2):
+        surfs = osys.surfaces(ph)
+        cs.n_surfaces[ph - 1] = len(surfs)
+        for k, s in enumerate(surfs):
+            d = cs.surfaces[ph - 1][k]
+            d.cx, d.cy, d.cz = s.cx, s.cy, s.cz
+            d.radius, d.radius_b = s.radius, s.radius_b
+            d.n1, d.n2 = s.n1, s.n2
+            d.eta = s.n1 / s.n2               # surfaces.f90:279,352: n1/n2 (IEEE division)
+            d.aperture = s.aperture
+            d.kind, d.flags = s.kind, s.flags
+    l2 = osys.L2[0]
+    b = osys.bottle
+    cs.ring_ellipse = 1 if b.ellipse else 0
+    cs.cos_theta_max = osys.cos_theta_max
+    cs.ring_r1, cs.ring_r2 = osys.r1, osys.r2
+    rl = l2.radius + 10e-3                   # sourceMod.f90:285
+    cs.ring_lens_r2 = rl * rl
+    cs.ring_lens_z = l2.fb
+    cs.ring_bottle_ra, cs.ring_bottle_rb, cs.ring_bottle_z = b.radiusa, b.radiusb, b.centre[2]
+    cs.bin_width = osys.bin_width
+    cs.na_angle = osys.na_angle
+    cs.twopi = TWOPI
+    return cs
+
+
+_LIB: Optional[C.CDLL] = None
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int32)
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libort_hip.so")
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load libort_hip.so and declare every symbol of include/ort.h.  Raises if absent."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or library_path()
+    if not os.path.exists(p):
+        raise OrtError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` — there is no CPU fallback for the trace path")
+    lib = C.CDLL(p)
+    vp, u64, i32, i64 = C.c_void_p, C.c_uint64, C.c_int, C.c_int64
+    sig = {
+        "ort_abi_version": (C.c_int, []),
+        "ort_last_error": (C.c_char_p, []),
+        "ort_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+        "ort_create": (C.c_int, [C.POINTER(OrtSystem), i32, vp, C.POINTER(vp)]),
+        "ort_destroy": (C.c_int, [vp]),
+        "ort_set_system": (C.c_int, [vp, C.POINTER(OrtSystem)]),
+        "ort_reset": (C.c_int, [vp]),
+        "ort_trace": (C.c_int, [vp, i32, u64, u64, u64]),
+        "ort_emit": (C.c_int, [vp, i32, u64, u64, u64, vp]),
+        "ort_trace_resident": (C.c_int, [vp, i32, u64, u64, u64, i32, vp]),
+        "ort_trace_rays": (C.c_int, [vp, i32, i64, _DP, i32, _DP, i32, u64, u64,
+                                     _DP, _DP, _IP, _IP, _IP, _IP]),
+        "ort_read": (C.c_int, [vp, _IP, C.POINTER(C.c_uint64)]),
+        "ort_device_image": (C.c_int, [vp, C.POINTER(vp)]),
+        "ort_device_counters": (C.c_int, [vp, C.POINTER(vp)]),
+        "ort_synchronize": (C.c_int, [vp]),
+        "ort_last_kernel_ms": (C.c_int, [vp, i32, C.POINTER(C.c_float)]),
+        "ort_set_timing": (C.c_int, [vp, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.ort_abi_version() != ABI_VERSION:
+        raise OrtError("libort_hip.so ABI version mismatch")
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ["ort_abi_version", "ort_last_error", "ort_device_count", "ort_create",
+                    "ort_destroy", "ort_set_system", "ort_reset", "ort_trace", "ort_emit",
+                    "ort_trace_resident", "ort_trace_rays", "ort_read", "ort_device_image",
+                    "ort_device_counters", "ort_synchronize", "ort_last_kernel_ms",
+                    "ort_set_timing"]
+
+
+def _check(lib, rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib.ort_last_error()
+        raise OrtError(f"{what} failed: {_ERRORS.get(rc, rc)}: "
+                       f"{msg.decode() if msg else ''}")
+
+
+def _dptr(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(_DP) if a is not None else None
+
+
+def _iptr(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(_IP) if a is not None else None
+
+
+class Context:
+    """One device's tracer: image accumulator + counters + staged surface table."""
+
+    def __init__(self, osys: OpticalSystem, device: int = 0, stream: int = 0):
+        self.lib = load_library()
+        self.system = osys
+        self._csys = pack_system(osys)
+        self._h = C.c_void_p()
+        _check(self.lib, self.lib.ort_create(C.byref(self._csys), device,
+                                             C.c_void_p(stream) if stream else None,
+                                             C.byref(self._h)), "ort_create")
+        self.device = device
+
+    def close(self) -> None:
+        if self._h:
+            self.lib.ort_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ------------------------------------------------------------------
+    def set_system(self, osys: OpticalSystem) -> None:
+        self.system = osys
+        self._csys = pack_system(osys)
+        _check(self.lib, self.lib.ort_set_system(self._h, C.byref(self._csys)), "ort_set_system")
+
+    def reset(self) -> None:
+        _check(self.lib, self.lib.ort_reset(self._h), "ort_reset")
+
+    def trace(self, phase: int, first_ray: int, n_rays: int, seed: int) -> None:
+        _check(self.lib, self.lib.ort_trace(self._h, phase, first_ray, n_rays, seed), "ort_trace")
+
+    def emit(self, phase: int, first_ray: int, n_rays: int, seed: int, d_pos_dir: int) -> None:
+        _check(self.lib, self.lib.ort_emit(self._h, phase, first_ray, n_rays, seed,
+                                           C.c_void_p(d_pos_dir)), "ort_emit")
+
+    def trace_resident(self, phase: int, first_ray: int, n_rays: int, seed: int,
+                       draw_base: int, d_pos_dir: int) -> None:
+        _check(self.lib, self.lib.ort_trace_resident(self._h, phase, first_ray, n_rays, seed,
+                                                     draw_base, C.c_void_p(d_pos_dir)),
+               "ort_trace_resident")
+
+    def synchronize(self) -> None:
+        _check(self.lib, self.lib.ort_synchronize(self._h), "ort_synchronize")
+
+    def read(self):
+        image = np.zeros((2, IMAGE_N, IMAGE_N), dtype=np.int32)
+        counters = np.zeros(NUM_COUNTERS, dtype=np.uint64)
+        _check(self.lib, self.lib.ort_read(self._h, _iptr(image),
+                                           counters.ctypes.data_as(C.POINTER(C.c_uint64))), "ort_read")
+        return image, counters
+
+    def device_image_ptr(self) -> int:
+        p = C.c_void_p()
+        _check(self.lib, self.lib.ort_device_image(self._h, C.byref(p)), "ort_device_image")
+        return p.value
+
+    def device_counters_ptr(self) -> int:
+        p = C.c_void_p()
+        _check(self.lib, self.lib.ort_device_counters(self._h, C.byref(p)), "ort_device_counters")
+        return p.value
+
+    def set_timing(self, enable: bool) -> None:
+        _check(self.lib, self.lib.ort_set_timing(self._h, int(enable)), "ort_set_timing")
+
+    def last_kernel_ms(self, kind: int = 0) -> float:
+        ms = C.c_float()
+        _check(self.lib, self.lib.ort_last_kernel_ms(self._h, kind, C.byref(ms)), "ort_last_kernel_ms")
+        return ms.value
+
+    def trace_rays(self, phase: int, n: int, pos_dir_in: Optional[np.ndarray] = None,
+                   u: Optional[np.ndarray] = None, draw_base: int = 0, seed: int = 0,
+                   first_ray: int = 0):
+        """Parity entry; returns dict(pos_dir, emitted, status, bin_xy, n_isect, n_draws)."""
+        if pos_dir_in is not None:
+            pos_dir_in = np.ascontiguousarray(pos_dir_in, dtype=np.float64)
+            assert pos_dir_in.shape == (6, n)
+        nu = 0
+        if u is not None:
+            u = np.ascontiguousarray(u, dtype=np.float64)
+            assert u.ndim == 2 and u.shape[1] == n
+            nu = u.shape[0]
+        out = dict(pos_dir=np.zeros((6, n)), emitted=np.zeros((6, n)),
+                   status=np.zeros(n, np.int32), bin_xy=np.zeros((2, n), np.int32),
+                   n_isect=np.zeros(n, np.int32), n_draws=np.zeros(n, np.int32))
+        _check(self.lib, self.lib.ort_trace_rays(
+            self._h, phase, n, _dptr(pos_dir_in), nu, _dptr(u), draw_base, seed, first_ray,
+            _dptr(out["pos_dir"]), _dptr(out["emitted"]), _iptr(out["status"]),
+            _iptr(out["bin_xy"]), _iptr(out["n_isect"]), _iptr(out["n_draws"])), "ort_trace_rays")
+        return out
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = C.c_int(0)
+    _check(lib, lib.ort_device_count(C.byref(n)), "ort_device_count")
+    return n.value

@@ -1,0 +1,202 @@
+"""TEST INFRASTRUCTURE — ctypes bindings of the checkers.
+
+  * Oracle      — oracle/libort_oracle.so, the plain-C restatement (ort_oracle.c)
+  * Reference   — oracle/_ref/libort_ref.so, the reference's own Fortran path
+                  sources compiled with flang (build container only, or prebuilt)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+Nothing in opticalraytrace_amd/ does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libort_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libort_ref.so")
+REF_PROG = os.path.join(HERE, "_ref", "raytrace")
+
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int32)
+
+
+class OrcVec(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+
+class OrcPlano(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ("thickness", "curve_radius", "radius", "fb", "f", "n1", "n2")] + \
+               [("centre", OrcVec), ("flatNormal", OrcVec)]
+
+
+class OrcDoublet(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ("R1", "R2", "R3", "radius", "fb", "f", "n1", "n2", "n3", "thickness")] + \
+               [("centre1", OrcVec), ("centre2", OrcVec), ("centre3", OrcVec)]
+
+
+class OrcBottle(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ("nbottle", "ncontents", "thickness", "radiusa", "radiusb")] + \
+               [("centre", OrcVec), ("ellipse", C.c_int32), ("pad", C.c_int32)]
+
+
+class OrcSystem(C.Structure):
+    _fields_ = [("L2", OrcPlano * 2), ("L3", OrcDoublet * 2), ("bottle", OrcBottle)] + \
+               [(k, C.c_double) for k in ("cosThetaMax", "r1", "r2", "img_plane", "fibre_offset",
+                                          "image_diameter", "iris_radius")] + \
+               [(k, C.c_int32) for k in ("iris_before", "iris_after", "use_bottle", "pad")]
+
+
+def build_oracle(force: bool = False) -> str:
+    if force or not os.path.exists(ORACLE_SO) or \
+            os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "ort_oracle.c")):
+        subprocess.run(["make", "-C", HERE, "oracle"], check=True, capture_output=True)
+    return ORACLE_SO
+
+
+def fill_system(osys) -> OrcSystem:
+    """opticalraytrace_amd.system.OpticalSystem -> the oracle's mirror of the Fortran types."""
+    S = OrcSystem()
+    for i in range(2):
+        p, d = osys.L2[i], osys.L3[i]
+        P = S.L2[i]
+        P.thickness, P.curve_radius, P.radius, P.fb, P.f, P.n1, P.n2 = \
+            p.thickness, p.curve_radius, p.radius, p.fb, p.f, p.n1, p.n2
+        P.centre = OrcVec(0.0, 0.0, p.centre_z)
+        P.flatNormal = OrcVec(0.0, 0.0, -1.0)
+        D = S.L3[i]
+        D.R1, D.R2, D.R3, D.radius, D.fb, D.f = d.R1, d.R2, d.R3, d.radius, d.fb, d.f
+        D.n1, D.n2, D.n3, D.thickness = d.n1, d.n2, d.n3, d.thickness
+        D.centre1 = OrcVec(0.0, 0.0, d.centre1_z)
+        D.centre2 = OrcVec(0.0, 0.0, d.centre2_z)
+        D.centre3 = OrcVec(0.0, 0.0, d.centre3_z)
+    b = osys.bottle
+    B = S.bottle
+    B.nbottle, B.ncontents, B.thickness, B.radiusa, B.radiusb = \
+        b.nbottle, b.ncontents, b.thickness, b.radiusa, b.radiusb
+    B.centre = OrcVec(*b.centre)
+    B.ellipse = 1 if b.ellipse else 0
+    s = osys.settings
+    S.cosThetaMax, S.r1, S.r2, S.img_plane = osys.cos_theta_max, osys.r1, osys.r2, osys.img_plane
+    S.fibre_offset, S.image_diameter, S.iris_radius = s.fibre_offset, s.image_diameter, s.iris_size
+    S.iris_before, S.iris_after = int(s.iris == "before"), int(s.iris == "after")
+    S.use_bottle = int(s.use_bottle)
+    return S
+
+
+def _dp(a):
+    return a.ctypes.data_as(_DP) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(_IP) if a is not None else None
+
+
+class Oracle:
+    def __init__(self, osys=None):
+        self.lib = C.CDLL(build_oracle())
+        L = self.lib
+        L.orc_sellmeier.restype = C.c_double
+        L.orc_sellmeier.argtypes = [C.c_double] * 7
+        L.orc_cauchy.restype = L.orc_dispersion.restype = C.c_double
+        L.orc_cauchy.argtypes = L.orc_dispersion.argtypes = [C.c_double] * 4
+        L.orc_uniform.restype = C.c_double
+        L.orc_uniform.argtypes = [C.c_uint64, C.c_int32, C.c_uint64, C.c_int32]
+        L.orc_trace_rays.restype = C.c_int
+        L.orc_trace_rays.argtypes = [C.POINTER(OrcSystem), C.c_int, C.c_int64, _DP, C.c_int, _DP,
+                                     C.c_int, C.c_uint64, C.c_uint64, _DP, _DP, _IP, _IP, _IP, _IP]
+        L.orc_trace.restype = C.c_int
+        L.orc_trace.argtypes = [C.POINTER(OrcSystem), C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
+                                _IP, C.POINTER(C.c_uint64), C.c_int]
+        self.sys = fill_system(osys) if osys is not None else None
+
+    def uniform(self, seed, phase, ray, draw) -> float:
+        return self.lib.orc_uniform(seed, phase, ray, draw)
+
+    def trace_rays(self, phase, n, pos_dir_in=None, u=None, draw_base=0, seed=0, first_ray=0):
+        if pos_dir_in is not None:
+            pos_dir_in = np.ascontiguousarray(pos_dir_in, dtype=np.float64)
+        nu = 0
+        if u is not None:
+            u = np.ascontiguousarray(u, dtype=np.float64)
+            nu = u.shape[0]
+        out = dict(pos_dir=np.zeros((6, n)), emitted=np.zeros((6, n)),
+                   status=np.zeros(n, np.int32), bin_xy=np.zeros((2, n), np.int32),
+                   n_isect=np.zeros(n, np.int32), n_draws=np.zeros(n, np.int32))
+        rc = self.lib.orc_trace_rays(C.byref(self.sys), phase, n, _dp(pos_dir_in), nu, _dp(u),
+                                     draw_base, seed, first_ray, _dp(out["pos_dir"]),
+                                     _dp(out["emitted"]), _ip(out["status"]), _ip(out["bin_xy"]),
+                                     _ip(out["n_isect"]), _ip(out["n_draws"]))
+        assert rc == 0
+        return out
+
+    def trace(self, phase, first, n, seed, image=None, counters=None, nthreads=0):
+        if image is None:
+            image = np.zeros((2, 401, 401), np.int32)
+        if counters is None:
+            counters = np.zeros(8, np.uint64)
+        rc = self.lib.orc_trace(C.byref(self.sys), phase, first, n, seed, _ip(image),
+                                counters.ctypes.data_as(C.POINTER(C.c_uint64)), nthreads)
+        assert rc == 0
+        return image, counters
+
+
+def reference_available() -> bool:
+    return os.path.exists(REF_SO)
+
+
+class Reference:
+    """The reference's own Fortran path (oracle/_ref/libort_ref.so)."""
+
+    def __init__(self, settings, res_dir: str):
+        self.lib = C.CDLL(REF_SO)
+        L = self.lib
+        L.ortref_init.restype = C.c_int
+        L.ortref_init.argtypes = [C.c_char_p] * 3 + [C.c_double] * 6 + \
+            [C.c_int, C.c_double, C.c_int]
+        L.ortref_constants.argtypes = [_DP]
+        L.ortref_trace_rays.argtypes = [C.c_int, C.c_int64, C.c_int, _DP, C.c_int, _DP, C.c_int,
+                                        _DP, _DP, _IP, _IP, _IP]
+        L.ortref_trace.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, _IP,
+                                   C.POINTER(C.c_int64)]
+        s = settings
+        iris_mode = {"none": 0, "before": 1, "after": 2}[s.iris]
+        rc = L.ortref_init(os.path.join(res_dir, s.bottle_file).encode(),
+                           os.path.join(res_dir, s.L2_file).encode(),
+                           os.path.join(res_dir, s.L3_file).encode(),
+                           s.wavelength, s.alpha, s.n_axicon, s.ring_width, s.image_diameter,
+                           s.fibre_offset, iris_mode, s.iris_size, int(s.use_bottle))
+        assert rc == 0
+
+    def constants(self) -> np.ndarray:
+        out = np.zeros(64)
+        self.lib.ortref_constants(_dp(out))
+        return out
+
+    def trace_rays(self, phase, n, pos_dir_in=None, u=None, draw_base=0):
+        """u must be given ([nu][n]); the Fortran side has column-major (n, nu) = same memory."""
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        nu = u.shape[0]
+        have_in = pos_dir_in is not None
+        pin = np.ascontiguousarray(pos_dir_in, dtype=np.float64) if have_in else np.zeros((6, n))
+        out = dict(pos_dir=np.zeros((6, n)), emitted=np.zeros((6, n)),
+                   status=np.zeros(n, np.int32), bin_xy=np.zeros((2, n), np.int32),
+                   n_draws=np.zeros(n, np.int32))
+        self.lib.ortref_trace_rays(phase, n, int(have_in), _dp(pin), nu, _dp(u), draw_base,
+                                   _dp(out["pos_dir"]), _dp(out["emitted"]), _ip(out["status"]),
+                                   _ip(out["bin_xy"]), _ip(out["n_draws"]))
+        return out
+
+    def trace(self, phase, first, n, seed, image=None):
+        if image is None:
+            image = np.zeros((2, 401, 401), np.int32)
+        lost = C.c_int64(0)
+        self.lib.ortref_trace(phase, first, n, seed, _ip(image), C.byref(lost))
+        return image, lost.value

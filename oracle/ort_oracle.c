@@ -1,0 +1,525 @@
+/* TEST INFRASTRUCTURE — CPU oracle (plain C restatement) of the per-ray hot path
+ * of lewisfish/OpticalRayTrace.  See ort_oracle.h for its status and who may use
+ * it.  Every function cites the reference file:line it follows.  Operation order
+ * is kept exactly as written in the Fortran (build with -ffp-contract=off): all
+ * `real` are fp64 there (reference src/Makefile:2, -freal-4-real-8).
+ */
+#define _GNU_SOURCE
+#include "ort_oracle.h"
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---------------------------------------------------------------- RNG ---- */
+/* Semantics of ran2(): one U[0,1) per call (src/random_mod.f90:39-46).  The
+ * generator itself is the compiler runtime's and is replaced by ORT-RNG-v1:
+ *   base = mix64(seed ^ (GOLDEN*phase)); z = base + GOLDEN*((ray<<24)+k+1);
+ *   u = (mix64(z) >> 11) * 2^-53.                                            */
+#define GOLDEN 0x9E3779B97F4A7C15ull
+
+static inline uint64_t mix64(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+double orc_uniform(uint64_t seed, int32_t phase, uint64_t ray, int32_t draw)
+{
+    uint64_t base = mix64(seed ^ (GOLDEN * (uint64_t)phase));
+    uint64_t z = base + GOLDEN * ((ray << 24) + (uint64_t)draw + 1ull);
+    return (double)(mix64(z) >> 11) * 0x1.0p-53;
+}
+
+typedef struct {
+    const double *table;   /* NULL => keyed */
+    int64_t stride;
+    int32_t len;
+    uint64_t seed, ray;
+    int32_t phase, k;
+} draws_t;
+
+static inline double ran2(draws_t *d)
+{
+    int32_t k = d->k++;
+    if (d->table) return k < d->len ? d->table[(int64_t)k * d->stride] : 0.5;
+    return orc_uniform(d->seed, d->phase, d->ray, k);
+}
+
+/* ranu, src/random_mod.f90:48-57 */
+static inline double ranu(draws_t *d, double a, double b) { return a + ran2(d) * (b - a); }
+
+/* ------------------------------------------------------- vector_class ---- */
+static inline orc_vec v(double x, double y, double z) { orc_vec r = {x, y, z}; return r; }
+/* vec_minus_vec :48-57, vec_add_vec :84-93 */
+static inline orc_vec vsub(orc_vec a, orc_vec b) { return v(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline orc_vec vadd(orc_vec a, orc_vec b) { return v(a.x + b.x, a.y + b.y, a.z + b.z); }
+/* vec_mult_scal / scal_mult_vec :139-160 */
+static inline orc_vec vscale(orc_vec a, double s) { return v(a.x * s, a.y * s, a.z * s); }
+/* vec_dot :96-106 */
+static inline double vdot(orc_vec a, orc_vec b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+/* magnitude_fn :175-186 — returns the NORMALISED vector, three divisions */
+static inline orc_vec vmagnitude(orc_vec a)
+{
+    double tmp = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    return v(a.x / tmp, a.y / tmp, a.z / tmp);
+}
+
+/* ----------------------------------------------------------- surfaces ---- */
+/* solveQuadratic, src/surfaces.f90:227-260 */
+static int solveQuadratic(double a, double b, double c, double *x0, double *x1)
+{
+    double discrim = b * b - 4.0 * a * c;
+    if (discrim < 0.0) return 0;
+    else if (discrim == 0.0) {
+        *x0 = -0.5 * b / a;
+        *x1 = *x0;
+    } else {
+        double q;
+        if (b > 0.0) q = -0.5 * (b + sqrt(discrim));
+        else         q = -0.5 * (b - sqrt(discrim));
+        *x0 = q / a;
+        *x1 = c / q;
+    }
+    return 1;
+}
+
+/* root choice shared by every intersect_*, src/surfaces.f90:75-86 */
+static int pick_root(double t0, double t1, double *t)
+{
+    if (t0 > t1) { double tmp = t1; t1 = t0; t0 = tmp; }
+    if (t0 < 0.0) {
+        t0 = t1;
+        if (t0 < 0.0) return 0;
+    }
+    *t = t0;
+    return 1;
+}
+
+/* intersect_sphere, src/surfaces.f90:52-89 */
+static int intersect_sphere(orc_vec orig, orc_vec dir, double *t, orc_vec centre, double radius)
+{
+    orc_vec L = vsub(orig, centre);
+    double a = vdot(dir, dir);
+    double b = 2.0 * vdot(dir, L);
+    double c = vdot(L, L) - radius * radius;
+    double t0, t1;
+    if (!solveQuadratic(a, b, c, &t0, &t1)) return 0;
+    return pick_root(t0, t1, t);
+}
+
+/* intersect_cylinder, src/surfaces.f90:91-130 — axis along x, uses y,z only */
+static int intersect_cylinder(orc_vec orig, orc_vec dir, double *t, orc_vec centre, double radius)
+{
+    orc_vec L = vsub(orig, centre);
+    double a = dir.z * dir.z + dir.y * dir.y;
+    double b = 2 * (dir.z * L.z + dir.y * L.y);
+    double c = L.z * L.z + L.y * L.y - radius * radius;
+    double t0, t1;
+    if (!solveQuadratic(a, b, c, &t0, &t1)) return 0;
+    return pick_root(t0, t1, t);
+}
+
+/* intersect_ellipse, src/surfaces.f90:133-176 */
+static int intersect_ellipse(orc_vec orig, orc_vec dir, double *t, orc_vec centre,
+                             double semia, double semib)
+{
+    double semia2div = 1. / (semia * semia);
+    double semib2div = 1. / (semib * semib);
+    orc_vec L = vsub(orig, centre);
+    double a = semia2div * (dir.z * dir.z) + semib2div * (dir.y * dir.y);
+    double b = 2 * (semia2div * dir.z * L.z + semib2div * dir.y * L.y);
+    double c = semia2div * (L.z * L.z) + semib2div * (L.y * L.y) - 1;
+    double t0, t1;
+    if (!solveQuadratic(a, b, c, &t0, &t1)) return 0;
+    return pick_root(t0, t1, t);
+}
+
+/* fresnel, src/surfaces.f90:336-372 */
+static double fresnel(orc_vec I, orc_vec N, double n1, double n2)
+{
+    double costt = fabs(vdot(I, N));
+    double sintt = sqrt(1. - costt * costt);
+    double sint2 = n1 / n2 * sintt;
+    double tir;
+    if (sint2 > 1.) return 1.0;
+    else if (costt == 1.) return 0.;
+    else {
+        sint2 = (n1 / n2) * sintt;
+        double cost2 = sqrt(1. - sint2 * sint2);
+        double r1 = fabs((n1 * costt - n2 * cost2) / (n1 * costt + n2 * cost2));
+        double r2 = fabs((n1 * cost2 - n2 * costt) / (n1 * cost2 + n2 * costt));
+        double f1 = r1 * r1;
+        double f2 = r2 * r2;
+        tir = 0.5 * (f1 + f2);
+        if (isnan(tir) || tir > 1. || tir < 0.) tir = 1.;
+        return tir;
+    }
+}
+
+/* reflect, src/surfaces.f90:285-300 */
+static orc_vec reflect(orc_vec I, orc_vec N)
+{
+    double s = 2. * vdot(N, I);
+    return vsub(I, vscale(N, s));
+}
+
+/* refract, src/surfaces.f90:303-333 */
+static orc_vec refract(orc_vec I, orc_vec N, double eta)
+{
+    orc_vec Ntmp = N;
+    double c1 = vdot(Ntmp, I);
+    if (c1 < 0.) c1 = -c1;
+    else Ntmp = vscale(N, -1.);
+    double c2 = sqrt(1.0 - eta * eta * (1.0 - c1 * c1));
+    return vadd(vscale(I, eta), vscale(Ntmp, eta * c1 - c2));
+}
+
+/* reflect_refract, src/surfaces.f90:262-282 — consumes exactly one draw */
+static void reflect_refract(orc_vec *I, orc_vec N, double n1, double n2, int *rflag, draws_t *d)
+{
+    *rflag = 0;
+    if (ran2(d) <= fresnel(*I, N, n1, n2)) {
+        *I = reflect(*I, N);
+        *rflag = 1;
+    } else {
+        *I = refract(*I, N, n1 / n2);
+    }
+}
+
+/* --------------------------------------------------------------- lens ---- */
+/* Sellmeier / cauchy / dispersion, src/lens.f90:647-695 */
+double orc_sellmeier(double wave, double b1, double b2, double b3, double c1, double c2, double c3)
+{
+    double w = wave * 1e6;
+    double wave2 = w * w;
+    double a = (b1 * wave2) / (wave2 - c1);
+    double b = (b2 * wave2) / (wave2 - c2);
+    double c = (b3 * wave2) / (wave2 - c3);
+    return sqrt(1.0 + (a + b + c));
+}
+
+double orc_cauchy(double wave, double a, double b, double c)
+{
+    double w = wave * 1e6;
+    /* wavetmp**(-2), **(-4): integer powers, evaluated as reciprocals of products */
+    return a + b * (1.0 / (w * w)) + c * (1.0 / ((w * w) * (w * w)));
+}
+
+double orc_dispersion(double wave, double a, double b, double c)
+{
+    double w = wave * 1e6;
+    double wave2 = w * w;
+    return a - b * wave2 + (c / wave2);
+}
+
+/* bottle_forward_sub, src/lens.f90:230-350 (scatter branches inactive) */
+static int bottle_forward(const orc_bottle *B, orc_vec *pos, orc_vec *dir, draws_t *d, int *nis)
+{
+    double t;
+    int flag;
+    orc_vec orig, normal;
+
+    if (B->ellipse) {
+        double rad1 = B->radiusa - B->thickness;
+        double rad2 = B->radiusb - B->thickness;
+        flag = intersect_ellipse(*pos, *dir, &t, B->centre, rad1, rad2);
+    } else {
+        flag = intersect_cylinder(*pos, *dir, &t, B->centre, B->radiusa - B->thickness);
+    }
+    (*nis)++;
+    if (!flag) return 1;
+
+    *pos = vadd(*pos, vscale(*dir, t));
+    orig = *pos;
+    orig.x = B->centre.x;
+    normal = vsub(B->centre, orig);
+    normal = vmagnitude(normal);
+    reflect_refract(dir, normal, B->ncontents, B->nbottle, &flag, d);
+    if (flag) return 1;
+
+    if (B->ellipse) flag = intersect_ellipse(*pos, *dir, &t, B->centre, B->radiusa / 2., B->radiusb / 2.);
+    else            flag = intersect_cylinder(*pos, *dir, &t, B->centre, B->radiusa);
+    (*nis)++;
+    if (!flag) return 1;
+
+    *pos = vadd(*pos, vscale(*dir, t));
+    orig = *pos;
+    orig.x = B->centre.x;
+    normal = vsub(B->centre, orig);
+    normal = vmagnitude(normal);
+    reflect_refract(dir, normal, B->nbottle, 1.0, &flag, d);
+    if (flag) return 1;
+    return 0;
+}
+
+/* plano_forward_sub, src/lens.f90:425-481 */
+static int plano_forward(const orc_plano *P, orc_vec *pos, orc_vec *dir, draws_t *d, int *nis)
+{
+    double a = P->centre.z + P->curve_radius - P->thickness;
+    double dd = (a - pos->z) / dir->z;
+    *pos = vadd(*pos, vscale(*dir, dd));
+    (*nis)++;
+    double r = sqrt(pos->x * pos->x + pos->y * pos->y);
+    if (r > P->radius) return 1;
+
+    int flag;
+    reflect_refract(dir, P->flatNormal, P->n1, P->n2, &flag, d);   /* flag ignored, :458-459 */
+
+    double t;
+    flag = intersect_sphere(*pos, *dir, &t, P->centre, P->curve_radius);
+    (*nis)++;
+    if (!flag) return 1;
+    *pos = vadd(*pos, vscale(*dir, t));
+
+    orc_vec curvedNormal = vsub(P->centre, *pos);
+    curvedNormal = vmagnitude(curvedNormal);
+    reflect_refract(dir, curvedNormal, P->n2, P->n1, &flag, d);
+    if (flag) return 1;
+    return 0;
+}
+
+/* doublet_forward_sub, src/lens.f90:531-645.  Returns 0 ok, 1 skip, 2 "Help3". */
+static int doublet_forward(const orc_doublet *D, orc_vec *pos, orc_vec *dir, draws_t *d, int *nis,
+                           int iris_before, int iris_after, double iris_radius)
+{
+    orc_vec normal, origpos;
+    int flag;
+    double t, r;
+
+    if (iris_before) {
+        origpos = *pos;
+        t = ((D->centre1.z - D->R1) - pos->z) / dir->z;
+        *pos = vadd(*pos, vscale(*dir, t));
+        (*nis)++;
+        r = sqrt(pos->x * pos->x + pos->y * pos->y);
+        if (r > D->radius * iris_radius) return 1;
+        *pos = origpos;
+    }
+
+    flag = intersect_sphere(*pos, *dir, &t, D->centre1, D->R1);
+    (*nis)++;
+    if (!flag) return 1;
+    *pos = vadd(*pos, vscale(*dir, t));
+    r = sqrt(pos->x * pos->x + pos->y * pos->y);
+    if (r > (D->radius * 1.0)) return 1;
+
+    normal = vsub(*pos, D->centre1);
+    normal = vmagnitude(normal);
+    reflect_refract(dir, normal, D->n1, D->n2, &flag, d);
+    if (flag) return 1;
+
+    flag = intersect_sphere(*pos, *dir, &t, D->centre2, D->R2);
+    (*nis)++;
+    if (!flag) return 1;
+    *pos = vadd(*pos, vscale(*dir, t));
+    normal = vsub(D->centre2, *pos);
+    normal = vmagnitude(normal);
+    reflect_refract(dir, normal, D->n2, D->n3, &flag, d);
+    if (flag) return 1;
+
+    flag = intersect_sphere(*pos, *dir, &t, D->centre3, D->R3);
+    (*nis)++;
+    if (!flag) return 2;                                  /* error stop "Help3", :617 */
+    *pos = vadd(*pos, vscale(*dir, t));
+    normal = vsub(D->centre3, *pos);
+    normal = vmagnitude(normal);
+    reflect_refract(dir, normal, D->n3, D->n1, &flag, d);
+    if (flag) return 1;
+
+    if (iris_after) {
+        origpos = *pos;
+        t = ((D->centre3.z + D->R3) - pos->z) / dir->z;
+        *pos = vadd(*pos, vscale(*dir, t));
+        (*nis)++;
+        r = sqrt(pos->x * pos->x + pos->y * pos->y);
+        if (r > D->radius * iris_radius) return 1;
+        *pos = origpos;
+    }
+    return 0;
+}
+
+/* telescope, src/optics_system.f90:6-52.  Returns 0 ok, 1 skip, 2 Help3. */
+static int telescope(const orc_system *S, int ph, orc_vec *pos, orc_vec *dir, draws_t *d, int *nis)
+{
+    int rc = plano_forward(&S->L2[ph], pos, dir, d, nis);
+    if (rc) return rc;
+    rc = doublet_forward(&S->L3[ph], pos, dir, d, nis, S->iris_before, S->iris_after, S->iris_radius);
+    if (rc) return rc;
+    double dd = ((S->img_plane + S->fibre_offset) - pos->z) / dir->z;
+    *pos = vadd(*pos, vscale(*dir, dd));
+    (*nis)++;
+    return 0;
+}
+
+/* ------------------------------------------------------------ sources ---- */
+static const double PI_F = 3.14159265358979323846;   /* 4.*atan(1.), src/constants.f90:5 */
+
+/* point, src/sourceMod.f90:12-47 (offset absent at the call site main.f90:136) */
+static void emit_point(double cosThetaMax, orc_vec *pos, orc_vec *dir, draws_t *d)
+{
+    const double twopi = 2. * PI_F;
+    double phi = twopi * ran2(d);
+    double cosp = cos(phi);
+    double sinp = sin(phi);
+    double ran = ran2(d);
+    double cost = (1.0 - ran) + ran * cosThetaMax;
+    double sint = sqrt(1.0 - cost * cost);
+    *dir = v(sint * cosp, sint * sinp, cost);
+    *pos = v(0.0, 0.0, 0.0 + 0.0);
+}
+
+/* ring, src/sourceMod.f90:250-300 */
+static void emit_ring(const orc_system *S, orc_vec *pos, orc_vec *dir, draws_t *d)
+{
+    const double twopi = 2. * PI_F;
+    const orc_plano *lens = &S->L2[0];
+    double Ra = S->bottle.radiusa, Rb = S->bottle.radiusb, off = S->bottle.centre.z;
+    double r = ranu(d, S->r1, S->r2);
+    double theta = ran2(d) * twopi;
+    double posx = sqrt(r) * cos(theta);
+    double posy = sqrt(r) * sin(theta);
+    double posz;
+    if (S->bottle.ellipse) {
+        double q = posy * Ra / Rb;
+        posz = off + sqrt(Ra * Ra - q * q);
+    } else {
+        posz = off + sqrt(Ra * Ra - posy * posy);
+    }
+    *pos = v(posx, posy, posz);
+
+    double rl = lens->radius + 10e-3;
+    r = ranu(d, 0., rl * rl);
+    theta = ran2(d) * twopi;
+    /* flang 22 -O2 lowers THIS sin/cos pair (and only this one) to glibc sincos(),
+     * whose results differ from sin()/cos() by 1 ulp for ~0.1 % of arguments; it is
+     * used here so that the oracle equals oracle/_ref bit for bit on this image.
+     * Which libm entry a compiler picks is outside the reference's definition. */
+    double st, ct;
+    sincos(theta, &st, &ct);
+    posx = sqrt(r) * ct;
+    posy = sqrt(r) * st;
+    orc_vec lp = v(posx, posy, lens->fb);
+    double ex = lp.x - pos->x, ey = lp.y - pos->y, ez = lp.z - pos->z;
+    double dist = sqrt(ex * ex + ey * ey + ez * ez);
+    *dir = v((lp.x - pos->x) / dist, (lp.y - pos->y) / dist, (lp.z - pos->z) / dist);
+    *dir = vmagnitude(*dir);
+}
+
+/* -------------------------------------------------------------- image ---- */
+/* makeImage2D, src/imageMod.f90:19-58.  Returns status, writes the bin. */
+static int make_image(orc_vec dir, orc_vec pos, double diameter, int *xp_out, int *yp_out)
+{
+    orc_vec n = v(0., 0., -1.);
+    n = vmagnitude(n);
+    orc_vec d = vmagnitude(dir);
+    d = vscale(d, -1.);
+    double top = vdot(n, d);
+    double bottom = sqrt(vdot(d, d)) * sqrt(vdot(n, n));
+    double angle = acos(top / bottom);
+    double na = asin(0.22);
+    if (angle > na) return ORC_NA_REJECT;
+    double binwid = diameter / 401.;
+    if (pos.x > 1000 || pos.y > 1000) return ORC_OFF_GRID;
+    double fx = floor(pos.x / binwid), fy = floor(pos.y / binwid);
+    if (!(fabs(fx) <= 200.) || !(fabs(fy) <= 200.)) return ORC_OFF_GRID;
+    *xp_out = (int)fx;
+    *yp_out = (int)fy;
+    return ORC_BINNED;
+}
+
+/* ---------------------------------------------------------- loop body ---- */
+/* one iteration of src/main.f90:90-109 (phase 1) or :127-162 (phase 2) */
+static int one_ray(const orc_system *S, int phase, int have_in, orc_vec *pos, orc_vec *dir,
+                   draws_t *d, int *nis, int *xp, int *yp, orc_vec *epos, orc_vec *edir)
+{
+    int ph = phase - 1, rc;
+    *nis = 0;
+    if (!have_in) {
+        if (phase == 1) emit_ring(S, pos, dir, d);
+        else            emit_point(S->cosThetaMax, pos, dir, d);
+    }
+    *epos = *pos; *edir = *dir;
+    if (phase == 2 && S->use_bottle) {
+        if (bottle_forward(&S->bottle, pos, dir, d, nis)) return ORC_LOST_BOTTLE;
+    }
+    rc = telescope(S, ph, pos, dir, d, nis);
+    if (rc == 1) return ORC_LOST_TELESCOPE;
+    if (rc == 2) return ORC_HELP3;
+    return make_image(*dir, *pos, S->image_diameter, xp, yp);
+}
+
+int orc_trace_rays(const orc_system *sys, int phase, int64_t n,
+                   const double *pos_dir_in, int nu, const double *u, int draw_base,
+                   uint64_t seed, uint64_t first_ray,
+                   double *pos_dir_out, double *emitted_out, int32_t *status,
+                   int32_t *bin_xy, int32_t *n_isect, int32_t *n_draws)
+{
+    if (!sys || (phase != 1 && phase != 2) || n < 0) return -1;
+    for (int64_t i = 0; i < n; i++) {
+        draws_t d;
+        memset(&d, 0, sizeof d);
+        if (u) { d.table = u + i; d.stride = n; d.len = nu; }
+        d.seed = seed; d.ray = first_ray + (uint64_t)i; d.phase = phase; d.k = draw_base;
+        orc_vec pos = {0, 0, 0}, dir = {0, 0, 0}, ep, ed;
+        if (pos_dir_in) {
+            pos = v(pos_dir_in[0 * n + i], pos_dir_in[1 * n + i], pos_dir_in[2 * n + i]);
+            dir = v(pos_dir_in[3 * n + i], pos_dir_in[4 * n + i], pos_dir_in[5 * n + i]);
+        }
+        int nis, xp = -9999, yp = -9999;
+        int st = one_ray(sys, phase, pos_dir_in != NULL, &pos, &dir, &d, &nis, &xp, &yp, &ep, &ed);
+        if (pos_dir_out) {
+            pos_dir_out[0 * n + i] = pos.x; pos_dir_out[1 * n + i] = pos.y; pos_dir_out[2 * n + i] = pos.z;
+            pos_dir_out[3 * n + i] = dir.x; pos_dir_out[4 * n + i] = dir.y; pos_dir_out[5 * n + i] = dir.z;
+        }
+        if (emitted_out) {
+            emitted_out[0 * n + i] = ep.x; emitted_out[1 * n + i] = ep.y; emitted_out[2 * n + i] = ep.z;
+            emitted_out[3 * n + i] = ed.x; emitted_out[4 * n + i] = ed.y; emitted_out[5 * n + i] = ed.z;
+        }
+        if (status) status[i] = st;
+        if (bin_xy) { bin_xy[i] = xp; bin_xy[n + i] = yp; }
+        if (n_isect) n_isect[i] = nis;
+        if (n_draws) n_draws[i] = d.k;
+    }
+    return 0;
+}
+
+int orc_trace(const orc_system *sys, int phase, uint64_t first, uint64_t n, uint64_t seed,
+              int32_t *image, uint64_t *counters, int nthreads)
+{
+    if (!sys || (phase != 1 && phase != 2) || !image || !counters) return -1;
+    uint64_t lost = 0, isect = 0, binned = 0, help3 = 0;
+    int32_t *layer = image + (size_t)(phase - 1) * 401 * 401;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(static) reduction(+:lost, isect, binned, help3)
+    for (uint64_t i = 0; i < n; i++) {
+        draws_t d;
+        memset(&d, 0, sizeof d);
+        d.seed = seed; d.ray = first + i; d.phase = phase; d.k = 0;
+        orc_vec pos, dir, ep, ed;
+        int nis, xp = 0, yp = 0;
+        int st = one_ray(sys, phase, 0, &pos, &dir, &d, &nis, &xp, &yp, &ep, &ed);
+        isect += (uint64_t)nis;
+        if (st == ORC_LOST_BOTTLE || st == ORC_LOST_TELESCOPE || st == ORC_HELP3) lost++;
+        if (st == ORC_HELP3) help3++;
+        if (st == ORC_BINNED) {
+            binned++;
+#pragma omp atomic
+            layer[(xp + 200) + 401 * (yp + 200)]++;
+        }
+    }
+    counters[phase - 1] += lost;
+    counters[2 + phase - 1] += isect;
+    counters[4 + phase - 1] += binned;
+    counters[6 + phase - 1] += help3;
+    return 0;
+}

@@ -1,0 +1,66 @@
+/* TEST INFRASTRUCTURE — not part of the product.
+ *
+ * Uniform-draw source injected into the *reference's own* Fortran modules when
+ * they are compiled into oracle/_ref/libort_ref.so (see oracle/Makefile).
+ *
+ * Why: every optical surface in the reference consumes one U[0,1) from
+ * `ran2()` (reference src/surfaces.f90:275, src/random_mod.f90:39-46), and
+ * `ran2()` is the compiler runtime's `random_number`, whose stream depends on
+ * the compiler and the thread count.  Two implementations can only be compared
+ * ray by ray when they are fed the same draws, so the harness replaces module
+ * `random` (and nothing else) by oracle/ref/ref_random.f90, which forwards to
+ * the functions below.  Two modes:
+ *
+ *   table mode  — the k-th draw of the current ray is u[k] from a caller table
+ *   keyed mode  — the k-th draw of ray i of phase p is ORT-RNG-v1(seed,p,i,k)
+ *
+ * ORT-RNG-v1 (the same definition is restated, independently, in
+ * oracle/ort_oracle.c and in the HIP kernels):
+ *   base = mix64(seed ^ (GOLDEN * phase))
+ *   z    = base + GOLDEN * ((ray << 24) + k + 1)
+ *   u    = (mix64(z) >> 11) * 2^-53,   mix64 = SplitMix64 finaliser
+ */
+#include <stdint.h>
+#include <stddef.h>
+
+#define GOLDEN 0x9E3779B97F4A7C15ull
+
+static inline uint64_t mix64(uint64_t z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+static _Thread_local const double *tl_table;   /* table mode when non-NULL */
+static _Thread_local int64_t  tl_table_stride;
+static _Thread_local int32_t  tl_table_len;
+static _Thread_local uint64_t tl_zray;         /* keyed mode: base + GOLDEN*(ray<<24) */
+static _Thread_local int32_t  tl_draw;         /* draws consumed by the current ray */
+
+void ortref_rng_table(const double *u, int64_t stride, int32_t len, int32_t first_draw)
+{
+    tl_table = u; tl_table_stride = stride; tl_table_len = len; tl_draw = first_draw;
+}
+
+void ortref_rng_key(uint64_t seed, int32_t phase, uint64_t ray, int32_t first_draw)
+{
+    uint64_t base = mix64(seed ^ (GOLDEN * (uint64_t)phase));
+    tl_table = NULL;
+    tl_zray = base + GOLDEN * (ray << 24);
+    tl_draw = first_draw;
+}
+
+int32_t ortref_rng_draws(void) { return tl_draw; }
+
+double ortref_draw(void)
+{
+    int32_t k = tl_draw++;
+    if (tl_table) {
+        if (k >= tl_table_len) return 0.5;   /* never reached on the checked path */
+        return tl_table[(int64_t)k * tl_table_stride];
+    }
+    uint64_t z = tl_zray + GOLDEN * (uint64_t)(k + 1);
+    return (double)(mix64(z) >> 11) * 0x1.0p-53;
+}
