@@ -83,6 +83,8 @@ typedef struct ort_system {
     /* image, src/imageMod.f90:19-58 */
     double bin_width;             /* image_diameter / 401. */
     double na_angle;              /* asin(0.22) */
+    double na_cos_min;            /* smallest x with acos(x) <= na_angle under the host libm: the
+                                     NA test of src/imageMod.f90:39-44 as one compare per ray */
     double twopi;                 /* 2.*4.*atan(1.) (src/constants.f90:5) */
 } ort_system;
 
@@ -160,6 +162,10 @@ int ort_trace_rays(ort_ctx *ctx, int phase, int64_t n,
  * equivalent of the OpenMP atomic image + reduction (src/main.f90:88,
  * src/imageMod.f90:55). */
 int ort_read(ort_ctx *ctx, int32_t *image, uint64_t *counters);
+/* Use caller-owned DEVICE buffers (e.g. torch tensors: int32[ORT_IMAGE_BINS],
+ * int64[ORT_NUM_COUNTERS]) as the accumulators from now on; they are not zeroed
+ * and not freed by the context.  NULL, NULL returns to the context's own. */
+int ort_attach_buffers(ort_ctx *ctx, void *d_image, void *d_counters);
 int ort_device_image(ort_ctx *ctx, void **d_image);
 int ort_device_counters(ort_ctx *ctx, void **d_counters);
 int ort_synchronize(ort_ctx *ctx);

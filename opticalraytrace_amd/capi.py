@@ -46,7 +46,8 @@ class OrtSystem(C.Structure):
                 ("ring_lens_r2", C.c_double), ("ring_lens_z", C.c_double),
                 ("ring_bottle_ra", C.c_double), ("ring_bottle_rb", C.c_double),
                 ("ring_bottle_z", C.c_double),
-                ("bin_width", C.c_double), ("na_angle", C.c_double), ("twopi", C.c_double)]
+                ("bin_width", C.c_double), ("na_angle", C.c_double), ("na_cos_min", C.c_double),
+                ("twopi", C.c_double)]
 
 
 def pack_system(osys: OpticalSystem) -> OrtSystem:
@@ -75,6 +76,7 @@ def pack_system(osys: OpticalSystem) -> OrtSystem:
     cs.ring_bottle_ra, cs.ring_bottle_rb, cs.ring_bottle_z = b.radiusa, b.radiusb, b.centre[2]
     cs.bin_width = osys.bin_width
     cs.na_angle = osys.na_angle
+    cs.na_cos_min = osys.na_cos_min
     cs.twopi = TWOPI
     return cs
 
@@ -113,6 +115,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ort_trace_rays": (C.c_int, [vp, i32, i64, _DP, i32, _DP, i32, u64, u64,
                                      _DP, _DP, _IP, _IP, _IP, _IP]),
         "ort_read": (C.c_int, [vp, _IP, C.POINTER(C.c_uint64)]),
+        "ort_attach_buffers": (C.c_int, [vp, vp, vp]),
         "ort_device_image": (C.c_int, [vp, C.POINTER(vp)]),
         "ort_device_counters": (C.c_int, [vp, C.POINTER(vp)]),
         "ort_synchronize": (C.c_int, [vp]),
@@ -131,7 +134,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = ["ort_abi_version", "ort_last_error", "ort_device_count", "ort_create",
                     "ort_destroy", "ort_set_system", "ort_reset", "ort_trace", "ort_emit",
-                    "ort_trace_resident", "ort_trace_rays", "ort_read", "ort_device_image",
+                    "ort_trace_resident", "ort_trace_rays", "ort_read", "ort_attach_buffers",
+                    "ort_device_image",
                     "ort_device_counters", "ort_synchronize", "ort_last_kernel_ms",
                     "ort_set_timing"]
 
@@ -212,6 +216,11 @@ class Context:
         _check(self.lib, self.lib.ort_read(self._h, _iptr(image),
                                            counters.ctypes.data_as(C.POINTER(C.c_uint64))), "ort_read")
         return image, counters
+
+    def attach_buffers(self, d_image: int, d_counters: int) -> None:
+        _check(self.lib, self.lib.ort_attach_buffers(
+            self._h, C.c_void_p(d_image) if d_image else None,
+            C.c_void_p(d_counters) if d_counters else None), "ort_attach_buffers")
 
     def device_image_ptr(self) -> int:
         p = C.c_void_p()

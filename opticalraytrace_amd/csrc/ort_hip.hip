@@ -1,0 +1,485 @@
+// ort_hip.hip — HIP kernels (gfx950 / CDNA4, wave64) and the C ABI of include/ort.h.
+//
+// Kernels
+//   trace_kernel<MODE>   one thread per ray inside 64-lane wavefronts, grid-stride
+//                        over the global ray index range; the whole ort_system
+//                        (surface list + emitter + image constants, ~2 KB) is staged
+//                        into LDS once per workgroup; the ray (pos, dir) lives in
+//                        VGPRs from emission to binning; the image is an int32
+//                        histogram in HBM updated with global atomics; the run
+//                        counters are reduced per workgroup in LDS and added once.
+//     MODE_FUSED     emit in-kernel (src/main.f90:90-109 / :127-162 whole body)
+//     MODE_RESIDENT  ray bundle read from HBM, SoA fp64 [6][n], coalesced
+//     MODE_DEBUG     parity entry: per-ray outputs, no binning side effect
+//   emit_kernel          fills an SoA bundle with the phase's source
+//
+// No MFMA: there is no contraction anywhere on this path; the kernel
+// is bound by fp64 VALU issue (divide / sqrt sequences), not by HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include "../../include/ort.h"
+#include "ort_device.h"
+
+using namespace ort;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBlocks = 256 * 8;     // 256 CUs x 8 workgroups: >> 256 workgroups fills all 8 XCDs
+
+enum { MODE_FUSED = 0, MODE_RESIDENT = 1, MODE_DEBUG = 2 };
+
+struct TraceArgs {
+    const ort_system *sys;       // device copy
+    int32_t *image;              // [2][401][401]
+    unsigned long long *counters;
+    uint64_t first_ray, n_rays, rng_base;
+    int phase, draw_base;
+    // resident / debug inputs
+    const double *pos_dir_in;    // SoA [6][n] or null
+    const double *u;             // [nu][n] or null
+    int nu;
+    // debug outputs (any may be null)
+    double *pos_dir_out, *emitted_out;
+    int32_t *status, *bin_xy, *n_isect, *n_draws;
+};
+
+// cooperative copy of the system into LDS, 8 bytes per thread per pass
+__device__ inline void stage_system(ort_system &dst, const ort_system *src)
+{
+    constexpr int words = sizeof(ort_system) / 8;
+    static_assert(sizeof(ort_system) % 8 == 0, "ort_system must be a whole number of 8-byte words");
+    const uint64_t *s = reinterpret_cast<const uint64_t *>(src);
+    uint64_t *d = reinterpret_cast<uint64_t *>(&dst);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) d[i] = s[i];
+    __syncthreads();
+}
+
+template <int MODE, class D>
+__device__ inline int trace_one(const ort_system &S, int phase, bool have_in, Ray &r, D &draws,
+                                int &nis, int &xp, int &yp, Ray &emitted)
+{
+    if (!have_in) {
+        if (phase == 1) emit_ring(S, r, draws);
+        else emit_point(S, r, draws);
+    }
+    if (MODE == MODE_DEBUG) emitted = r;
+    const int ns = S.n_surfaces[phase - 1];
+    const ort_surface *surf = S.surfaces[phase - 1];
+    int st = ORT_ST_LOST_TELESCOPE;
+    for (int k = 0; k < ns; ++k) {
+        st = surface_step(S, surf[k], r, draws, nis, xp, yp);
+        if (st >= 0) break;
+    }
+    return st;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void trace_kernel(TraceArgs a)
+{
+    __shared__ ort_system S;
+    __shared__ unsigned int blk[4];       // lost, isect, binned, help3
+    stage_system(S, a.sys);
+    if (MODE != MODE_DEBUG) {
+        if (threadIdx.x < 4) blk[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    unsigned int lost = 0, isect = 0, binned = 0, help3 = 0;
+    int32_t *layer = a.image + (size_t)(a.phase - 1) * ORT_IMAGE_N * ORT_IMAGE_N;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n = a.n_rays;
+
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        Ray r, em;
+        int nis = 0, xp = -9999, yp = -9999, st;
+        bool have_in = false;
+        if (MODE != MODE_FUSED && a.pos_dir_in) {
+            have_in = true;
+            r.pos = {a.pos_dir_in[0 * n + i], a.pos_dir_in[1 * n + i], a.pos_dir_in[2 * n + i]};
+            r.dir = {a.pos_dir_in[3 * n + i], a.pos_dir_in[4 * n + i], a.pos_dir_in[5 * n + i]};
+        }
+        int kdraws;
+        if (MODE == MODE_DEBUG) {
+            Draws d;
+            if (a.u) d.init_table(a.u + i, (int64_t)n, a.nu, a.draw_base);
+            else d.init_keyed(a.rng_base, a.first_ray + i, a.draw_base);
+            st = trace_one<MODE>(S, a.phase, have_in, r, d, nis, xp, yp, em);
+            kdraws = d.k;
+        } else {
+            KeyedDraws d;
+            d.init_keyed(a.rng_base, a.first_ray + i, have_in ? a.draw_base : 0);
+            st = trace_one<MODE>(S, a.phase, have_in, r, d, nis, xp, yp, em);
+            kdraws = d.k;
+        }
+        if (MODE == MODE_DEBUG) {
+            if (a.pos_dir_out) {
+                a.pos_dir_out[0 * n + i] = r.pos.x; a.pos_dir_out[1 * n + i] = r.pos.y;
+                a.pos_dir_out[2 * n + i] = r.pos.z; a.pos_dir_out[3 * n + i] = r.dir.x;
+                a.pos_dir_out[4 * n + i] = r.dir.y; a.pos_dir_out[5 * n + i] = r.dir.z;
+            }
+            if (a.emitted_out) {
+                a.emitted_out[0 * n + i] = em.pos.x; a.emitted_out[1 * n + i] = em.pos.y;
+                a.emitted_out[2 * n + i] = em.pos.z; a.emitted_out[3 * n + i] = em.dir.x;
+                a.emitted_out[4 * n + i] = em.dir.y; a.emitted_out[5 * n + i] = em.dir.z;
+            }
+            if (a.status) a.status[i] = st;
+            if (a.bin_xy) { a.bin_xy[i] = xp; a.bin_xy[n + i] = yp; }
+            if (a.n_isect) a.n_isect[i] = nis;
+            if (a.n_draws) a.n_draws[i] = kdraws;
+        } else {
+            (void)kdraws;
+            isect += (unsigned)nis;
+            if (st == ORT_ST_BINNED) {
+                binned++;
+                atomicAdd(&layer[(xp + 200) + ORT_IMAGE_N * (yp + 200)], 1);   // imageMod.f90:55-56
+            } else if (st >= ORT_ST_LOST_BOTTLE) {
+                lost++;                                                       // optics_system.f90:32,42; main.f90:151
+                if (st == ORT_ST_HELP3) help3++;
+            }
+        }
+    }
+    if (MODE != MODE_DEBUG) {
+        atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect);
+        atomicAdd(&blk[2], binned); atomicAdd(&blk[3], help3);
+        __syncthreads();
+        if (threadIdx.x < 4 && blk[threadIdx.x])
+            atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int phase,
+                                                      uint64_t first_ray, uint64_t n, uint64_t rng_base,
+                                                      double *pos_dir)
+{
+    __shared__ ort_system S;
+    stage_system(S, sys);
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        KeyedDraws d;
+        d.init_keyed(rng_base, first_ray + i, 0);
+        Ray r;
+        if (phase == 1) emit_ring(S, r, d);
+        else emit_point(S, r, d);
+        pos_dir[0 * n + i] = r.pos.x; pos_dir[1 * n + i] = r.pos.y; pos_dir[2 * n + i] = r.pos.z;
+        pos_dir[3 * n + i] = r.dir.x; pos_dir[4 * n + i] = r.dir.y; pos_dir[5 * n + i] = r.dir.z;
+    }
+}
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (e != hipSuccess) snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(g_err, sizeof g_err, "%s", what);
+    return code;
+}
+
+#define HIP_TRY(expr)                                              \
+    do {                                                           \
+        hipError_t e_ = (expr);                                    \
+        if (e_ != hipSuccess) return fail(ORT_E_HIP, #expr, e_);   \
+    } while (0)
+
+int grid_for(uint64_t n)
+{
+    uint64_t b = (n + kBlock - 1) / kBlock;
+    if (b < 1) b = 1;
+    if (b > (uint64_t)kMaxBlocks) b = kMaxBlocks;
+    return (int)b;
+}
+
+int check_system(const ort_system *sys)
+{
+    if (!sys) return fail(ORT_E_INVALID, "system is NULL");
+    if (sys->abi_version != ORT_ABI_VERSION) return fail(ORT_E_INVALID, "ort_system.abi_version mismatch");
+    for (int p = 0; p < 2; ++p) {
+        int n = sys->n_surfaces[p];
+        if (n < 1 || n > ORT_MAX_SURFACES) return fail(ORT_E_INVALID, "n_surfaces out of range");
+        for (int k = 0; k < n; ++k) {
+            int kind = sys->surfaces[p][k].kind;
+            if (kind < ORT_SURF_PLANE || kind > ORT_SURF_IMAGE) return fail(ORT_E_INVALID, "bad surface kind");
+            if ((kind == ORT_SURF_IMAGE) != (k == n - 1))
+                return fail(ORT_E_INVALID, "the image plane must be the last surface, and only the last");
+        }
+    }
+    return ORT_OK;
+}
+
+}  // namespace
+
+struct ort_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    ort_system *d_sys;
+    int32_t *d_image, *own_image;
+    unsigned long long *d_counters, *own_counters;
+    bool timing;
+    hipEvent_t ev[3][2];
+    bool ev_valid[3];
+};
+
+extern "C" {
+
+int ort_abi_version(void) { return ORT_ABI_VERSION; }
+
+const char *ort_last_error(void) { return g_err; }
+
+int ort_device_count(int *count)
+{
+    if (!count) return fail(ORT_E_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(ORT_E_NODEVICE, "hipGetDeviceCount", e); }
+    *count = n;
+    return ORT_OK;
+}
+
+int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out)
+{
+    if (!out) return fail(ORT_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = check_system(sys);
+    if (rc) return rc;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(ORT_E_NODEVICE, "no HIP device: the trace path has no CPU fallback");
+    if (device < 0 || device >= n) return fail(ORT_E_NODEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    ort_ctx *c = new (std::nothrow) ort_ctx();
+    if (!c) return fail(ORT_E_NOMEM, "host allocation failed");
+    memset(c, 0, sizeof *c);
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIP_TRY(hipMalloc(&c->d_sys, sizeof(ort_system)));
+    HIP_TRY(hipMalloc(&c->own_image, ORT_IMAGE_BINS * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->own_counters, ORT_NUM_COUNTERS * sizeof(unsigned long long)));
+    c->d_image = c->own_image;
+    c->d_counters = c->own_counters;
+    for (int k = 0; k < 3; ++k) {
+        HIP_TRY(hipEventCreate(&c->ev[k][0]));
+        HIP_TRY(hipEventCreate(&c->ev[k][1]));
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_sys, sys, sizeof(ort_system), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_image, 0, ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, ORT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = c;
+    return ORT_OK;
+}
+
+int ort_destroy(ort_ctx *c)
+{
+    if (!c) return ORT_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 3; ++k) { (void)hipEventDestroy(c->ev[k][0]); (void)hipEventDestroy(c->ev[k][1]); }
+    (void)hipFree(c->d_sys); (void)hipFree(c->own_image); (void)hipFree(c->own_counters);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return ORT_OK;
+}
+
+int ort_set_system(ort_ctx *c, const ort_system *sys)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    int rc = check_system(sys);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    // the copy source must stay valid until the copy has run: synchronise
+    HIP_TRY(hipMemcpyAsync(c->d_sys, sys, sizeof(ort_system), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORT_OK;
+}
+
+int ort_reset(ort_ctx *c)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_image, 0, ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, ORT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
+    return ORT_OK;
+}
+
+static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
+{
+    a.sys = c->d_sys; a.image = c->d_image; a.counters = c->d_counters;
+    if (a.n_rays == 0) return ORT_OK;
+    int grid = grid_for(a.n_rays);
+    if (c->timing && evk >= 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
+    switch (mode) {
+    case MODE_FUSED: hipLaunchKernelGGL(trace_kernel<MODE_FUSED>, dim3(grid), dim3(kBlock), 0, c->stream, a); break;
+    case MODE_RESIDENT: hipLaunchKernelGGL(trace_kernel<MODE_RESIDENT>, dim3(grid), dim3(kBlock), 0, c->stream, a); break;
+    default: hipLaunchKernelGGL(trace_kernel<MODE_DEBUG>, dim3(grid), dim3(kBlock), 0, c->stream, a); break;
+    }
+    HIP_TRY(hipGetLastError());
+    if (c->timing && evk >= 0) { HIP_TRY(hipEventRecord(c->ev[evk][1], c->stream)); c->ev_valid[evk] = true; }
+    return ORT_OK;
+}
+
+int ort_trace(ort_ctx *c, int phase, uint64_t first_ray, uint64_t n_rays, uint64_t seed)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    if (phase != 1 && phase != 2) return fail(ORT_E_INVALID, "phase must be 1 (ring) or 2 (point)");
+    HIP_TRY(hipSetDevice(c->device));
+    TraceArgs a;
+    memset(&a, 0, sizeof a);
+    a.first_ray = first_ray; a.n_rays = n_rays; a.rng_base = stream_base(seed, phase);
+    a.phase = phase;
+    return launch_trace(c, MODE_FUSED, a, 0);
+}
+
+int ort_trace_resident(ort_ctx *c, int phase, uint64_t first_ray, uint64_t n_rays, uint64_t seed,
+                       int draw_base, const double *d_pos_dir)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    if (phase != 1 && phase != 2) return fail(ORT_E_INVALID, "phase must be 1 (ring) or 2 (point)");
+    if (!d_pos_dir && n_rays) return fail(ORT_E_INVALID, "d_pos_dir is NULL");
+    if (draw_base < 0) return fail(ORT_E_INVALID, "draw_base < 0");
+    HIP_TRY(hipSetDevice(c->device));
+    TraceArgs a;
+    memset(&a, 0, sizeof a);
+    a.first_ray = first_ray; a.n_rays = n_rays; a.rng_base = stream_base(seed, phase);
+    a.phase = phase; a.draw_base = draw_base; a.pos_dir_in = d_pos_dir;
+    return launch_trace(c, MODE_RESIDENT, a, 1);
+}
+
+int ort_emit(ort_ctx *c, int phase, uint64_t first_ray, uint64_t n_rays, uint64_t seed, double *d_pos_dir)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    if (phase != 1 && phase != 2) return fail(ORT_E_INVALID, "phase must be 1 (ring) or 2 (point)");
+    if (!d_pos_dir && n_rays) return fail(ORT_E_INVALID, "d_pos_dir is NULL");
+    if (n_rays == 0) return ORT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[2][0], c->stream));
+    hipLaunchKernelGGL(emit_kernel, dim3(grid_for(n_rays)), dim3(kBlock), 0, c->stream,
+                       c->d_sys, phase, first_ray, n_rays, stream_base(seed, phase), d_pos_dir);
+    HIP_TRY(hipGetLastError());
+    if (c->timing) { HIP_TRY(hipEventRecord(c->ev[2][1], c->stream)); c->ev_valid[2] = true; }
+    return ORT_OK;
+}
+
+int ort_trace_rays(ort_ctx *c, int phase, int64_t n, const double *pos_dir_in, int nu, const double *u,
+                   int draw_base, uint64_t seed, uint64_t first_ray, double *pos_dir_out,
+                   double *emitted_out, int32_t *status, int32_t *bin_xy, int32_t *n_isect,
+                   int32_t *n_draws)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    if (phase != 1 && phase != 2) return fail(ORT_E_INVALID, "phase must be 1 (ring) or 2 (point)");
+    if (n < 0 || draw_base < 0 || nu < 0 || (u && nu == 0)) return fail(ORT_E_INVALID, "bad sizes");
+    if (n == 0) return ORT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t N = (size_t)n;
+    double *d_in = nullptr, *d_u = nullptr, *d_out = nullptr, *d_em = nullptr;
+    int32_t *d_st = nullptr, *d_bin = nullptr, *d_nis = nullptr, *d_nd = nullptr;
+    int rc = ORT_OK;
+#define TRY_GOTO(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(ORT_E_HIP, #expr, e_); goto done; } } while (0)
+    if (pos_dir_in) {
+        TRY_GOTO(hipMalloc(&d_in, 6 * N * sizeof(double)));
+        TRY_GOTO(hipMemcpyAsync(d_in, pos_dir_in, 6 * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if (u) {
+        TRY_GOTO(hipMalloc(&d_u, (size_t)nu * N * sizeof(double)));
+        TRY_GOTO(hipMemcpyAsync(d_u, u, (size_t)nu * N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if (pos_dir_out) TRY_GOTO(hipMalloc(&d_out, 6 * N * sizeof(double)));
+    if (emitted_out) TRY_GOTO(hipMalloc(&d_em, 6 * N * sizeof(double)));
+    if (status) TRY_GOTO(hipMalloc(&d_st, N * sizeof(int32_t)));
+    if (bin_xy) TRY_GOTO(hipMalloc(&d_bin, 2 * N * sizeof(int32_t)));
+    if (n_isect) TRY_GOTO(hipMalloc(&d_nis, N * sizeof(int32_t)));
+    if (n_draws) TRY_GOTO(hipMalloc(&d_nd, N * sizeof(int32_t)));
+    {
+        TraceArgs a;
+        memset(&a, 0, sizeof a);
+        a.first_ray = first_ray; a.n_rays = (uint64_t)n; a.rng_base = stream_base(seed, phase);
+        a.phase = phase; a.draw_base = draw_base; a.pos_dir_in = d_in; a.u = d_u; a.nu = nu;
+        a.pos_dir_out = d_out; a.emitted_out = d_em; a.status = d_st; a.bin_xy = d_bin;
+        a.n_isect = d_nis; a.n_draws = d_nd;
+        rc = launch_trace(c, MODE_DEBUG, a, -1);
+        if (rc) goto done;
+    }
+    if (d_out) TRY_GOTO(hipMemcpyAsync(pos_dir_out, d_out, 6 * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (d_em) TRY_GOTO(hipMemcpyAsync(emitted_out, d_em, 6 * N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (d_st) TRY_GOTO(hipMemcpyAsync(status, d_st, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (d_bin) TRY_GOTO(hipMemcpyAsync(bin_xy, d_bin, 2 * N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (d_nis) TRY_GOTO(hipMemcpyAsync(n_isect, d_nis, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (d_nd) TRY_GOTO(hipMemcpyAsync(n_draws, d_nd, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TRY_GOTO(hipStreamSynchronize(c->stream));
+done:
+#undef TRY_GOTO
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_in); (void)hipFree(d_u); (void)hipFree(d_out); (void)hipFree(d_em);
+    (void)hipFree(d_st); (void)hipFree(d_bin); (void)hipFree(d_nis); (void)hipFree(d_nd);
+    return rc;
+}
+
+int ort_read(ort_ctx *c, int32_t *image, uint64_t *counters)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (image)
+        HIP_TRY(hipMemcpyAsync(image, c->d_image, ORT_IMAGE_BINS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (counters)
+        HIP_TRY(hipMemcpyAsync(counters, c->d_counters, ORT_NUM_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORT_OK;
+}
+
+int ort_attach_buffers(ort_ctx *c, void *d_image, void *d_counters)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    if ((d_image == nullptr) != (d_counters == nullptr))
+        return fail(ORT_E_INVALID, "attach both buffers or neither");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->d_image = d_image ? (int32_t *)d_image : c->own_image;
+    c->d_counters = d_counters ? (unsigned long long *)d_counters : c->own_counters;
+    return ORT_OK;
+}
+
+int ort_device_image(ort_ctx *c, void **d_image)
+{
+    if (!c || !d_image) return fail(ORT_E_INVALID, "NULL argument");
+    *d_image = c->d_image;
+    return ORT_OK;
+}
+
+int ort_device_counters(ort_ctx *c, void **d_counters)
+{
+    if (!c || !d_counters) return fail(ORT_E_INVALID, "NULL argument");
+    *d_counters = c->d_counters;
+    return ORT_OK;
+}
+
+int ort_synchronize(ort_ctx *c)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORT_OK;
+}
+
+int ort_set_timing(ort_ctx *c, int enable)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    c->timing = enable != 0;
+    return ORT_OK;
+}
+
+int ort_last_kernel_ms(ort_ctx *c, int kind, float *ms)
+{
+    if (!c || !ms) return fail(ORT_E_INVALID, "NULL argument");
+    if (kind < 0 || kind > 2) return fail(ORT_E_INVALID, "kind must be 0, 1 or 2");
+    *ms = -1.f;
+    if (!c->ev_valid[kind]) return ORT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[kind][1]));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev[kind][0], c->ev[kind][1]));
+    return ORT_OK;
+}
+
+}  // extern "C"

@@ -30,6 +30,31 @@ F_SKIP_ON_REFLECT, F_MISS_IS_HELP3, F_BOTTLE = 1, 2, 4
 MAX_SURFACES = 12
 
 
+def acos_threshold(na: float) -> float:
+    """min{x in [0,1] : acos(x) <= na} over the doubles, by bisection on the bit pattern."""
+    import struct
+
+    def f2i(x: float) -> int:
+        return struct.unpack("<q", struct.pack("<d", x))[0]
+
+    def i2f(i: int) -> float:
+        return struct.unpack("<d", struct.pack("<q", i))[0]
+
+    lo, hi = f2i(0.0), f2i(1.0)          # acos(lo) > na, acos(hi) = 0 <= na
+    if not (math.acos(0.0) > na >= 0.0):
+        raise ValueError("na outside (0, pi/2)")
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        if math.acos(i2f(mid)) <= na:
+            hi = mid
+        else:
+            lo = mid
+    # acos must be monotone around the threshold for the compare to be equivalent
+    for k in range(1, 65):
+        assert math.acos(i2f(hi + k)) <= na and math.acos(i2f(lo - k + 1 - 1)) > na
+    return i2f(hi)
+
+
 @dataclass
 class Surface:
     kind: int
@@ -145,6 +170,16 @@ class OpticalSystem:
     @property
     def na_angle(self) -> float:
         return math.asin(NA_SINE)                              # imageMod.f90:40
+
+    @property
+    def na_cos_min(self) -> float:
+        """Smallest double x with acos(x) <= asin(0.22) under this host's libm.
+
+        src/imageMod.f90:39-44 rejects a ray when acos(x) > asin(0.22); acos is
+        monotone, so the same decision is `x < na_cos_min`, one compare per ray on
+        the device with the host libm's (= the reference's) rounding of acos.
+        """
+        return acos_threshold(self.na_angle)
 
     def max_intersections(self, phase: int) -> int:
         return len(self.surfaces(phase))

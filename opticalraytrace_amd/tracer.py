@@ -1,0 +1,191 @@
+"""Host driver: the Python counterpart of `program raytrace` (reference src/main.f90).
+
+It reproduces the outer boundary of the reference for the hot path — read a
+settings file, trace `nphotons` ring rays then `nphotons` point rays, write the
+three raw float64 image files and append the `trans-stats.dat` row — with the two
+OpenMP loops (src/main.f90:90-109, :127-162) replaced by `ort_trace` launches on
+one or more MI355X.
+
+Multi-GPU (one process per GPU, torch.distributed / RCCL): the global ray index
+range [0, nphotons) of each phase is cut into contiguous shards, one per rank
+(SURVEY §8e).  Draws are keyed on the GLOBAL ray index, so the summed image is
+bit-identical for any number of ranks.  The only exchange is one sum-all-reduce of
+the int32 image (1.29 MB) and one of the 8 int64 counters per run — the RCCL
+equivalent of `!$omp atomic` on the shared image + `reduction(+:rcount,pcount)`
+(src/imageMod.f90:55, src/main.f90:88).
+
+torch is used for device memory, streams and torch.distributed only.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import fstr
+from .capi import (C_BINNED_POINT, C_BINNED_RING, C_ISECT_POINT, C_ISECT_RING, C_LOST_POINT,
+                   C_LOST_RING, IMAGE_N, NUM_COUNTERS, Context)
+from .params import Settings
+from .system import OpticalSystem
+
+DEFAULT_SEED = 123456789          # src/main.f90:79
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, lo+cnt) of the global ray range for `rank` of `world`."""
+    if world < 1 or not (0 <= rank < world) or n < 0:
+        raise ValueError("bad shard request")
+    lo = (n * rank) // world
+    hi = (n * (rank + 1)) // world
+    return lo, hi - lo
+
+
+@dataclass
+class RunResult:
+    image: np.ndarray             # int32 [2][401][401]; [0] ring, [1] point
+    counters: np.ndarray          # uint64 [8], see include/ort.h ORT_C_*
+    nphotons: int
+
+    @property
+    def ring_transmitted(self) -> float:      # main.f90:175,180
+        return 100.0 * (1.0 - (float(self.counters[C_LOST_RING]) / float(self.nphotons)))
+
+    @property
+    def point_transmitted(self) -> float:     # main.f90:175,181
+        return 100.0 * (1.0 - (float(self.counters[C_LOST_POINT]) / float(self.nphotons)))
+
+    @property
+    def intersections(self) -> int:
+        return int(self.counters[C_ISECT_RING]) + int(self.counters[C_ISECT_POINT])
+
+
+class RayTracer:
+    """One rank's tracer.  `device` is the local HIP device index."""
+
+    def __init__(self, system: OpticalSystem, device: int = 0, rank: int = 0, world: int = 1,
+                 process_group=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("RayTracer needs a HIP device: the trace path has no CPU fallback")
+        self.torch = torch
+        self.system = system
+        self.rank, self.world, self.group = rank, world, process_group
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        # accumulators live in torch tensors so RCCL can reduce them in place
+        self.image = torch.zeros((2, IMAGE_N, IMAGE_N), dtype=torch.int32, device=self.device)
+        self.counters = torch.zeros(NUM_COUNTERS, dtype=torch.int64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.ctx = Context(system, device=device, stream=stream)
+        self.ctx.attach_buffers(self.image.data_ptr(), self.counters.data_ptr())
+
+    def close(self) -> None:
+        self.ctx.close()
+
+    def reset(self) -> None:
+        self.image.zero_()
+        self.counters.zero_()
+
+    def trace_phase(self, phase: int, nphotons: int, seed: int = DEFAULT_SEED) -> None:
+        """This rank's shard of one phase (asynchronous)."""
+        lo, cnt = shard_range(nphotons, self.rank, self.world)
+        self.ctx.trace(phase, lo, cnt, seed)
+
+    def reduce(self) -> None:
+        """Sum image + counters over ranks (RCCL all-reduce over xGMI); no-op for world == 1."""
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.image, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(self.counters, op=dist.ReduceOp.SUM, group=self.group)
+
+    def result(self, nphotons: int) -> RunResult:
+        self.torch.cuda.synchronize(self.device)
+        return RunResult(self.image.cpu().numpy().copy(),
+                         self.counters.cpu().numpy().astype(np.uint64), nphotons)
+
+    def run(self, nphotons: Optional[int] = None, seed: int = DEFAULT_SEED,
+            phases=(1, 2)) -> RunResult:
+        """Both loops of src/main.f90 + the reduction; returns the global result on every rank."""
+        n = self.system.settings.nphotons if nphotons is None else nphotons
+        self.reset()
+        for phase in phases:
+            self.trace_phase(phase, n, seed)
+        self.reduce()
+        return self.result(n)
+
+
+# ---------------------------------------------------------------------------
+# output side of the boundary: src/main.f90:45-48, :168-185; src/imageMod.f90:93-114
+# ---------------------------------------------------------------------------
+def output_basename(system: OpticalSystem) -> str:
+    """File-name stem of src/main.f90:45-48."""
+    s, b = system.settings, system.bottle
+    from .system import PI
+    alpha_rad = s.alpha * PI / 180.0
+    iris = {"before": [True, False], "after": [False, True], "none": [False, False]}[s.iris]
+    return (s.light_source.strip() + "_bottle_" + fstr.str_logical(s.use_bottle)
+            + "_Ra_" + fstr.str_real(b.radiusa, 7) + "_Rb_" + fstr.str_real(b.radiusb, 7)
+            + "_offset_" + fstr.str_real(b.centre[2], 7)
+            + "_" + fstr.str_logical_array(iris) + "_" + fstr.str_real(s.iris_size, 7)
+            + "_L2f_" + fstr.str_real(system.L2[0].f, 6) + "_L3f_" + fstr.str_real(system.L3[0].f, 6)
+            + "_fo_" + fstr.str_real(s.fibre_offset, 7)
+            + "_alp_" + fstr.str_real(alpha_rad * 180 / PI, 7)
+            + "_bwidth_" + fstr.str_real(s.ring_width, 7)
+            + "_sep_" + fstr.str_real(s.isors_offset, 7))
+
+
+def write_images(image: np.ndarray, stem: str) -> Tuple[str, str, str]:
+    """writeImage2D, src/imageMod.f90:93-114: three raw float64 streams, xp fastest."""
+    ring = image[0].astype(np.float64)
+    point = image[1].astype(np.float64)
+    names = (stem + "-ring.dat", stem + "-point.dat", stem + "-total.dat")
+    ring.tofile(names[0])
+    point.tofile(names[1])
+    (ring + point).tofile(names[2])
+    return names
+
+
+STATS_HEADER = (" r/%, p/%, l2%f, l3%f, bottle?, radiusA, radiusB, iris_pos, iris_radius, "
+                "offset, source_type, seperation")     # main.f90:171
+
+
+def append_stats(folder: str, system: OpticalSystem, res: RunResult) -> str:
+    """The trans-stats.dat row of src/main.f90:168-178.  Field order and separators are the
+    reference's; the exact column padding of list-directed output is compiler-specific."""
+    s, b = system.settings, system.bottle
+    path = os.path.join(folder, "trans-stats.dat")
+    new = not os.path.exists(path)
+    iris = {"before": "T F", "after": "F T", "none": "F F"}[s.iris]
+    row = (f" {res.ring_transmitted!r} , {res.point_transmitted!r} , {system.L2[1].f!r} , "
+           f"{system.L3[1].f!r} , {fstr.str_logical(s.use_bottle)} , {b.radiusa!r} , {b.radiusb!r} , "
+           f"{iris} , {fstr.str_real(s.iris_size, 7)} , {b.centre[2]!r} , {s.light_source.strip()}, "
+           f"{s.isors_offset!r}")
+    with open(path, "a") as f:
+        if new:
+            f.write(STATS_HEADER + "\n")
+        f.write(row + "\n")
+    return path
+
+
+def run_settings_file(settings_path: str, res_dir: Optional[str] = None, data_dir: str = "data",
+                      device: int = 0, verbose: bool = True) -> RunResult:
+    """`bin/raytrace <settings>` for the hot path on one GPU: read, trace, write (src/main.f90)."""
+    settings = Settings.from_file(settings_path)
+    res_dir = res_dir or os.path.dirname(os.path.abspath(settings_path))
+    system = OpticalSystem.from_settings(settings, res_dir)
+    tracer = RayTracer(system, device=device)
+    try:
+        res = tracer.run()
+    finally:
+        tracer.close()
+    folder = os.path.join(data_dir, settings.data_folder)
+    os.makedirs(folder, exist_ok=True)                      # setupMod.f90:124-131
+    append_stats(folder, system, res)
+    if verbose:                                             # main.f90:180-181
+        print(f"Ring  transmitted:  {res.ring_transmitted:8.2f}%")
+        print(f"Point transmitted:  {res.point_transmitted:8.2f}%")
+    if settings.make_images:                                # main.f90:183-185
+        write_images(res.image, os.path.join(folder, output_basename(system) + "_image"))
+    return res

@@ -1,0 +1,66 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu() -> bool:
+    return os.path.exists("/dev/kfd")
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container (/dev/kfd absent)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def hip_library():
+    """Path of the in-tree libort_hip.so, built here when hipcc is available."""
+    from opticalraytrace_amd.capi import library_path
+    p = library_path()
+    src = os.path.join(os.path.dirname(p), "ort_hip.hip")
+    hdr = os.path.join(os.path.dirname(p), "ort_device.h")
+    stale = (not os.path.exists(p)) or any(os.path.getmtime(p) < os.path.getmtime(f) for f in (src, hdr))
+    if stale and os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.run(["make", "-C", os.path.dirname(p)], check=True, capture_output=True)
+    if not os.path.exists(p):
+        pytest.fail(f"{p} missing and cannot be built: the product has no fallback")
+    return p
+
+
+CONFIGS = {
+    # name: Settings overrides.  cfg1/cfg2 are BASELINE.json configs[0]/[1].
+    "large": dict(bottle_file="clearBottle-large.params"),
+    "small": dict(bottle_file="clearBottle-small.params"),
+    "large_iris_before": dict(bottle_file="clearBottle-large.params", iris="before", iris_size=0.8),
+    "small_iris_after": dict(bottle_file="clearBottle-small.params", iris="after", iris_size=0.8),
+    "ellipse": dict(bottle_file="clearBottle-ellipse.params"),
+    "small_f60_nobottle": dict(bottle_file="clearBottle-small.params", use_bottle=False,
+                               L3_file="achromaticDoublet-f60.0mm.params",
+                               L2_file="planoConvex-f49.8mm.params", fibre_offset=1e-3),
+}
+
+
+def make_system(name: str):
+    from opticalraytrace_amd.params import Settings
+    from opticalraytrace_amd.system import OpticalSystem
+    s = Settings(nphotons=100000, make_images=True, **CONFIGS[name])
+    return s, OpticalSystem.from_settings(s)
+
+
+@pytest.fixture(scope="session", params=list(CONFIGS))
+def config_name(request):
+    return request.param

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF.
+
+Runs only in the build container: it loads oracle/_ref/libort_ref.so, which
+oracle/Makefile compiles from the reference's own Fortran path sources where they
+lie under /root/reference/src (flang), and reads the reference's own data files
+/root/reference/res/*.params.  The fixtures hold numbers only — inputs (settings,
+uniform draws, rays) and the outputs the reference produced for them:
+
+  <config>.npz
+    constants      46 values of the reference's constructors / set-up lines
+    p{1,2}_u       [9][n] uniforms fed to ran2(), in draw order
+    p{1,2}_emitted [6][n] ray produced by ring / point
+    p{1,2}_pos_dir [6][n] ray state when the reference loop body ended
+    p{1,2}_status  0 binned, 1 reached image plane but not binned, 3 lost in bottle,
+                   4 lost in telescope
+    p{1,2}_bin     [2][n] image bin, -9999 when not binned
+    p{1,2}_ndraws  draws consumed
+    p{1,2}x_*      the same rays re-traced from EXPLICIT input (pos_dir_in = emitted,
+                   draws starting at index 4 / 2): no transcendental on that path
+    img{1,2}_idx/_cnt  sparse image of 100000 keyed rays (ORT-RNG-v1, seed 123456789)
+    img{1,2}_lost      the reference's rcount / pcount for that run
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
+
+from conftest import CONFIGS  # noqa: E402
+from opticalraytrace_amd.params import Settings  # noqa: E402
+from oracle.binding import Reference  # noqa: E402
+
+REF_RES = "/root/reference/res"
+N_RAYS = 192
+N_IMAGE = 100000
+SEED = 123456789          # src/main.f90:79
+
+
+def main():
+    for ci, (name, over) in enumerate(CONFIGS.items()):
+        s = Settings(nphotons=N_IMAGE, make_images=True, **over)
+        ref = Reference(s, REF_RES)
+        out = {"constants": ref.constants()[:46]}
+        rng = np.random.default_rng(1000 + ci)
+        for phase in (1, 2):
+            u = rng.random((9, N_RAYS))
+            # force both Fresnel branches on some rays (u=0 reflects, u->1 refracts)
+            u[4:, :8] = 0.0
+            u[4:, 8:16] = 1.0 - 2.0 ** -53
+            r = ref.trace_rays(phase, N_RAYS, u=u)
+            p = f"p{phase}_"
+            out[p + "u"] = u
+            out[p + "emitted"] = r["emitted"]
+            out[p + "pos_dir"] = r["pos_dir"]
+            out[p + "status"] = r["status"]
+            out[p + "bin"] = r["bin_xy"]
+            out[p + "ndraws"] = r["n_draws"]
+            base = 4 if phase == 1 else 2
+            rx = ref.trace_rays(phase, N_RAYS, pos_dir_in=r["emitted"], u=u, draw_base=base)
+            p = f"p{phase}x_"
+            out[p + "pos_dir"] = rx["pos_dir"]
+            out[p + "status"] = rx["status"]
+            out[p + "bin"] = rx["bin_xy"]
+            out[p + "ndraws"] = rx["n_draws"]
+            img, lost = ref.trace(phase, 0, N_IMAGE, SEED)
+            flat = img.reshape(-1)
+            idx = np.nonzero(flat)[0].astype(np.int32)
+            out[f"img{phase}_idx"] = idx
+            out[f"img{phase}_cnt"] = flat[idx].astype(np.int32)
+            out[f"img{phase}_lost"] = np.int64(lost)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.startswith("img")})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+"""The C oracle against the committed golden vectors (generated from the reference
+itself by tests/golden/make_golden.py).  CPU only; bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import CONFIGS, make_system
+from parity import SEED, assert_rays_equal, load_golden, merge_status, sparse_image
+from oracle.binding import Oracle
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("phase", [1, 2])
+def test_oracle_matches_golden_rays(name, phase):
+    g = load_golden(name)
+    _, osys = make_system(name)
+    orc = Oracle(osys)
+    u = g[f"p{phase}_u"]
+    n = u.shape[1]
+    got = orc.trace_rays(phase, n, u=u)
+    want = dict(status=g[f"p{phase}_status"], bin_xy=g[f"p{phase}_bin"],
+                n_draws=g[f"p{phase}_ndraws"], pos_dir=g[f"p{phase}_pos_dir"])
+    assert np.array_equal(got["emitted"], g[f"p{phase}_emitted"]), "emitted rays not bit-exact"
+    assert_rays_equal(got, want, exact=True, what=f"{name} phase {phase}")
+    # explicit-input variant (no emitter on the path)
+    base = 4 if phase == 1 else 2
+    gotx = orc.trace_rays(phase, n, pos_dir_in=g[f"p{phase}_emitted"], u=u, draw_base=base)
+    wantx = dict(status=g[f"p{phase}x_status"], bin_xy=g[f"p{phase}x_bin"],
+                 n_draws=g[f"p{phase}x_ndraws"], pos_dir=g[f"p{phase}x_pos_dir"])
+    assert_rays_equal(gotx, wantx, exact=True, what=f"{name} phase {phase} explicit")
+    # both Fresnel branches were forced in the fixture
+    if name not in ("ellipse",):
+        st = merge_status(g[f"p{phase}_status"])
+        assert (st[:8] != 0).all(), "u=0 rays must reflect somewhere and be lost or rejected"
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_oracle_matches_golden_images(name):
+    g = load_golden(name)
+    _, osys = make_system(name)
+    orc = Oracle(osys)
+    img = np.zeros((2, 401, 401), np.int32)
+    cnt = np.zeros(8, np.uint64)
+    for phase in (1, 2):
+        orc.trace(phase, 0, 100000, SEED, img, cnt)
+    want = sparse_image(g["img1_idx"], g["img1_cnt"]) + sparse_image(g["img2_idx"], g["img2_cnt"])
+    assert np.array_equal(img, want)
+    assert int(cnt[0]) == int(g["img1_lost"]) and int(cnt[1]) == int(g["img2_lost"])
+    assert int(cnt[4]) == int(img[0].sum()) and int(cnt[5]) == int(img[1].sum())
+
+
+def test_rng_known_answers():
+    """ORT-RNG-v1 pinned numerically (SplitMix64 finaliser; independent Python restatement)."""
+    M = (1 << 64) - 1
+    G = 0x9E3779B97F4A7C15
+
+    def mix(z):
+        z ^= z >> 30; z = (z * 0xBF58476D1CE4E5B9) & M
+        z ^= z >> 27; z = (z * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    def uni(seed, phase, ray, k):
+        base = mix(seed ^ ((G * phase) & M))
+        z = (base + G * (((ray << 24) + k + 1) & M)) & M
+        return (mix(z) >> 11) * 2.0 ** -53
+
+    orc = Oracle()
+    for seed, phase, ray, k in [(SEED, 1, 0, 0), (SEED, 2, 12345678901, 8), (0, 2, 2 ** 31 - 1, 3),
+                                (2 ** 63 + 5, 1, 999, 15)]:
+        assert orc.uniform(seed, phase, ray, k) == uni(seed, phase, ray, k)
+    us = np.array([orc.uniform(SEED, 2, i, i % 9) for i in range(20000)])
+    assert 0.0 <= us.min() and us.max() < 1.0
+    assert abs(us.mean() - 0.5) < 0.01 and abs(us.var() - 1 / 12) < 0.005
+
+
+def test_oracle_partition_invariance():
+    """Images add over any split of the global ray index range."""
+    _, osys = make_system("small")
+    orc = Oracle(osys)
+    a, ca = orc.trace(2, 0, 30000, SEED)
+    b = np.zeros_like(a); cb = np.zeros(8, np.uint64)
+    for lo, n in [(0, 1), (1, 9999), (10000, 20000)]:
+        orc.trace(2, lo, n, SEED, b, cb)
+    assert np.array_equal(a, b) and np.array_equal(ca, cb)
