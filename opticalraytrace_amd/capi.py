@@ -96,6 +96,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if _LIB is not None and path is None:
         return _LIB
     p = path or library_path()
+    try:
+        # PyTorch-ROCm bundles its own HIP/HSA runtime.  It must be the first one loaded into
+        # the process: libort_hip.so then binds to that same runtime (same SONAME), and torch
+        # tensors, streams and RCCL share one device context with the kernels.  Loading
+        # /opt/rocm's runtime first leaves torch with "No HIP GPUs are available".
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(p):
         raise OrtError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; "
                        "g.build()'` — there is no CPU fallback for the trace path")

@@ -61,37 +61,29 @@ class RunResult:
         return int(self.counters[C_ISECT_RING]) + int(self.counters[C_ISECT_POINT])
 
 
-class RayTracer:
-    """One rank's tracer.  `device` is the local HIP device index."""
+class ShardedRun:
+    """Rank-local half of a sharded run: owns the accumulators (torch tensors), cuts the global
+    ray range, and sums image + counters over ranks.  How a shard is traced is the subclass's
+    business (`_trace_shard`); the only tracer in this package is the HIP one below."""
 
-    def __init__(self, system: OpticalSystem, device: int = 0, rank: int = 0, world: int = 1,
-                 process_group=None):
-        import torch
-        if not torch.cuda.is_available():
-            raise RuntimeError("RayTracer needs a HIP device: the trace path has no CPU fallback")
-        self.torch = torch
-        self.system = system
+    def __init__(self, image, counters, rank: int = 0, world: int = 1, process_group=None):
+        self.image, self.counters = image, counters
         self.rank, self.world, self.group = rank, world, process_group
-        self.device = torch.device("cuda", device)
-        torch.cuda.set_device(self.device)
-        # accumulators live in torch tensors so RCCL can reduce them in place
-        self.image = torch.zeros((2, IMAGE_N, IMAGE_N), dtype=torch.int32, device=self.device)
-        self.counters = torch.zeros(NUM_COUNTERS, dtype=torch.int64, device=self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.ctx = Context(system, device=device, stream=stream)
-        self.ctx.attach_buffers(self.image.data_ptr(), self.counters.data_ptr())
 
-    def close(self) -> None:
-        self.ctx.close()
+    def _trace_shard(self, phase: int, lo: int, cnt: int, seed: int) -> None:
+        raise NotImplementedError
+
+    def _synchronize(self) -> None:
+        pass
 
     def reset(self) -> None:
         self.image.zero_()
         self.counters.zero_()
 
     def trace_phase(self, phase: int, nphotons: int, seed: int = DEFAULT_SEED) -> None:
-        """This rank's shard of one phase (asynchronous)."""
+        """This rank's shard of one phase (asynchronous on the GPU path)."""
         lo, cnt = shard_range(nphotons, self.rank, self.world)
-        self.ctx.trace(phase, lo, cnt, seed)
+        self._trace_shard(phase, lo, cnt, seed)
 
     def reduce(self) -> None:
         """Sum image + counters over ranks (RCCL all-reduce over xGMI); no-op for world == 1."""
@@ -101,19 +93,52 @@ class RayTracer:
             dist.all_reduce(self.counters, op=dist.ReduceOp.SUM, group=self.group)
 
     def result(self, nphotons: int) -> RunResult:
-        self.torch.cuda.synchronize(self.device)
+        self._synchronize()
         return RunResult(self.image.cpu().numpy().copy(),
                          self.counters.cpu().numpy().astype(np.uint64), nphotons)
 
-    def run(self, nphotons: Optional[int] = None, seed: int = DEFAULT_SEED,
-            phases=(1, 2)) -> RunResult:
+    def run(self, nphotons: int, seed: int = DEFAULT_SEED, phases=(1, 2)) -> RunResult:
         """Both loops of src/main.f90 + the reduction; returns the global result on every rank."""
-        n = self.system.settings.nphotons if nphotons is None else nphotons
         self.reset()
         for phase in phases:
-            self.trace_phase(phase, n, seed)
+            self.trace_phase(phase, nphotons, seed)
         self.reduce()
-        return self.result(n)
+        return self.result(nphotons)
+
+
+class RayTracer(ShardedRun):
+    """One rank's MI355X tracer.  `device` is the local HIP device index.  No CPU fallback."""
+
+    def __init__(self, system: OpticalSystem, device: int = 0, rank: int = 0, world: int = 1,
+                 process_group=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("RayTracer needs a HIP device: the trace path has no CPU fallback")
+        self.torch = torch
+        self.system = system
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        # accumulators live in torch tensors so RCCL can reduce them in place
+        image = torch.zeros((2, IMAGE_N, IMAGE_N), dtype=torch.int32, device=self.device)
+        counters = torch.zeros(NUM_COUNTERS, dtype=torch.int64, device=self.device)
+        super().__init__(image, counters, rank, world, process_group)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.ctx = Context(system, device=device, stream=stream)
+        self.ctx.attach_buffers(self.image.data_ptr(), self.counters.data_ptr())
+
+    def close(self) -> None:
+        self.ctx.close()
+
+    def _trace_shard(self, phase: int, lo: int, cnt: int, seed: int) -> None:
+        self.ctx.trace(phase, lo, cnt, seed)
+
+    def _synchronize(self) -> None:
+        self.torch.cuda.synchronize(self.device)
+
+    def run(self, nphotons: Optional[int] = None, seed: int = DEFAULT_SEED,
+            phases=(1, 2)) -> RunResult:
+        n = self.system.settings.nphotons if nphotons is None else nphotons
+        return super().run(n, seed, phases)
 
 
 # ---------------------------------------------------------------------------

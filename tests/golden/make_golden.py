@@ -77,5 +77,45 @@ def main():
         print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.startswith("img")})
 
 
+def refprog():
+    """End-to-end run of the UNMODIFIED reference program (oracle/_ref/raytrace: all 13
+    sources incl. its own random_mod.f90 + main.f90) in a scratch tree; its RNG stream is
+    the Fortran runtime's, so these fixtures pin statistics (transmission, image moments),
+    the output file name and the file format — not individual rays."""
+    import shutil
+    import subprocess
+    import tempfile
+    from oracle.binding import REF_PROG
+    n = 1_000_000
+    for tag, over in (("large", CONFIGS["large"]), ("small", CONFIGS["small"])):
+        tmp = tempfile.mkdtemp(prefix="ortref_")
+        for d in ("bin", "res", "data"):
+            os.makedirs(os.path.join(tmp, d))
+        for f in os.listdir(REF_RES):
+            if f.endswith(".params") and f != "settings.params":
+                shutil.copy(os.path.join(REF_RES, f), os.path.join(tmp, "res", f))
+        # init_emit_image opens the image-source file unconditionally (src/setupMod.f90:120-121)
+        np.ones((512, 512)).tofile(os.path.join(tmp, "res", "ones.dat"))
+        s = Settings(nphotons=n, make_images=True, image_source="ones.dat", data_folder="run", **over)
+        s.write(os.path.join(tmp, "res", "cfg.params"))
+        p = subprocess.run([REF_PROG, "cfg.params"], cwd=os.path.join(tmp, "bin"),
+                           capture_output=True, text=True, check=True)
+        folder = os.path.join(tmp, "data", "run")
+        files = sorted(f for f in os.listdir(folder) if f.endswith(".dat") and "image" in f)
+        stem = files[0][:-len("_image-point.dat")]
+        out = {"stdout": np.array(p.stdout), "stem": np.array(stem), "nphotons": np.int64(n),
+               "stats": np.array(open(os.path.join(folder, "trans-stats.dat")).read())}
+        for layer in ("ring", "point", "total"):
+            a = np.fromfile(os.path.join(folder, stem + f"_image-{layer}.dat"), np.float64)
+            assert a.size == 401 * 401
+            idx = np.nonzero(a)[0].astype(np.int32)
+            out[layer + "_idx"] = idx
+            out[layer + "_cnt"] = a[idx].astype(np.int32)
+        np.savez_compressed(os.path.join(HERE, f"refprog_{tag}.npz"), **out)
+        print("refprog", tag, p.stdout.strip().splitlines()[-2:], stem)
+        shutil.rmtree(tmp)
+
+
 if __name__ == "__main__":
     main()
+    refprog()
