@@ -72,6 +72,11 @@ typedef struct ort_system {
     int32_t abi_version;          /* ORT_ABI_VERSION */
     int32_t n_surfaces[2];        /* [0] phase 1 (ring), [1] phase 2 (point) */
     int32_t ring_ellipse;         /* bottle%ellipse for the ring emitter (src/sourceMod.f90:276) */
+    int32_t split[2];             /* per phase: index of the first surface of segment 2 of the queued
+                                     kernel (rays that survive surfaces [0, split) are compacted through
+                                     a wave-private LDS queue); 0 or n_surfaces = single segment.
+                                     Scheduling only: results do not depend on it. */
+    int32_t reserved[2];
     ort_surface surfaces[2][ORT_MAX_SURFACES];
     /* point emitter, src/sourceMod.f90:12-47 */
     double cos_theta_max;
@@ -82,6 +87,7 @@ typedef struct ort_system {
     double ring_bottle_ra, ring_bottle_rb, ring_bottle_z;
     /* image, src/imageMod.f90:19-58 */
     double bin_width;             /* image_diameter / 401. */
+    double inv_bin_width;         /* 1 / bin_width, for the filtered bin lookup (ort_device.h) */
     double na_angle;              /* asin(0.22) */
     double na_cos_min;            /* smallest x with acos(x) <= na_angle under the host libm: the
                                      NA test of src/imageMod.f90:39-44 as one compare per ray */
@@ -175,6 +181,11 @@ int ort_synchronize(ort_ctx *ctx);
  * trace, 1 resident trace, 2 emit. */
 int ort_last_kernel_ms(ort_ctx *ctx, int kind, float *ms);
 int ort_set_timing(ort_ctx *ctx, int enable);
+/* Tuning / A-B knob, a bit mask: bit 0 set (default) = queued kernel (LDS ray queue between
+ * segments), clear = plain lockstep kernel; bit 1 set = every predicate evaluated literally
+ * (no filtered predicates, see csrc/ort_device.h), clear (default) = filtered.  All four
+ * combinations produce bit-identical rays, images and counters.  Default 1. */
+int ort_set_kernel_variant(ort_ctx *ctx, int variant);
 
 #ifdef __cplusplus
 }

@@ -39,14 +39,14 @@ class OrtSurface(C.Structure):
 
 class OrtSystem(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("n_surfaces", C.c_int32 * 2),
-                ("ring_ellipse", C.c_int32),
+                ("ring_ellipse", C.c_int32), ("split", C.c_int32 * 2), ("reserved", C.c_int32 * 2),
                 ("surfaces", (OrtSurface * MAX_SURFACES) * 2),
                 ("cos_theta_max", C.c_double),
                 ("ring_r1", C.c_double), ("ring_r2", C.c_double),
                 ("ring_lens_r2", C.c_double), ("ring_lens_z", C.c_double),
                 ("ring_bottle_ra", C.c_double), ("ring_bottle_rb", C.c_double),
                 ("ring_bottle_z", C.c_double),
-                ("bin_width", C.c_double), ("na_angle", C.c_double), ("na_cos_min", C.c_double),
+                ("bin_width", C.c_double), ("inv_bin_width", C.c_double), ("na_angle", C.c_double), ("na_cos_min", C.c_double),
                 ("twopi", C.c_double)]
 
 
@@ -57,6 +57,7 @@ def pack_system(osys: OpticalSystem) -> OrtSystem:
     for ph in (1, 2):
         surfs = osys.surfaces(ph)
         cs.n_surfaces[ph - 1] = len(surfs)
+        cs.split[ph - 1] = osys.queue_split(ph)
         for k, s in enumerate(surfs):
             d = cs.surfaces[ph - 1][k]
             d.cx, d.cy, d.cz = s.cx, s.cy, s.cz
@@ -75,6 +76,7 @@ def pack_system(osys: OpticalSystem) -> OrtSystem:
     cs.ring_lens_z = l2.fb
     cs.ring_bottle_ra, cs.ring_bottle_rb, cs.ring_bottle_z = b.radiusa, b.radiusb, b.centre[2]
     cs.bin_width = osys.bin_width
+    cs.inv_bin_width = 1.0 / osys.bin_width
     cs.na_angle = osys.na_angle
     cs.na_cos_min = osys.na_cos_min
     cs.twopi = TWOPI
@@ -87,6 +89,8 @@ _IP = C.POINTER(C.c_int32)
 
 
 def library_path() -> str:
+    if os.environ.get("ORT_HIP_LIB"):          # development: A/B another build of the same ABI
+        return os.environ["ORT_HIP_LIB"]
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libort_hip.so")
 
 
@@ -129,6 +133,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ort_synchronize": (C.c_int, [vp]),
         "ort_last_kernel_ms": (C.c_int, [vp, i32, C.POINTER(C.c_float)]),
         "ort_set_timing": (C.c_int, [vp, i32]),
+        "ort_set_kernel_variant": (C.c_int, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a symbol
@@ -145,7 +150,7 @@ EXPORTED_SYMBOLS = ["ort_abi_version", "ort_last_error", "ort_device_count", "or
                     "ort_trace_resident", "ort_trace_rays", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
                     "ort_device_counters", "ort_synchronize", "ort_last_kernel_ms",
-                    "ort_set_timing"]
+                    "ort_set_timing", "ort_set_kernel_variant"]
 
 
 def _check(lib, rc: int, what: str) -> None:
@@ -242,6 +247,9 @@ class Context:
 
     def set_timing(self, enable: bool) -> None:
         _check(self.lib, self.lib.ort_set_timing(self._h, int(enable)), "ort_set_timing")
+
+    def set_kernel_variant(self, variant: int) -> None:
+        _check(self.lib, self.lib.ort_set_kernel_variant(self._h, variant), "ort_set_kernel_variant")
 
     def last_kernel_ms(self, kind: int = 0) -> float:
         ms = C.c_float()

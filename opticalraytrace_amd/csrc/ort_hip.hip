@@ -28,6 +28,9 @@ using namespace ort;
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef ORT_MIN_WAVES
+#define ORT_MIN_WAVES 1
+#endif
 constexpr int kMaxBlocks = 256 * 8;     // 256 CUs x 8 workgroups: >> 256 workgroups fills all 8 XCDs
 
 enum { MODE_FUSED = 0, MODE_RESIDENT = 1, MODE_DEBUG = 2 };
@@ -58,7 +61,7 @@ __device__ inline void stage_system(ort_system &dst, const ort_system *src)
     __syncthreads();
 }
 
-template <int MODE, class D>
+template <int MODE, bool FILT, class D>
 __device__ inline int trace_one(const ort_system &S, int phase, bool have_in, Ray &r, D &draws,
                                 int &nis, int &xp, int &yp, Ray &emitted)
 {
@@ -71,14 +74,15 @@ __device__ inline int trace_one(const ort_system &S, int phase, bool have_in, Ra
     const ort_surface *surf = S.surfaces[phase - 1];
     int st = ORT_ST_LOST_TELESCOPE;
     for (int k = 0; k < ns; ++k) {
-        st = surface_step(S, surf[k], r, draws, nis, xp, yp);
+        st = surface_step<FILT>(S, surf[k], r, draws, nis, xp, yp);
         if (st >= 0) break;
     }
     return st;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void trace_kernel(TraceArgs a)
+// FILT: filtered predicates (ort_device.h); false = every predicate evaluated literally.
+template <int MODE, bool FILT>
+__global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs a)
 {
     __shared__ ort_system S;
     __shared__ unsigned int blk[4];       // lost, isect, binned, help3
@@ -106,12 +110,12 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(TraceArgs a)
             Draws d;
             if (a.u) d.init_table(a.u + i, (int64_t)n, a.nu, a.draw_base);
             else d.init_keyed(a.rng_base, a.first_ray + i, a.draw_base);
-            st = trace_one<MODE>(S, a.phase, have_in, r, d, nis, xp, yp, em);
+            st = trace_one<MODE, FILT>(S, a.phase, have_in, r, d, nis, xp, yp, em);
             kdraws = d.k;
         } else {
             KeyedDraws d;
             d.init_keyed(a.rng_base, a.first_ray + i, have_in ? a.draw_base : 0);
-            st = trace_one<MODE>(S, a.phase, have_in, r, d, nis, xp, yp, em);
+            st = trace_one<MODE, FILT>(S, a.phase, have_in, r, d, nis, xp, yp, em);
             kdraws = d.k;
         }
         if (MODE == MODE_DEBUG) {
@@ -148,6 +152,141 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(TraceArgs a)
         if (threadIdx.x < 4 && blk[threadIdx.x])
             atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
     }
+}
+
+// ---------------------------------------------------------------------------
+// Queued variant ("wavefront per ray bundle"): every wave is an independent worker
+// over a contiguous range of global ray indices.  The surface list is cut into two
+// segments at S.split (host-chosen: just after the aperture stop that removes most
+// rays).  Segment 1 runs in lockstep on 64 fresh rays; the survivors are appended to
+// a wave-private ray queue in LDS (SoA: pos, dir, RNG counter; 128 slots).  As soon
+// as 64 rays are queued the wave runs segment 2 on a FULL wavefront.  Dead lanes of
+// segment 1 therefore never ride along through segment 2 — the lanes stay busy
+// although rays die at different surfaces.  No workgroup barrier is involved: a
+// queue is only ever touched by the wave that owns it.  Per-ray arithmetic and draw
+// order are exactly those of the lockstep kernel, so results are bit-identical.
+// ---------------------------------------------------------------------------
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kQueueCap = 128;      // >= 63 leftover + 64 new survivors
+constexpr int kQueueFields = 7;     // px py pz dx dy dz + RNG counter bits
+
+__device__ inline int lane_prefix(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+template <int MODE, bool FILT>
+__global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(TraceArgs a)
+{
+    __shared__ ort_system S;
+    __shared__ double Q[kWavesPerBlock][kQueueFields][kQueueCap];
+    __shared__ unsigned int blk[4];
+    stage_system(S, a.sys);
+    if (threadIdx.x < 4) blk[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double (*q)[kQueueCap] = Q[wave];
+    const int ph = a.phase - 1;
+    const ort_surface *surf = S.surfaces[ph];
+    const int ns = S.n_surfaces[ph];
+    int split = S.split[ph];
+    if (split <= 0 || split >= ns) split = ns;          // no queue point: one segment
+    int32_t *layer = a.image + (size_t)ph * ORT_IMAGE_N * ORT_IMAGE_N;
+    const uint64_t n = a.n_rays;
+
+    // contiguous, 64-aligned range of ray indices for this wave
+    const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
+    const uint64_t wid = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    uint64_t chunk = (n + nwaves - 1) / nwaves;
+    chunk = (chunk + 63) & ~63ull;
+    uint64_t lo = wid * chunk; if (lo > n) lo = n;
+    uint64_t hi = lo + chunk;  if (hi > n) hi = n;
+
+    unsigned int lost = 0, isect = 0, binned = 0, help3 = 0;
+    auto finish = [&](int st, int nis, int xp, int yp) {
+        isect += (unsigned)nis;
+        if (st == ORT_ST_BINNED) {
+            binned++;
+            atomicAdd(&layer[(xp + 200) + ORT_IMAGE_N * (yp + 200)], 1);      // imageMod.f90:55-56
+        } else if (st >= ORT_ST_LOST_BOTTLE) {
+            lost++;                                                          // optics_system.f90:32,42; main.f90:151
+            if (st == ORT_ST_HELP3) help3++;
+        }
+    };
+
+    uint64_t next = lo;
+    int qcount = 0, qhead = 0;
+    for (;;) {
+        const bool have_new = next < hi;
+        if (qcount >= 64 || (!have_new && qcount > 0)) {
+            // ---- segment 2 on up to 64 queued rays
+            const int m = qcount < 64 ? qcount : 64;
+            const bool act = lane < m;
+            const int slot = (qhead + lane) & (kQueueCap - 1);
+            qhead = (qhead + m) & (kQueueCap - 1);
+            qcount -= m;
+            if (act) {
+                Ray r;
+                KeyedDraws d;
+                r.pos = {q[0][slot], q[1][slot], q[2][slot]};
+                r.dir = {q[3][slot], q[4][slot], q[5][slot]};
+                d.z = (uint64_t)__double_as_longlong(q[6][slot]);
+                d.k = 0;
+                int nis = 0, xp = 0, yp = 0, st = ORT_ST_LOST_TELESCOPE;
+                for (int k = split; k < ns; ++k) {
+                    st = surface_step<FILT>(S, surf[k], r, d, nis, xp, yp);
+                    if (st >= 0) break;
+                }
+                finish(st, nis, xp, yp);
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else if (have_new) {
+            // ---- segment 1 on 64 fresh rays
+            const uint64_t i = next + (uint64_t)lane;
+            const bool act = i < hi;
+            next += 64;
+            Ray r;
+            KeyedDraws d;
+            int nis = 0, xp = 0, yp = 0, st = -1;
+            if (act) {
+                if (MODE == MODE_RESIDENT) {
+                    d.init_keyed(a.rng_base, a.first_ray + i, a.draw_base);
+                    r.pos = {a.pos_dir_in[0 * n + i], a.pos_dir_in[1 * n + i], a.pos_dir_in[2 * n + i]};
+                    r.dir = {a.pos_dir_in[3 * n + i], a.pos_dir_in[4 * n + i], a.pos_dir_in[5 * n + i]};
+                } else {
+                    d.init_keyed(a.rng_base, a.first_ray + i, 0);
+                    if (a.phase == 1) emit_ring(S, r, d);
+                    else emit_point(S, r, d);
+                }
+                for (int k = 0; k < split; ++k) {
+                    st = surface_step<FILT>(S, surf[k], r, d, nis, xp, yp);
+                    if (st >= 0) break;
+                }
+            }
+            const bool survive = act && st < 0;
+            const unsigned long long mask = __ballot(survive);
+            if (survive) {
+                const int slot = (qhead + qcount + lane_prefix(mask)) & (kQueueCap - 1);
+                q[0][slot] = r.pos.x; q[1][slot] = r.pos.y; q[2][slot] = r.pos.z;
+                q[3][slot] = r.dir.x; q[4][slot] = r.dir.y; q[5][slot] = r.dir.z;
+                q[6][slot] = __longlong_as_double((long long)d.z);
+                isect += (unsigned)nis;                    // counted so far; segment 2 adds the rest
+            } else if (act) {
+                finish(st, nis, xp, yp);
+            }
+            qcount += __popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            break;
+        }
+    }
+    atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect);
+    atomicAdd(&blk[2], binned); atomicAdd(&blk[3], help3);
+    __syncthreads();
+    if (threadIdx.x < 4 && blk[threadIdx.x])
+        atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int phase,
@@ -204,6 +343,7 @@ int check_system(const ort_system *sys)
             if ((kind == ORT_SURF_IMAGE) != (k == n - 1))
                 return fail(ORT_E_INVALID, "the image plane must be the last surface, and only the last");
         }
+        if (sys->split[p] < 0 || sys->split[p] > n) return fail(ORT_E_INVALID, "split out of range");
     }
     return ORT_OK;
 }
@@ -218,6 +358,7 @@ struct ort_ctx {
     int32_t *d_image, *own_image;
     unsigned long long *d_counters, *own_counters;
     bool timing;
+    int variant;                 // 0 lockstep, 1 queued (default)
     hipEvent_t ev[3][2];
     bool ev_valid[3];
 };
@@ -253,6 +394,7 @@ int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out)
     if (!c) return fail(ORT_E_NOMEM, "host allocation failed");
     memset(c, 0, sizeof *c);
     c->device = device;
+    c->variant = 1;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     HIP_TRY(hipMalloc(&c->d_sys, sizeof(ort_system)));
@@ -311,11 +453,25 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
     if (a.n_rays == 0) return ORT_OK;
     int grid = grid_for(a.n_rays);
     if (c->timing && evk >= 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
-    switch (mode) {
-    case MODE_FUSED: hipLaunchKernelGGL(trace_kernel<MODE_FUSED>, dim3(grid), dim3(kBlock), 0, c->stream, a); break;
-    case MODE_RESIDENT: hipLaunchKernelGGL(trace_kernel<MODE_RESIDENT>, dim3(grid), dim3(kBlock), 0, c->stream, a); break;
-    default: hipLaunchKernelGGL(trace_kernel<MODE_DEBUG>, dim3(grid), dim3(kBlock), 0, c->stream, a); break;
+    const bool queued = (c->variant & 1) && mode != MODE_DEBUG;
+    const bool filt = (c->variant & 2) == 0;
+    if (queued) {
+        // every wave walks a 64-aligned contiguous range: no more waves than 64-ray batches
+        uint64_t batches = (a.n_rays + 63) / 64;
+        uint64_t blocks = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (blocks < (uint64_t)grid) grid = (int)blocks;
     }
+#define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
+    if (mode == MODE_FUSED) {
+        if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true>)); else ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, false>)); }
+        else { if (filt) ORT_LAUNCH((trace_kernel<MODE_FUSED, true>)); else ORT_LAUNCH((trace_kernel<MODE_FUSED, false>)); }
+    } else if (mode == MODE_RESIDENT) {
+        if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true>)); else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, false>)); }
+        else { if (filt) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true>)); else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false>)); }
+    } else {
+        if (filt) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true>)); else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false>));
+    }
+#undef ORT_LAUNCH
     HIP_TRY(hipGetLastError());
     if (c->timing && evk >= 0) { HIP_TRY(hipEventRecord(c->ev[evk][1], c->stream)); c->ev_valid[evk] = true; }
     return ORT_OK;
@@ -460,6 +616,14 @@ int ort_synchronize(ort_ctx *c)
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORT_OK;
+}
+
+int ort_set_kernel_variant(ort_ctx *c, int variant)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    if (variant < 0 || variant > 3) return fail(ORT_E_INVALID, "variant must be in 0..3");
+    c->variant = variant;
     return ORT_OK;
 }
 

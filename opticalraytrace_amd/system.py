@@ -163,6 +163,16 @@ class OpticalSystem:
         assert len(out) <= MAX_SURFACES
         return out
 
+    def queue_split(self, phase: int) -> int:
+        """Where the queued kernel cuts the surface list (index of the first surface of segment
+        2): just after the aperture stop that removes most rays — the plano flat face for the
+        ring source (69 % of ring rays miss it), the first doublet face for the point
+        source (a third of the remaining rays miss it).  Scheduling only; results are identical
+        for any value."""
+        names = [s.name for s in self.surfaces(phase)]
+        stop = "L2 flat" if phase == 1 else "L3 face 1"
+        return names.index(stop) + 1
+
     @property
     def bin_width(self) -> float:
         return self.settings.image_diameter / 401.0            # imageMod.f90:45

@@ -222,3 +222,73 @@ def test_errors_do_not_abort(hip_library):
     with Context(osys) as ctx:
         with pytest.raises(OrtError):
             ctx.trace(3, 0, 10, 1)
+
+
+@pytest.mark.parametrize("name", ["large", "small_iris_after", "small_f60_nobottle", "ellipse"])
+def test_queued_kernel_equals_lockstep_kernel(ctxs, name):
+    """The LDS-queued kernel only reschedules rays: image and counters are bit-identical to the
+    lockstep kernel's, for ragged sizes too (partial batches, queue flush at the tail)."""
+    osys, ctx = ctxs(name)
+    for n in (1, 63, 64, 65, 4097, 250_003):
+        out = []
+        for variant in (0, 1, 2, 3):      # lockstep/queued x filtered/literal predicates
+            ctx.set_kernel_variant(variant)
+            ctx.reset()
+            ctx.trace(1, 5, n, SEED)
+            ctx.trace(2, 11, n, SEED)
+            out.append(ctx.read())
+        ctx.set_kernel_variant(1)
+        for v in (1, 2, 3):
+            assert np.array_equal(out[0][0], out[v][0]), (name, n, v)
+            assert np.array_equal(out[0][1], out[v][1]), (name, n, v, out[0][1], out[v][1])
+
+
+def _special_rays(osys):
+    """Rays that sit ON the decision boundaries the filtered predicates guard: normal incidence
+    (costt == 1 exactly), grazing / total-reflection geometry, tangent rays (discriminant ~ 0),
+    rays through the exact aperture edge and bin edges, u = 0 and u = 1 - 2^-53."""
+    rng = np.random.default_rng(99)
+    l2 = osys.L2[0]
+    rays = []
+    # on-axis and axis-parallel
+    for x, y in [(0, 0), (1e-3, 0), (0, -2e-3), (l2.radius, 0), (0, l2.radius), (l2.radius * (1 + 1e-16), 0)]:
+        rays.append([x, y, 0.0, 0.0, 0.0, 1.0])
+    # steep rays around the critical angle inside the bottle / towards the lens edge
+    for th in np.linspace(0.30, 1.55, 40):
+        for ph in (0.0, 0.7, 1.57079632679, 3.1):
+            rays.append([0, 0, 0, np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)])
+    # tangent-ish rays to the bottle cylinder / lens spheres from displaced origins
+    R = osys.bottle.radiusa - osys.bottle.thickness
+    for eps in (0.0, 1e-16, -1e-16, 1e-12, -1e-12, 1e-9):
+        rays.append([0.0, R * (1 + eps), osys.bottle.centre[2], 0.0, 0.0, 1.0])
+        rays.append([1e-3, (R - 1e-3) * (1 + eps), osys.bottle.centre[2] - 0.01, 0.0, 1e-3, 1.0])
+    # exact bin edges at the image plane: straight rays at multiples of the bin width
+    bw = osys.bin_width
+    for k in (-200, -1, 0, 1, 7, 200, 201):
+        rays.append([k * bw, -k * bw, osys.img_plane - 1e-3, 0.0, 0.0, 1.0])
+    a = np.array(rays, dtype=np.float64).T.copy()
+    n = a.shape[1]
+    u = rng.random((9, n))
+    u[:, ::5] = 0.0
+    u[:, 1::5] = 1.0 - 2.0 ** -53
+    return a, u
+
+
+@pytest.mark.parametrize("name", ["large", "small", "ellipse", "small_iris_after"])
+@pytest.mark.parametrize("phase", [1, 2])
+def test_boundary_rays_bit_exact_in_both_predicate_modes(ctxs, name, phase):
+    osys, ctx = ctxs(name)
+    orc = _oracle(osys)
+    a, u = _special_rays(osys)
+    n = a.shape[1]
+    want = orc.trace_rays(phase, n, pos_dir_in=a, u=u, draw_base=0)
+    for variant in (1, 3):                  # debug entry: filtered / literal predicates
+        ctx.set_kernel_variant(variant)
+        got = ctx.trace_rays(phase, n, pos_dir_in=a, u=u, draw_base=0)
+        ok = np.isfinite(want["pos_dir"]).all(0)
+        assert np.array_equal(got["status"], want["status"]), (variant, np.nonzero(got["status"] != want["status"]))
+        assert np.array_equal(got["n_isect"], want["n_isect"]) and np.array_equal(got["n_draws"], want["n_draws"])
+        assert np.array_equal(got["bin_xy"], want["bin_xy"])
+        assert np.array_equal(got["pos_dir"][:, ok], want["pos_dir"][:, ok])
+        assert np.array_equal(np.isnan(got["pos_dir"]), np.isnan(want["pos_dir"]))
+    ctx.set_kernel_variant(1)
