@@ -61,3 +61,31 @@ def test_gpu_statistics_match_reference_program(hip_library, name):
         img, cnt = ctx.read()
     assert_same_distribution(img[0], ring, n, n_ref, f"{name} ring")
     assert_same_distribution(img[1], point, n, n_ref, f"{name} point")
+
+
+@pytest.mark.gpu
+def test_end_to_end_settings_file_run(hip_library, tmp_path):
+    """`bin/raytrace <settings>` replaced: same settings text in, same files out."""
+    import os
+    from opticalraytrace_amd.params import Settings, resource_dir
+    from opticalraytrace_amd.tracer import run_settings_file
+    g = load_golden("refprog_small")
+    s = Settings(nphotons=1_000_000, make_images=True, bottle_file="clearBottle-small.params",
+                 data_folder="run")
+    cfg = tmp_path / "cfg.params"
+    s.write(str(cfg))
+    res = run_settings_file(str(cfg), res_dir=resource_dir(), data_dir=str(tmp_path / "data"), verbose=False)
+    folder = tmp_path / "data" / "run"
+    stem = str(g["stem"])
+    for layer in ("ring", "point", "total"):
+        f = folder / f"{stem}_image-{layer}.dat"
+        assert f.exists() and f.stat().st_size == 401 * 401 * 8
+    tot = np.fromfile(folder / f"{stem}_image-total.dat", np.float64)
+    assert tot.sum() == res.image.sum() and tot.sum() > 0
+    rows = open(folder / "trans-stats.dat").read().splitlines()
+    assert len(rows) == 2 and rows[0].lstrip().startswith("r/%")
+    # the reference program printed 2.46 % / 60.07 % for this set-up at 1e6 rays
+    assert abs(res.ring_transmitted - 2.46) < 0.1 and abs(res.point_transmitted - 60.07) < 0.3
+    ring, point = _ref_layers(g)
+    assert_same_distribution(res.image[0], ring, 1_000_000, int(g["nphotons"]), "ring")
+    assert_same_distribution(res.image[1], point, 1_000_000, int(g["nphotons"]), "point")
