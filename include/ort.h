@@ -183,8 +183,10 @@ int ort_last_kernel_ms(ort_ctx *ctx, int kind, float *ms);
 int ort_set_timing(ort_ctx *ctx, int enable);
 /* Tuning / A-B knob, a bit mask: bit 0 set (default) = queued kernel (LDS ray queue between
  * segments), clear = plain lockstep kernel; bit 1 set = every predicate evaluated literally
- * (no filtered predicates, see csrc/ort_device.h), clear (default) = filtered.  All four
- * combinations produce bit-identical rays, images and counters.  Default 1. */
+ * (no filtered predicates, see csrc/ort_device.h), clear (default) = filtered; bit 2 set =
+ * bin straight into the image, clear (default) = bin into 8 private replicas folded into the
+ * image after the launch.  All combinations produce bit-identical rays, images and
+ * counters.  Default 1. */
 int ort_set_kernel_variant(ort_ctx *ctx, int variant);
 
 #ifdef __cplusplus

@@ -231,14 +231,14 @@ def test_queued_kernel_equals_lockstep_kernel(ctxs, name):
     osys, ctx = ctxs(name)
     for n in (1, 63, 64, 65, 4097, 250_003):
         out = []
-        for variant in (0, 1, 2, 3):      # lockstep/queued x filtered/literal predicates
+        for variant in (0, 1, 2, 3, 5, 6):   # lockstep/queued x filtered/literal x replicas/direct
             ctx.set_kernel_variant(variant)
             ctx.reset()
             ctx.trace(1, 5, n, SEED)
             ctx.trace(2, 11, n, SEED)
             out.append(ctx.read())
         ctx.set_kernel_variant(1)
-        for v in (1, 2, 3):
+        for v in range(1, len(out)):
             assert np.array_equal(out[0][0], out[v][0]), (name, n, v)
             assert np.array_equal(out[0][1], out[v][1]), (name, n, v, out[0][1], out[v][1])
 

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--bottle", default="clearBottle-large.params")
     ap.add_argument("--variants", default="0,1,2,3")
+    ap.add_argument("--phases", default="2,1")
     args = ap.parse_args()
     global VARIANTS
     VARIANTS = [int(v) for v in args.variants.split(',')]
@@ -29,7 +30,7 @@ def main():
     ctx.set_timing(True)
     res = {}
     for rnd in range(args.rounds + 1):
-        for phase in (2, 1):
+        for phase in [int(p) for p in args.phases.split(',')]:
             for variant in VARIANTS:
                 ctx.set_kernel_variant(variant)
                 ctx.reset()
