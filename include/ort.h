@@ -181,6 +181,11 @@ int ort_synchronize(ort_ctx *ctx);
  * trace, 1 resident trace, 2 emit. */
 int ort_last_kernel_ms(ort_ctx *ctx, int kind, float *ms);
 int ort_set_timing(ort_ctx *ctx, int enable);
+/* Arithmetic of the traced path from now on: 0 (default) = fp64, the reference's arithmetic
+ * (all `real` are fp64, src/Makefile:2), bit-exact; 1 = fp32 study path (BASELINE configs[4]):
+ * the same operations in single precision, uniforms = top 24 bits of the same draws.  It has
+ * no reference to be exact against; tests/test_gpu_fp32.py measures its deviation from fp64. */
+int ort_set_precision(ort_ctx *ctx, int precision);
 /* Tuning / A-B knob, a bit mask: bit 0 set (default) = queued kernel (LDS ray queue between
  * segments), clear = plain lockstep kernel; bit 1 set = every predicate evaluated literally
  * (no filtered predicates, see csrc/ort_device.h), clear (default) = filtered; bit 2 set =

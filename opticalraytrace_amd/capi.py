@@ -134,6 +134,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ort_last_kernel_ms": (C.c_int, [vp, i32, C.POINTER(C.c_float)]),
         "ort_set_timing": (C.c_int, [vp, i32]),
         "ort_set_kernel_variant": (C.c_int, [vp, i32]),
+        "ort_set_precision": (C.c_int, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a symbol
@@ -150,7 +151,7 @@ EXPORTED_SYMBOLS = ["ort_abi_version", "ort_last_error", "ort_device_count", "or
                     "ort_trace_resident", "ort_trace_rays", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
                     "ort_device_counters", "ort_synchronize", "ort_last_kernel_ms",
-                    "ort_set_timing", "ort_set_kernel_variant"]
+                    "ort_set_timing", "ort_set_kernel_variant", "ort_set_precision"]
 
 
 def _check(lib, rc: int, what: str) -> None:
@@ -250,6 +251,10 @@ class Context:
 
     def set_kernel_variant(self, variant: int) -> None:
         _check(self.lib, self.lib.ort_set_kernel_variant(self._h, variant), "ort_set_kernel_variant")
+
+    def set_precision(self, precision: int) -> None:
+        """0 = fp64 (reference arithmetic, default), 1 = fp32 study path."""
+        _check(self.lib, self.lib.ort_set_precision(self._h, precision), "ort_set_precision")
 
     def last_kernel_ms(self, kind: int = 0) -> float:
         ms = C.c_float()

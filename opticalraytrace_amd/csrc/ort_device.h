@@ -46,13 +46,18 @@ __host__ __device__ inline uint64_t stream_base(uint64_t seed, int phase)
     return mix64(seed ^ (kGolden * (uint64_t)phase));
 }
 
-// top 53 bits of x as a double in [0,1): both halves convert exactly and their
-// sum has <= 53 significant bits, so this equals (double)(x >> 11) * 2^-53.
+// top 53 bits of x as a double in [0,1) = (double)(x >> 11) * 2^-53, exactly, without the
+// quarter-rate int->fp64 conversions: 2^84 + hi*2^32 and 2^52 + lo are built from bits
+// (0x453.. / 0x433.. exponent words), their difference from (2^84 + 2^52) is the exact
+// 53-bit integer hi*2^32 + lo, and the final scaling is a power of two.
 __device__ inline double bits_to_unit(uint64_t x)
 {
-    uint32_t hi = (uint32_t)(x >> 32);
-    uint32_t lo = (uint32_t)(x >> 11) & 0x1FFFFFu;
-    return (double)hi * 0x1.0p-32 + (double)lo * 0x1.0p-53;
+    const uint32_t hi = (uint32_t)(x >> 43);               // top 21 bits
+    const uint32_t lo = (uint32_t)(x >> 11);               // next 32 bits
+    const double dh = __hiloint2double(0x45300000, (int)hi);   // 2^84 + hi * 2^32
+    const double dl = __hiloint2double(0x43300000, (int)lo);   // 2^52 + lo
+    const double v = (dh - 0x1.00000001p84) + dl;              // (hi*2^32 - 2^52) + (2^52 + lo), both steps exact
+    return v * 0x1.0p-53;
 }
 
 // Per-ray draw source.  peek() is the next uniform, advance(c) consumes it where c.
@@ -84,7 +89,12 @@ struct Draws {
         z += c ? kGolden : 0ull;
     }
     __device__ inline double next() { double u = peek(); advance(true); return u; }
+    template <class T> __device__ inline T peek_as() const { return (T)peek(); }
+    template <class T> __device__ inline T next_as() { return (T)next(); }
 };
+
+// fp32 path: the top 24 bits of the SAME 64-bit draw, so a ray sees (to 2^-24) the same uniform
+__device__ inline float bits_to_unit_f32(uint64_t x) { return (float)(uint32_t)(x >> 40) * 0x1.0p-24f; }
 
 // keyed-only variant used by the production kernels (one 64-bit counter per lane)
 struct KeyedDraws {
@@ -100,6 +110,17 @@ struct KeyedDraws {
 #endif
     __device__ inline void advance(bool c) { z += c ? kGolden : 0ull; }
     __device__ inline double next() { z += kGolden; return bits_to_unit(mix64(z)); }
+    template <class T> __device__ inline T peek_as() const
+    {
+        if constexpr (sizeof(T) == 8) return peek();
+        else return bits_to_unit_f32(mix64(z + kGolden));
+    }
+    template <class T> __device__ inline T next_as()
+    {
+        T u = peek_as<T>();
+        z += kGolden;
+        return u;
+    }
 };
 
 // Development-only ablation switches (tools/ablate.sh): they BREAK the numerics contract
@@ -118,23 +139,67 @@ struct KeyedDraws {
 // ----------------------------------------------------------------------------
 // 3-vector algebra, src/vector_class.f90:48-186
 // ----------------------------------------------------------------------------
-struct Vec { double x, y, z; };
+// T = double is the reference's arithmetic (all `real` are fp64).  T = float is the fp32 study
+// path of BASELINE configs[4]: same operations, single precision, literal predicates only.
+template <class T> struct VecT { T x, y, z; };
+using Vec = VecT<double>;
 
-__device__ inline Vec vsub(Vec a, Vec b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ inline Vec vadd(Vec a, Vec b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ inline Vec vscale(Vec a, double s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ inline double vdot(Vec a, Vec b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
-__device__ inline Vec vselect(bool c, Vec a, Vec b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
-// magnitude_fn (:175-186): NORMALISES, by three divisions
-__device__ inline Vec vnormalise(Vec a)
+template <class T> __device__ inline VecT<T> vsub(VecT<T> a, VecT<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> __device__ inline VecT<T> vadd(VecT<T> a, VecT<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class T> __device__ inline VecT<T> vscale(VecT<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class T> __device__ inline T vdot(VecT<T> a, VecT<T> b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+template <class T> __device__ inline VecT<T> vselect(bool c, VecT<T> a, VecT<T> b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
+__device__ inline bool wave_any(bool p) { return __ballot(p) != 0ull; }
+
+// x/t, y/t, z/t — three IEEE-754 divisions by the same denominator — with the
+// reciprocal refinement done once.  This is the compiler's own fp64 division
+// sequence (v_div_scale / v_rcp / 2 Newton steps / v_div_fmas / v_div_fixup)
+// with the denominator-only half shared; it is taken only when v_div_scale
+// returns the same scaled denominator for all three numerators (always, outside
+// the subnormal/overflow corners), so each quotient is bit-for-bit `x / t`.
+__device__ inline VecT<float> div3(VecT<float> v, float t) { return {v.x / t, v.y / t, v.z / t}; }
+
+__device__ inline Vec div3(Vec v, double t)
 {
-    double tmp = ORT_SQRT(a.x * a.x + a.y * a.y + a.z * a.z);
-    return {ORT_DIV(a.x, tmp), ORT_DIV(a.y, tmp), ORT_DIV(a.z, tmp)};
+#if defined(ORT_ABL_FASTDIV)
+    return {ORT_DIV(v.x, t), ORT_DIV(v.y, t), ORT_DIV(v.z, t)};
+#else
+    bool f0, f1, f2, fd;
+    const double d0 = __builtin_amdgcn_div_scale(v.x, t, false, &fd);
+    const double d1 = __builtin_amdgcn_div_scale(v.y, t, false, &fd);
+    const double d2 = __builtin_amdgcn_div_scale(v.z, t, false, &fd);
+    const bool shared = (d0 == d1) && (d0 == d2);
+    double r = __builtin_amdgcn_rcp(d0);
+    double e = __builtin_fma(-d0, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d0, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double n0 = __builtin_amdgcn_div_scale(v.x, t, true, &f0);
+    const double n1 = __builtin_amdgcn_div_scale(v.y, t, true, &f1);
+    const double n2 = __builtin_amdgcn_div_scale(v.z, t, true, &f2);
+    const double m0 = n0 * r, m1 = n1 * r, m2 = n2 * r;
+    Vec q;
+    q.x = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-d0, m0, n0), r, m0, f0), t, v.x);
+    q.y = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-d0, m1, n1), r, m1, f1), t, v.y);
+    q.z = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-d0, m2, n2), r, m2, f2), t, v.z);
+    if (wave_any(!shared)) {        // NaN or extreme exponents: plain divisions for those lanes
+        q.x = shared ? q.x : v.x / t;
+        q.y = shared ? q.y : v.y / t;
+        q.z = shared ? q.z : v.z / t;
+    }
+    return q;
+#endif
 }
 
-struct Ray { Vec pos, dir; };
+// magnitude_fn (:175-186): NORMALISES, by three divisions
+template <class T> __device__ inline VecT<T> vnormalise(VecT<T> a)
+{
+    T tmp = ORT_SQRT(a.x * a.x + a.y * a.y + a.z * a.z);
+    return div3(a, tmp);
+}
 
-__device__ inline bool wave_any(bool p) { return __ballot(p) != 0ull; }
+template <class T> struct RayT { VecT<T> pos, dir; };
+using Ray = RayT<double>;
 
 // ----------------------------------------------------------------------------
 // Filtered predicates (FILT = true, the production setting).
@@ -168,6 +233,32 @@ __device__ inline double rsq_approx(double s)
     return __builtin_fma(y, e, y);
 }
 
+// The staged system as the kernels see it.  For T = double this is ort_system itself (the
+// device copy is staged byte for byte); for T = float a converted copy is staged.
+template <class T> struct SurfaceT {
+    T cx, cy, cz, radius, radius_b, n1, n2, eta, aperture;
+    int32_t kind;
+    uint32_t flags;
+};
+template <class T> struct SystemT {
+    int32_t n_surfaces[2], split[2], ring_ellipse, pad;
+    SurfaceT<T> surfaces[2][ORT_MAX_SURFACES];
+    T cos_theta_max, ring_r1, ring_r2, ring_lens_r2, ring_lens_z, ring_bottle_ra, ring_bottle_rb, ring_bottle_z;
+    T bin_width, inv_bin_width, na_cos_min, twopi;
+};
+template <class T> struct SysTypes { using Sys = SystemT<T>; using Surf = SurfaceT<T>; };
+template <> struct SysTypes<double> { using Sys = ort_system; using Surf = ort_surface; };
+
+template <class T> __device__ inline bool aperture_present(T a);
+template <> __device__ inline bool aperture_present<double>(double a)
+{
+    return __builtin_amdgcn_readfirstlane(__double2hiint(a)) >= 0;
+}
+template <> __device__ inline bool aperture_present<float>(float a)
+{
+    return __builtin_amdgcn_readfirstlane(__float_as_int(a)) >= 0;
+}
+
 // ----------------------------------------------------------------------------
 // solveQuadratic (src/surfaces.f90:227-260) + root choice (:75-86), predicated.
 // Away from tangency the order of the two roots follows from signs alone
@@ -177,36 +268,37 @@ __device__ inline double rsq_approx(double s)
 //   q > 0 : roots c/q <= q/a ; c/q < 0 <=> c < 0  -> t = c < 0 ? q/a : c/q   (always a hit)
 //   q < 0 : q/a < 0 ; hit <=> c/q >= 0 <=> c <= 0 -> t = c/q
 // ----------------------------------------------------------------------------
-template <bool FILT>
-__device__ inline void solve_and_pick(double a, double b, double c, bool live, double &t, bool &hit)
+template <bool FILT, class T>
+__device__ inline void solve_and_pick(T a, T b, T c, bool live, T &t, bool &hit)
 {
-    const double discrim = b * b - 4.0 * a * c;
-    const bool neg = discrim < 0.0;                   // :243 — no real root
-    const double sq = ORT_SQRT(discrim);                  // NaN when neg: those lanes are misses
-    const double q = (b > 0.0) ? -0.5 * (b + sq) : -0.5 * (b - sq);
+    static_assert(!FILT || sizeof(T) == 8, "filtered predicates are derived for fp64 only");
+    const T discrim = b * b - T(4.0) * a * c;
+    const bool neg = discrim < T(0.0);                // :243 — no real root
+    const T sq = ORT_SQRT(discrim);                   // NaN when neg: those lanes are misses
+    const T q = (b > T(0.0)) ? T(-0.5) * (b + sq) : T(-0.5) * (b - sq);
     bool ok = false;
-    t = 0.0;
+    t = T(0.0);
     hit = false;
     if (FILT) {
-        const double bb = b * b;
-        ok = discrim > 1e-10 * bb && a > 1e-10 && a < 1e10 && bb < 1e200 &&
-             fabs(q) > 1e-100 && (c == 0.0 || fabs(c) > 1e-200);
-        const bool qpos = q > 0.0;
-        const bool use_qa = qpos && (c < 0.0);
+        const T bb = b * b;
+        ok = discrim > T(1e-10) * bb && a > T(1e-10) && a < T(1e10) && bb < T(1e200) &&
+             fabs(q) > T(1e-100) && (c == T(0.0) || fabs(c) > T(1e-200));
+        const bool qpos = q > T(0.0);
+        const bool use_qa = qpos && (c < T(0.0));
         t = ORT_DIV(use_qa ? q : c, use_qa ? a : q);
-        hit = qpos || !(c > 0.0);
+        hit = qpos || !(c > T(0.0));
     }
     const bool slow = !neg && !ok;                    // tangent, degenerate or NaN: literal formula
     if (wave_any(live && slow)) {
-        const bool dz = discrim == 0.0;               // :245-247
-        const double xd = -0.5 * b / a;
-        double t0 = dz ? xd : q / a;
-        double t1 = dz ? xd : c / q;
+        const bool dz = discrim == T(0.0);            // :245-247
+        const T xd = T(-0.5) * b / a;
+        T t0 = dz ? xd : q / a;
+        T t1 = dz ? xd : c / q;
         const bool sw = t0 > t1;                      // :75-79
-        const double lo = sw ? t1 : t0, hi = sw ? t0 : t1;
-        const bool lneg = lo < 0.0;                   // :80-83
+        const T lo = sw ? t1 : t0, hi = sw ? t0 : t1;
+        const bool lneg = lo < T(0.0);                // :80-83
         t = slow ? (lneg ? hi : lo) : t;
-        hit = slow ? !(lneg && hi < 0.0) : hit;
+        hit = slow ? !(lneg && hi < T(0.0)) : hit;
     }
     hit = hit && !neg;
 }
@@ -214,48 +306,49 @@ __device__ inline void solve_and_pick(double a, double b, double c, bool live, d
 // intersect_sphere (src/surfaces.f90:52-89) and intersect_cylinder (:91-130) in
 // one body: the x-axis cylinder is the sphere with the x terms removed
 // (a = dz^2+dy^2 etc. — fp addition commutes, so the sums are bit-identical).
-template <bool FILT>
-__device__ inline void intersect_quadric(const Ray &r, double cx, double cy, double cz, double radius,
-                                         bool cylinder, bool live, double &t, bool &hit)
+template <bool FILT, class T>
+__device__ inline void intersect_quadric(const RayT<T> &r, T cx, T cy, T cz, T radius,
+                                         bool cylinder, bool live, T &t, bool &hit)
 {
-    double Lx = cylinder ? 0.0 : r.pos.x - cx;
-    double Ly = r.pos.y - cy;
-    double Lz = r.pos.z - cz;
-    double dx = cylinder ? 0.0 : r.dir.x;
-    double a = (dx * dx) + (r.dir.y * r.dir.y) + (r.dir.z * r.dir.z);
-    double b = 2.0 * ((dx * Lx) + (r.dir.y * Ly) + (r.dir.z * Lz));
-    double c = ((Lx * Lx) + (Ly * Ly) + (Lz * Lz)) - radius * radius;
+    T Lx = cylinder ? T(0.0) : r.pos.x - cx;
+    T Ly = r.pos.y - cy;
+    T Lz = r.pos.z - cz;
+    T dx = cylinder ? T(0.0) : r.dir.x;
+    T a = (dx * dx) + (r.dir.y * r.dir.y) + (r.dir.z * r.dir.z);
+    T b = T(2.0) * ((dx * Lx) + (r.dir.y * Ly) + (r.dir.z * Lz));
+    T c = ((Lx * Lx) + (Ly * Ly) + (Lz * Lz)) - radius * radius;
     solve_and_pick<FILT>(a, b, c, live, t, hit);
 }
 
 // intersect_ellipse, src/surfaces.f90:133-176
-template <bool FILT>
-__device__ inline void intersect_ellipse(const Ray &r, double cy, double cz, double semia, double semib,
-                                         bool live, double &t, bool &hit)
+template <bool FILT, class T>
+__device__ inline void intersect_ellipse(const RayT<T> &r, T cy, T cz, T semia, T semib,
+                                         bool live, T &t, bool &hit)
 {
-    double sa = 1. / (semia * semia);
-    double sb = 1. / (semib * semib);
-    double Ly = r.pos.y - cy;
-    double Lz = r.pos.z - cz;
-    double a = sa * (r.dir.z * r.dir.z) + sb * (r.dir.y * r.dir.y);
-    double b = 2 * (sa * r.dir.z * Lz + sb * r.dir.y * Ly);
-    double c = sa * (Lz * Lz) + sb * (Ly * Ly) - 1;
+    T sa = T(1.) / (semia * semia);
+    T sb = T(1.) / (semib * semib);
+    T Ly = r.pos.y - cy;
+    T Lz = r.pos.z - cz;
+    T a = sa * (r.dir.z * r.dir.z) + sb * (r.dir.y * r.dir.y);
+    T b = T(2) * (sa * r.dir.z * Lz + sb * r.dir.y * Ly);
+    T c = sa * (Lz * Lz) + sb * (Ly * Ly) - T(1);
     solve_and_pick<FILT>(a, b, c, live, t, hit);
 }
 
 // fresnel, src/surfaces.f90:336-372, as one expression (eta = n1/n2 rounded once on
 // the host).  costt > 1 (rounding at normal incidence) makes sintt NaN, every
 // comparison false, tir NaN -> 1: the reference then ALWAYS reflects; kept.
-__device__ inline double fresnel(double costt, double n1, double n2, double eta)
+template <class T>
+__device__ inline T fresnel(T costt, T n1, T n2, T eta)
 {
-    double sintt = ORT_SQRT(1. - costt * costt);
-    double sint2 = eta * sintt;
-    double cost2 = ORT_SQRT(1. - sint2 * sint2);
-    double r1 = fabs((n1 * costt - n2 * cost2) / (n1 * costt + n2 * cost2));
-    double r2 = fabs((n1 * cost2 - n2 * costt) / (n1 * cost2 + n2 * costt));
-    double tir = 0.5 * (r1 * r1 + r2 * r2);
-    tir = (tir != tir || tir > 1. || tir < 0.) ? 1. : tir;     // :366-369
-    return (sint2 > 1.) ? 1.0 : ((costt == 1.) ? 0. : tir);    // :353-358
+    T sintt = ORT_SQRT(T(1.) - costt * costt);
+    T sint2 = eta * sintt;
+    T cost2 = ORT_SQRT(T(1.) - sint2 * sint2);
+    T r1 = fabs((n1 * costt - n2 * cost2) / (n1 * costt + n2 * cost2));
+    T r2 = fabs((n1 * cost2 - n2 * costt) / (n1 * cost2 + n2 * costt));
+    T tir = T(0.5) * (r1 * r1 + r2 * r2);
+    tir = (tir != tir || tir > T(1.) || tir < T(0.)) ? T(1.) : tir;     // :366-369
+    return (sint2 > T(1.)) ? T(1.0) : ((costt == T(1.)) ? T(0.) : tir);  // :353-358
 }
 
 // reflect_refract (src/surfaces.f90:262-282) with reflect (:285-300) and refract
@@ -265,15 +358,15 @@ __device__ inline double fresnel(double costt, double n1, double n2, double eta)
 // reciprocals and with refract's own c2 standing in for fresnel's cost2 (the same
 // quantity, rounded along another path; they differ by < 1e-13 once k > 1e-6).
 // |R' - R| < 1e-12, the margin is 1e-10.
-template <bool FILT>
-__device__ inline bool reflect_refract(Vec &I, Vec N, double n1, double n2, double eta, double u, bool live)
+template <bool FILT, class T>
+__device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta, T u, bool live)
 {
-    const double c1s = vdot(N, I);                       // == vdot(I, N): the products commute
-    const double c1 = fabs(c1s);                         // costt (fresnel) and |c1| (refract)
-    const double k = 1.0 - eta * eta * (1.0 - c1 * c1);  // refract's radicand, refract's order (:327)
-    const double c2 = ORT_SQRT(k);                           // NaN beyond total reflection: unused there
+    const T c1s = vdot(N, I);                            // == vdot(I, N): the products commute
+    const T c1 = fabs(c1s);                              // costt (fresnel) and |c1| (refract)
+    const T k = T(1.0) - eta * eta * (T(1.0) - c1 * c1); // refract's radicand, refract's order (:327)
+    const T c2 = ORT_SQRT(k);                            // NaN beyond total reflection: unused there
     bool reflected = false, decided = false;
-    if (FILT) {
+    if constexpr (FILT) {
         double a1 = n1 * c1, b1 = n2 * c2, a2 = n1 * c2, b2 = n2 * c1;
         double f1 = (a1 - b1) * rcp_approx(a1 + b1);
         double f2 = (a2 - b2) * rcp_approx(a2 + b2);
@@ -286,67 +379,71 @@ __device__ inline bool reflect_refract(Vec &I, Vec N, double n1, double n2, doub
         bool rl = u <= fresnel(c1, n1, n2, eta);         // :275
         reflected = decided ? reflected : rl;
     }
-    const Vec refl = vsub(I, vscale(N, 2. * c1s));       // :297
-    const Vec Nt = (c1s < 0.) ? N : vscale(N, -1.);      // :320-325
-    const Vec refr = vadd(vscale(I, eta), vscale(Nt, eta * c1 - c2));   // :329
+    const VecT<T> refl = vsub(I, vscale(N, T(2.) * c1s));      // :297
+    const VecT<T> Nt = (c1s < T(0.)) ? N : vscale(N, T(-1.));  // :320-325
+    const VecT<T> refr = vadd(vscale(I, eta), vscale(Nt, eta * c1 - c2));   // :329
     I = vselect(live, vselect(reflected, refl, refr), I);
     return reflected;
 }
 
 // aperture test `sqrt(x^2+y^2) > A` (lens.f90:450-454, :576-580, :559-563): decided on
 // the squares unless they agree to 1e-12 (then the reference's square root is taken)
-template <bool FILT>
-__device__ inline bool outside_aperture(double x, double y, double A, bool live)
+template <bool FILT, class T>
+__device__ inline bool outside_aperture(T x, T y, T A, bool live)
 {
-    const double s2 = x * x + y * y;
-    const double A2 = A * A;
+    const T s2 = x * x + y * y;
+    const T A2 = A * A;
     bool out = s2 > A2;
-    const bool near = FILT ? !(fabs(s2 - A2) > 1e-12 * A2) : true;
+    const bool near = FILT ? !(fabs(s2 - A2) > T(1e-12) * A2) : true;
     if (wave_any(live && near)) out = near ? (ORT_SQRT(s2) > A) : out;
     return out;
 }
+
+template <class T> __device__ inline void sincos_t(T x, T *s, T *c);
+template <> __device__ inline void sincos_t<double>(double x, double *s, double *c) { sincos(x, s, c); }
+template <> __device__ inline void sincos_t<float>(float x, float *s, float *c) { sincosf(x, s, c); }
 
 // ----------------------------------------------------------------------------
 // emitters (straight-line)
 // ----------------------------------------------------------------------------
 // point, src/sourceMod.f90:12-47 (called without offset, src/main.f90:136)
-template <class D>
-__device__ inline void emit_point(const ort_system &S, Ray &r, D &draws)
+template <class T, class Sys, class D>
+__device__ inline void emit_point(const Sys &S, RayT<T> &r, D &draws)
 {
-    double phi = S.twopi * draws.next();
-    double sinp, cosp;
-    sincos(phi, &sinp, &cosp);
-    double ran = draws.next();
-    double cost = (1.0 - ran) + ran * S.cos_theta_max;
-    double sint = ORT_SQRT(1.0 - cost * cost);
+    T phi = S.twopi * draws.template next_as<T>();
+    T sinp, cosp;
+    sincos_t<T>(phi, &sinp, &cosp);
+    T ran = draws.template next_as<T>();
+    T cost = (T(1.0) - ran) + ran * S.cos_theta_max;
+    T sint = ORT_SQRT(T(1.0) - cost * cost);
     r.dir = {sint * cosp, sint * sinp, cost};
-    r.pos = {0.0, 0.0, 0.0};
+    r.pos = {T(0.0), T(0.0), T(0.0)};
 }
 
 // ring, src/sourceMod.f90:250-300
-template <class D>
-__device__ inline void emit_ring(const ort_system &S, Ray &r, D &draws)
+template <class T, class Sys, class D>
+__device__ inline void emit_ring(const Sys &S, RayT<T> &r, D &draws)
 {
-    double rr = S.ring_r1 + draws.next() * (S.ring_r2 - S.ring_r1);       // ranu(r1, r2)
-    double theta = draws.next() * S.twopi;
-    double st, ct;
-    sincos(theta, &st, &ct);
-    double sq = ORT_SQRT(rr);
-    double posx = sq * ct;
-    double posy = sq * st;
-    double Ra = S.ring_bottle_ra;
-    double q = S.ring_ellipse ? posy * Ra / S.ring_bottle_rb : posy;       // :277 vs :279
-    double posz = S.ring_bottle_z + ORT_SQRT(Ra * Ra - q * q);
+    T rr = S.ring_r1 + draws.template next_as<T>() * (S.ring_r2 - S.ring_r1);     // ranu(r1, r2)
+    T theta = draws.template next_as<T>() * S.twopi;
+    T st, ct;
+    sincos_t<T>(theta, &st, &ct);
+    T sq = ORT_SQRT(rr);
+    T posx = sq * ct;
+    T posy = sq * st;
+    T Ra = S.ring_bottle_ra;
+    T q = S.ring_ellipse ? posy * Ra / S.ring_bottle_rb : posy;            // :277 vs :279
+    T posz = S.ring_bottle_z + ORT_SQRT(Ra * Ra - q * q);
     r.pos = {posx, posy, posz};
-    rr = 0. + draws.next() * (S.ring_lens_r2 - 0.);                        // ranu(0., (radius+10e-3)**2)
-    theta = draws.next() * S.twopi;
-    sincos(theta, &st, &ct);
+    rr = T(0.) + draws.template next_as<T>() * (S.ring_lens_r2 - T(0.));           // ranu(0., (radius+10e-3)**2)
+    theta = draws.template next_as<T>() * S.twopi;
+    sincos_t<T>(theta, &st, &ct);
     sq = ORT_SQRT(rr);
-    double ex = sq * ct - r.pos.x;
-    double ey = sq * st - r.pos.y;
-    double ez = S.ring_lens_z - r.pos.z;
-    double dist = ORT_SQRT(ex * ex + ey * ey + ez * ez);
-    r.dir = vnormalise({ORT_DIV(ex, dist), ORT_DIV(ey, dist), ORT_DIV(ez, dist)});
+    T ex = sq * ct - r.pos.x;
+    T ey = sq * st - r.pos.y;
+    T ez = S.ring_lens_z - r.pos.z;
+    T dist = ORT_SQRT(ex * ex + ey * ey + ez * ez);
+    r.dir = vnormalise(div3(VecT<T>{ex, ey, ez}, dist));
 }
 
 // ----------------------------------------------------------------------------
@@ -357,27 +454,27 @@ __device__ inline void emit_ring(const ort_system &S, Ray &r, D &draws)
 // reference's).  NaN / x > 1 fall through as accepted, exactly as
 // `if(angle > na) return` does with a NaN angle.  Returns the ORT_ST_* status.
 // ----------------------------------------------------------------------------
-template <bool FILT>
-__device__ inline int make_image(const ort_system &S, const Ray &r, bool live, int &xp, int &yp)
+template <bool FILT, class T, class Sys>
+__device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int &xp, int &yp)
 {
     bool na_decided = false, reject = false;
-    if (FILT) {
+    if constexpr (FILT) {
         // x = dir_z / |dir| up to 1e-13; the literal form below rounds it five more times
         double xa = r.dir.z * rsq_approx(vdot(r.dir, r.dir));
         na_decided = fabs(xa - S.na_cos_min) > 1e-10;
         reject = xa < S.na_cos_min;
     }
     if (wave_any(live && !na_decided)) {
-        Vec d = vnormalise(r.dir);
-        d = vscale(d, -1.);
-        double top = (0. * d.x) + (0. * d.y) + (-1. * d.z);
-        double bottom = ORT_SQRT(vdot(d, d)) * 1.0;
+        VecT<T> d = vnormalise(r.dir);
+        d = vscale(d, T(-1.));
+        T top = (T(0.) * d.x) + (T(0.) * d.y) + (T(-1.) * d.z);
+        T bottom = ORT_SQRT(vdot(d, d)) * T(1.0);
         bool rl = (top / bottom) < S.na_cos_min;
         reject = na_decided ? reject : rl;
     }
-    double fx = 0., fy = 0.;
+    T fx = T(0.), fy = T(0.);
     bool bin_decided = false;
-    if (FILT) {
+    if constexpr (FILT) {
         // floor(x / binwid) from one multiply unless the quotient is within 1e-6 of an integer
         // (|q * 2.3e-16| < 1e-9 for |q| < 4e6)
         double qx = r.pos.x * S.inv_bin_width, qy = r.pos.y * S.inv_bin_width;
@@ -387,12 +484,12 @@ __device__ inline int make_image(const ort_system &S, const Ray &r, bool live, i
                       fabs(qx) < 1e6 && fabs(qy) < 1e6;
     }
     if (wave_any(live && !reject && !bin_decided)) {
-        double lx = floor(r.pos.x / S.bin_width), ly = floor(r.pos.y / S.bin_width);
+        T lx = floor(r.pos.x / S.bin_width), ly = floor(r.pos.y / S.bin_width);
         fx = bin_decided ? fx : lx;
         fy = bin_decided ? fy : ly;
     }
-    const bool off = (r.pos.x > 1000 || r.pos.y > 1000) ||            // :48
-                     !(fabs(fx) <= 200.) || !(fabs(fy) <= 200.);       // :52
+    const bool off = (r.pos.x > T(1000) || r.pos.y > T(1000)) ||            // :48
+                     !(fabs(fx) <= T(200.)) || !(fabs(fy) <= T(200.));       // :52
     const bool binned = live && !reject && !off;
     xp = binned ? (int)fx : xp;
     yp = binned ? (int)fy : yp;
@@ -408,58 +505,58 @@ __device__ inline int make_image(const ort_system &S, const Ray &r, bool live, i
 //   bottle   src/lens.f90:230-350      plano   :425-481     doublet :531-645
 //   image    src/optics_system.f90:48-49 + imageMod
 // ----------------------------------------------------------------------------
-template <bool FILT, class D>
-__device__ inline void surface_step(const ort_system &S, const ort_surface &s, Ray &r, D &draws,
+template <bool FILT, class T, class Sys, class Surf, class D>
+__device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &draws,
                                     int &nis, int &st, int &xp, int &yp)
 {
     const bool live = st < 0;
     const int kind = __builtin_amdgcn_readfirstlane(s.kind);
     const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)s.flags);
-    const bool has_ap = __builtin_amdgcn_readfirstlane(__double2hiint(s.aperture)) >= 0;   // aperture >= 0
+    const bool has_ap = aperture_present<T>(s.aperture);                     // aperture >= 0
     const int lost = (flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE;
     nis += live ? 1 : 0;
-    Vec N;
+    VecT<T> N;
     bool proceed;                    // lanes that reach the Fresnel decision at this surface
     int ended = -1;                  // status of lanes that end before it
     if (kind == ORT_SURF_SPHERE || kind == ORT_SURF_CYLINDER || kind == ORT_SURF_ELLIPSE) {
-        double t;
+        T t;
         bool hit;
         const bool cyl = kind != ORT_SURF_SPHERE;
-        if (kind == ORT_SURF_ELLIPSE) intersect_ellipse<FILT>(r, s.cy, s.cz, s.radius, s.radius_b, live, t, hit);
-        else intersect_quadric<FILT>(r, s.cx, s.cy, s.cz, s.radius, cyl, live, t, hit);
-        const Vec moved = vadd(r.pos, vscale(r.dir, t));
+        if (kind == ORT_SURF_ELLIPSE) intersect_ellipse<FILT, T>(r, s.cy, s.cz, s.radius, s.radius_b, live, t, hit);
+        else intersect_quadric<FILT, T>(r, s.cx, s.cy, s.cz, s.radius, cyl, live, t, hit);
+        const VecT<T> moved = vadd(r.pos, vscale(r.dir, t));
         r.pos = vselect(live && hit, moved, r.pos);
         bool out = false;
-        if (has_ap) out = outside_aperture<FILT>(moved.x, moved.y, s.aperture, live && hit);
+        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, live && hit);
         // normal = centre - pos, with orig%x = centre%x for the bottle (lens.f90:288-290)
-        N = vnormalise({cyl ? 0.0 : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z});
+        N = vnormalise(VecT<T>{cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z});
         ended = !hit ? ((flags & ORT_F_MISS_IS_HELP3) ? ORT_ST_HELP3 : lost) : (out ? lost : -1);
         proceed = live && hit && !out;
     } else {
         // plane kinds: d = (z_plane - pos%z) / dir%z ; pos = pos + dir*d
-        const double d = ORT_DIV(s.cz - r.pos.z, r.dir.z);
-        const Vec moved = vadd(r.pos, vscale(r.dir, d));
+        const T d = ORT_DIV(s.cz - r.pos.z, r.dir.z);
+        const VecT<T> moved = vadd(r.pos, vscale(r.dir, d));
         if (kind == ORT_SURF_IMAGE) {
             r.pos = vselect(live, moved, r.pos);
-            const int ist = make_image<FILT>(S, r, live, xp, yp);
+            const int ist = make_image<FILT, T>(S, r, live, xp, yp);
             st = live ? ist : st;
             return;
         }
         bool out = false;
-        if (has_ap) out = outside_aperture<FILT>(moved.x, moved.y, s.aperture, live);
+        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, live);
         if (kind == ORT_SURF_IRIS) {
             r.pos = vselect(live && out, moved, r.pos);     // pos = origpos unless lost (lens.f90:564, :643)
             st = (live && out) ? lost : st;
             return;
         }
         r.pos = vselect(live, moved, r.pos);
-        N = {0., 0., -1.};                                  // flatNormal, lens.f90:165
+        N = {T(0.), T(0.), T(-1.)};                         // flatNormal, lens.f90:165
         ended = out ? lost : -1;
         proceed = live && !out;
     }
-    const double u = draws.peek();
+    const T u = draws.template peek_as<T>();
     draws.advance(proceed);
-    const bool reflected = reflect_refract<FILT>(r.dir, N, s.n1, s.n2, s.eta, u, proceed);
+    const bool reflected = reflect_refract<FILT, T>(r.dir, N, s.n1, s.n2, s.eta, u, proceed);
     const bool dies = reflected && (flags & ORT_F_SKIP_ON_REFLECT);
     st = live ? (proceed ? (dies ? lost : -1) : ended) : st;
 }

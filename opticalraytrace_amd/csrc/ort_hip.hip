@@ -64,6 +64,31 @@ __device__ inline void stage_system(ort_system &dst, const ort_system *src)
     __syncthreads();
 }
 
+// fp32 study path: the same system, converted once per workgroup while staging
+__device__ inline void stage_system(SystemT<float> &dst, const ort_system *src)
+{
+    for (int i = threadIdx.x; i < 2 * ORT_MAX_SURFACES; i += blockDim.x) {
+        const ort_surface &a = src->surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES];
+        SurfaceT<float> &b = dst.surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES];
+        b.cx = (float)a.cx; b.cy = (float)a.cy; b.cz = (float)a.cz; b.radius = (float)a.radius;
+        b.radius_b = (float)a.radius_b; b.n1 = (float)a.n1; b.n2 = (float)a.n2; b.eta = (float)a.eta;
+        b.aperture = (float)a.aperture; b.kind = a.kind; b.flags = a.flags;
+    }
+    if (threadIdx.x == 0) {
+        dst.n_surfaces[0] = src->n_surfaces[0]; dst.n_surfaces[1] = src->n_surfaces[1];
+        dst.split[0] = src->split[0]; dst.split[1] = src->split[1];
+        dst.ring_ellipse = src->ring_ellipse; dst.pad = 0;
+        dst.cos_theta_max = (float)src->cos_theta_max;
+        dst.ring_r1 = (float)src->ring_r1; dst.ring_r2 = (float)src->ring_r2;
+        dst.ring_lens_r2 = (float)src->ring_lens_r2; dst.ring_lens_z = (float)src->ring_lens_z;
+        dst.ring_bottle_ra = (float)src->ring_bottle_ra; dst.ring_bottle_rb = (float)src->ring_bottle_rb;
+        dst.ring_bottle_z = (float)src->ring_bottle_z;
+        dst.bin_width = (float)src->bin_width; dst.inv_bin_width = (float)src->inv_bin_width;
+        dst.na_cos_min = (float)src->na_cos_min; dst.twopi = (float)src->twopi;
+    }
+    __syncthreads();
+}
+
 // Where this workgroup bins its hits.  The point-source image is a blob of a few thousand
 // 64-byte lines; with one image every wave of the chip queues its atomics on those same
 // lines (measured: +0.19 ms on a 0.75 ms launch at 4 waves/SIMD).  So the hits go to one of
@@ -95,21 +120,21 @@ __global__ __launch_bounds__(256) void fold_kernel(int32_t *image, int32_t *repl
 
 // One lockstep pass of a wave over surfaces [k0, k1): every lane steps with its `st`
 // predicate; the loop leaves as soon as no lane of the wave is alive (uniform branch).
-template <bool FILT, class D>
-__device__ inline void walk(const ort_system &S, const ort_surface *surf, int k0, int k1, Ray &r, D &draws,
+template <bool FILT, class T, class Sys, class Surf, class D>
+__device__ inline void walk(const Sys &S, const Surf *surf, int k0, int k1, RayT<T> &r, D &draws,
                             int &nis, int &st, int &xp, int &yp)
 {
     for (int k = k0; k < k1; ++k) {
         if (!wave_any(st < 0)) break;
-        surface_step<FILT>(S, surf[k], r, draws, nis, st, xp, yp);
+        surface_step<FILT, T>(S, surf[k], r, draws, nis, st, xp, yp);
     }
 }
 
 // FILT: filtered predicates (ort_device.h); false = every predicate evaluated literally.
-template <int MODE, bool FILT>
+template <int MODE, bool FILT, class T>
 __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs a)
 {
-    __shared__ ort_system S;
+    __shared__ typename SysTypes<T>::Sys S;
     __shared__ unsigned int blk[4];       // lost, isect, binned, help3
     stage_system(S, a.sys);
     if (MODE != MODE_DEBUG) {
@@ -122,34 +147,34 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
     const uint64_t n = a.n_rays;
 
     const int ns = S.n_surfaces[a.phase - 1];
-    const ort_surface *surf = S.surfaces[a.phase - 1];
+    const typename SysTypes<T>::Surf *surf = S.surfaces[a.phase - 1];
     // whole waves iterate together (the tail wave keeps its out-of-range lanes dead)
     const uint64_t base0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ull;
     for (uint64_t wbase = base0; wbase < n; wbase += stride) {
         const uint64_t i = wbase + (threadIdx.x & 63);
         const bool act = i < n;
         const uint64_t ic = act ? i : n - 1;             // clamped index for loads of idle lanes
-        Ray r = {{0., 0., 0.}, {0., 0., 1.}}, em;
+        RayT<T> r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}}, em;
         int nis = 0, xp = -9999, yp = -9999, st = act ? -1 : ORT_ST_NA_REJECT;
         const bool have_in = MODE != MODE_FUSED && a.pos_dir_in;
         if (have_in) {
-            r.pos = {a.pos_dir_in[0 * n + ic], a.pos_dir_in[1 * n + ic], a.pos_dir_in[2 * n + ic]};
-            r.dir = {a.pos_dir_in[3 * n + ic], a.pos_dir_in[4 * n + ic], a.pos_dir_in[5 * n + ic]};
+            r.pos = {(T)a.pos_dir_in[0 * n + ic], (T)a.pos_dir_in[1 * n + ic], (T)a.pos_dir_in[2 * n + ic]};
+            r.dir = {(T)a.pos_dir_in[3 * n + ic], (T)a.pos_dir_in[4 * n + ic], (T)a.pos_dir_in[5 * n + ic]};
         }
         int kdraws = 0;
         if (MODE == MODE_DEBUG) {
             Draws d;
             if (a.u) d.init_table(a.u + ic, (int64_t)n, a.nu, a.draw_base);
             else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
-            if (!have_in) { if (a.phase == 1) emit_ring(S, r, d); else emit_point(S, r, d); }
+            if (!have_in) { if (a.phase == 1) emit_ring<T>(S, r, d); else emit_point<T>(S, r, d); }
             em = r;
-            walk<FILT>(S, surf, 0, ns, r, d, nis, st, xp, yp);
+            walk<FILT, T>(S, surf, 0, ns, r, d, nis, st, xp, yp);
             kdraws = d.k;
         } else {
             KeyedDraws d;
             d.init_keyed(a.rng_base, a.first_ray + ic, have_in ? a.draw_base : 0);
-            if (!have_in) { if (a.phase == 1) emit_ring(S, r, d); else emit_point(S, r, d); }
-            walk<FILT>(S, surf, 0, ns, r, d, nis, st, xp, yp);
+            if (!have_in) { if (a.phase == 1) emit_ring<T>(S, r, d); else emit_point<T>(S, r, d); }
+            walk<FILT, T>(S, surf, 0, ns, r, d, nis, st, xp, yp);
         }
         if (!act) continue;
         if (MODE == MODE_DEBUG) {
@@ -271,7 +296,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 d.z = (uint64_t)__double_as_longlong(q[6][slot]);
             }
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
-            walk<FILT>(S, surf, split, ns, r, d, nis, st, xp, yp);
+            walk<FILT, double>(S, surf, split, ns, r, d, nis, st, xp, yp);
             if (act) finish(st, nis, xp, yp);
             __builtin_amdgcn_wave_barrier();
         } else if (have_new) {
@@ -289,10 +314,10 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 r.dir = {a.pos_dir_in[3 * n + ic], a.pos_dir_in[4 * n + ic], a.pos_dir_in[5 * n + ic]};
             } else {
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                if (a.phase == 1) emit_ring(S, r, d);
-                else emit_point(S, r, d);
+                if (a.phase == 1) emit_ring<double>(S, r, d);
+                else emit_point<double>(S, r, d);
             }
-            walk<FILT>(S, surf, 0, split, r, d, nis, st, xp, yp);
+            walk<FILT, double>(S, surf, 0, split, r, d, nis, st, xp, yp);
             const bool survive = act && st < 0;
             const unsigned long long mask = __ballot(survive);
             if (survive) {
@@ -328,8 +353,8 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int
         KeyedDraws d;
         d.init_keyed(rng_base, first_ray + i, 0);
         Ray r;
-        if (phase == 1) emit_ring(S, r, d);
-        else emit_point(S, r, d);
+        if (phase == 1) emit_ring<double>(S, r, d);
+        else emit_point<double>(S, r, d);
         pos_dir[0 * n + i] = r.pos.x; pos_dir[1 * n + i] = r.pos.y; pos_dir[2 * n + i] = r.pos.z;
         pos_dir[3 * n + i] = r.dir.x; pos_dir[4 * n + i] = r.dir.y; pos_dir[5 * n + i] = r.dir.z;
     }
@@ -392,7 +417,8 @@ struct ort_ctx {
     int32_t *d_replicas;         // kReplicas zeroed images (scratch between trace and fold)
     unsigned long long *d_counters, *own_counters;
     bool timing;
-    int variant;                 // 0 lockstep, 1 queued (default)
+    int variant;                 // bit mask, see ort_set_kernel_variant
+    int precision;               // 0 fp64 (reference arithmetic), 1 fp32 (study path)
     hipEvent_t ev[3][2];
     bool ev_valid[3];
 };
@@ -491,7 +517,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
     if (a.n_rays == 0) return ORT_OK;
     int grid = grid_for(a.n_rays);
     if (c->timing && evk >= 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
-    const bool queued = (c->variant & 1) && mode != MODE_DEBUG;
+    const bool queued = (c->variant & 1) && mode != MODE_DEBUG && c->precision == 0;
     const bool filt = (c->variant & 2) == 0;
     if (queued) {
         // every wave walks a 64-aligned contiguous range: no more waves than 64-ray batches
@@ -500,14 +526,19 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
         if (blocks < (uint64_t)grid) grid = (int)blocks;
     }
 #define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
-    if (mode == MODE_FUSED) {
+    if (c->precision == 1) {
+        // fp32 study path (BASELINE configs[4]): lockstep kernel, literal predicates
+        if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, false, float>));
+        else if (mode == MODE_RESIDENT) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, float>));
+        else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, float>));
+    } else if (mode == MODE_FUSED) {
         if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true>)); else ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, false>)); }
-        else { if (filt) ORT_LAUNCH((trace_kernel<MODE_FUSED, true>)); else ORT_LAUNCH((trace_kernel<MODE_FUSED, false>)); }
+        else { if (filt) ORT_LAUNCH((trace_kernel<MODE_FUSED, true, double>)); else ORT_LAUNCH((trace_kernel<MODE_FUSED, false, double>)); }
     } else if (mode == MODE_RESIDENT) {
         if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true>)); else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, false>)); }
-        else { if (filt) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true>)); else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false>)); }
+        else { if (filt) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true, double>)); else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, double>)); }
     } else {
-        if (filt) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true>)); else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false>));
+        if (filt) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, double>)); else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, double>));
     }
 #undef ORT_LAUNCH
     if (use_rep) hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, a.phase);
@@ -663,6 +694,14 @@ int ort_set_kernel_variant(ort_ctx *c, int variant)
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
     if (variant < 0 || variant > 7) return fail(ORT_E_INVALID, "variant must be in 0..7");
     c->variant = variant;
+    return ORT_OK;
+}
+
+int ort_set_precision(ort_ctx *c, int precision)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    if (precision != 0 && precision != 1) return fail(ORT_E_INVALID, "precision must be 0 (fp64) or 1 (fp32)");
+    c->precision = precision;
     return ORT_OK;
 }
 

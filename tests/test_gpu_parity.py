@@ -292,3 +292,31 @@ def test_boundary_rays_bit_exact_in_both_predicate_modes(ctxs, name, phase):
         assert np.array_equal(got["pos_dir"][:, ok], want["pos_dir"][:, ok])
         assert np.array_equal(np.isnan(got["pos_dir"]), np.isnan(want["pos_dir"]))
     ctx.set_kernel_variant(1)
+
+
+def test_config3_ring_1e8_and_config4_shape_1e9(ctxs):
+    """BASELINE configs[2] (ring source, 1e8 rays) and the per-GPU shape of configs[3]
+    (ring + point through the full stack, 1e9 rays per layer) at FULL size on one GPU:
+    size-independent properties (the oracle would need hours)."""
+    osys, ctx = ctxs("large")
+    ctx.reset()
+    n3 = 100_000_000
+    ctx.trace(1, 0, n3, SEED)
+    img, cnt = ctx.read()
+    lost, isect, binned = int(cnt[0]), int(cnt[2]), int(cnt[4])
+    assert int(img[0].sum()) == binned and img[1].sum() == 0
+    assert abs(isect / n3 - 1.553) < 0.005                      # SURVEY §6: 1.553 intersections per ring ray
+    assert abs(100 * (1 - lost / n3) - 0.033) < 0.005           # reference: 0.033 % transmitted (BASELINE.md §2)
+    # configs[3] shape: 1e9 rays per layer, here as 4 calls of 2.5e8 per layer with increasing offsets
+    ctx.reset()
+    n4, parts = 1_000_000_000, 4
+    for phase in (1, 2):
+        for k in range(parts):
+            ctx.trace(phase, k * (n4 // parts), n4 // parts, SEED)
+    img, cnt = ctx.read()
+    assert int(img[0].sum()) == int(cnt[4]) and int(img[1].sum()) == int(cnt[5])
+    assert int(img.max()) < 2 ** 31 - 1                         # quirk 14: one layer cannot overflow a bin
+    assert abs(int(cnt[3]) / n4 - 6.315) < 0.002 and abs(int(cnt[2]) / n4 - 1.553) < 0.002
+    assert abs(100 * (1 - int(cnt[1]) / n4) - 49.25) < 0.02     # reference at 1e7: 49.24 %
+    assert abs(int(cnt[5]) / n4 - 0.41832) < 3e-4
+    assert int(cnt[6]) == 0 and int(cnt[7]) == 0
