@@ -317,6 +317,7 @@ def test_config3_ring_1e8_and_config4_shape_1e9(ctxs):
     assert int(img[0].sum()) == int(cnt[4]) and int(img[1].sum()) == int(cnt[5])
     assert int(img.max()) < 2 ** 31 - 1                         # quirk 14: one layer cannot overflow a bin
     assert abs(int(cnt[3]) / n4 - 6.315) < 0.002 and abs(int(cnt[2]) / n4 - 1.553) < 0.002
-    assert abs(100 * (1 - int(cnt[1]) / n4) - 49.25) < 0.02     # reference at 1e7: 49.24 %
-    assert abs(int(cnt[5]) / n4 - 0.41832) < 3e-4
+    # the reference program printed 49.25 % (1e6 rays, sigma 0.05) and 49.24 % (1e7, sigma 0.016)
+    assert abs(100 * (1 - int(cnt[1]) / n4) - 49.24) < 0.05
+    assert abs(int(cnt[5]) / n4 - 0.41832) < 1.5e-3                # 418320 of 1e6 binned in the reference run
     assert int(cnt[6]) == 0 and int(cnt[7]) == 0
