@@ -129,6 +129,12 @@ class RayTracer(ShardedRun):
     def close(self) -> None:
         self.ctx.close()
 
+    def set_system(self, system: OpticalSystem) -> None:
+        """Re-stage another optical system on the same context (sweeps: src/main.f90 is re-run
+        once per settings file by runner.py; here only 2 KB move)."""
+        self.system = system
+        self.ctx.set_system(system)
+
     def _trace_shard(self, phase: int, lo: int, cnt: int, seed: int) -> None:
         self.ctx.trace(phase, lo, cnt, seed)
 
@@ -194,17 +200,22 @@ def append_stats(folder: str, system: OpticalSystem, res: RunResult) -> str:
     return path
 
 
-def run_settings_file(settings_path: str, res_dir: Optional[str] = None, data_dir: str = "data",
-                      device: int = 0, verbose: bool = True) -> RunResult:
-    """`bin/raytrace <settings>` for the hot path on one GPU: read, trace, write (src/main.f90)."""
-    settings = Settings.from_file(settings_path)
-    res_dir = res_dir or os.path.dirname(os.path.abspath(settings_path))
+def run_settings(settings: Settings, res_dir: Optional[str] = None, data_dir: str = "data",
+                 device: int = 0, verbose: bool = True, tracer: Optional[RayTracer] = None) -> RunResult:
+    """One simulation = one execution of `bin/raytrace <settings>` for the hot path: build the
+    system, trace both loops, append the stats row, write the images (src/main.f90).  Pass a
+    `tracer` to reuse its context across many runs (sweeps): only the 2 KB system is re-staged."""
     system = OpticalSystem.from_settings(settings, res_dir)
-    tracer = RayTracer(system, device=device)
+    own = tracer is None
+    if own:
+        tracer = RayTracer(system, device=device)
+    else:
+        tracer.set_system(system)
     try:
         res = tracer.run()
     finally:
-        tracer.close()
+        if own:
+            tracer.close()
     folder = os.path.join(data_dir, settings.data_folder)
     os.makedirs(folder, exist_ok=True)                      # setupMod.f90:124-131
     append_stats(folder, system, res)
@@ -214,3 +225,12 @@ def run_settings_file(settings_path: str, res_dir: Optional[str] = None, data_di
     if settings.make_images:                                # main.f90:183-185
         write_images(res.image, os.path.join(folder, output_basename(system) + "_image"))
     return res
+
+
+def run_settings_file(settings_path: str, res_dir: Optional[str] = None, data_dir: str = "data",
+                      device: int = 0, verbose: bool = True,
+                      tracer: Optional[RayTracer] = None) -> RunResult:
+    """`bin/raytrace <settings>` for the hot path on one GPU: read, trace, write (src/main.f90)."""
+    settings = Settings.from_file(settings_path)
+    res_dir = res_dir or os.path.dirname(os.path.abspath(settings_path))
+    return run_settings(settings, res_dir, data_dir, device, verbose, tracer)
