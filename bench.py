@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--phase", type=int, default=2, help="2 = point loop (configs[1]); 1 = ring loop")
     ap.add_argument("--cpu-rays", type=int, default=20_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and all-reduce even with one rank (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,8 +84,10 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the trace path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -97,38 +101,47 @@ def main():
     phase, total_rays = args.phase, args.rays * world
     ci, cb = (C_ISECT_POINT, C_BINNED_POINT) if phase == 2 else (C_ISECT_RING, C_BINNED_RING)
 
-    def step():
-        tracer.reset()
-        tracer.trace_phase(phase, total_rays, DEFAULT_SEED)
-        tracer.reduce()
+    # One RUN = warmup + K steps; step k traces the global ray indices [k*T, (k+1)*T) (T = rays
+    # per GPU x ranks), sharded over the ranks, accumulating into the per-GPU image.  As in the
+    # reference (one shared image for the whole loop, src/main.f90:88-109) the image is reduced
+    # ONCE per run — inside the timed region — not once per batch.
+    def step(k):
+        lo, cnt = (total_rays * rank) // world, (total_rays * (rank + 1)) // world - (total_rays * rank) // world
+        tracer.ctx.trace(phase, k * total_rays + lo, cnt, DEFAULT_SEED)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    tracer.reset()
+    for k in range(args.warmup):
+        step(k)
+    tracer.reduce(force=use_dist)
     fence()
-    kernel_ms = []
+    tracer.reset()
+    fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # HIP events recorded on the tracer's stream around the launch; reading them after the
-        # step only waits for that launch, which the next reset() would wait for anyway
-        kernel_ms.append(tracer.ctx.last_kernel_ms(0))
+    for k in range(args.steps):
+        step(args.warmup + k)
+    tracer.reduce(force=use_dist)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    # per-launch kernel durations from the HIP events each launch recorded on the tracer's stream
+    kernel_ms = tracer.ctx.kernel_times(min(args.steps, 64))
 
-    res = tracer.result(total_rays)                # counters of the LAST step = one step's work
-    isect_per_step = int(res.counters[ci])         # already summed over ranks by reduce()
-    binned_per_step = int(res.counters[cb])
-    value = isect_per_step * args.steps / elapsed
+    res = tracer.result(total_rays * args.steps)   # counters of the whole timed run, summed over ranks
+    isect_total = int(res.counters[ci])
+    binned_total = int(res.counters[cb])
+    assert int(res.image[phase - 1].sum()) == binned_total, "image and counter disagree"
+    isect_per_step = isect_total / args.steps
+    binned_per_step = binned_total / args.steps
+    value = isect_total / elapsed
 
     # roofline of the dominant kernel (the fused trace kernel), per launch = per rank per step
     k_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3
@@ -166,13 +179,14 @@ def main():
                                f"phase {phase}, clearBottle-large + planoConvex-f39.9mm + "
                                f"achromaticDoublet-f50.0mm, {args.rays} rays per GPU",
                    "rays_per_gpu": args.rays, "phase": phase, "seed": DEFAULT_SEED,
-                   "sharding": f"contiguous global ray ranges over {world} rank(s), RCCL sum of image+counters",
+                   "sharding": f"contiguous global ray ranges over {world} rank(s); one RCCL sum of "
+                               "image+counters per run of K steps, inside the timed region",
                    "intersections_per_step": isect_per_step, "binned_per_step": binned_per_step,
                    "rays_per_s": total_rays * args.steps / elapsed},
         "roofline": {
             "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "trace_kernel<MODE_FUSED>", "kernel_ms": k_s * 1e3,
+            "kernel": "trace_queue_kernel<MODE_FUSED, filtered> (+ fold_kernel, same event bracket)", "kernel_ms": k_s * 1e3,
             "algorithmic_bytes_per_launch": alg_bytes,
             "note": "SURVEY §8(d) contract figure 48 B/ray + 8 B/binned ray; the path is fp64-VALU "
                     "bound, see roofline_fp64 (DESIGN.md §5)",
@@ -189,7 +203,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     tracer.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -181,6 +181,10 @@ int ort_synchronize(ort_ctx *ctx);
  * trace, 1 resident trace, 2 emit. */
 int ort_last_kernel_ms(ort_ctx *ctx, int kind, float *ms);
 int ort_set_timing(ort_ctx *ctx, int enable);
+/* Durations (ms) of the most recent fused-trace launches (ort_trace), oldest first, at most 64:
+ * every launch records its own event pair on the context's stream, so a host loop can issue
+ * many steps without synchronising and read the per-launch times afterwards. */
+int ort_kernel_times(ort_ctx *ctx, float *ms, int capacity, int *count);
 /* Arithmetic of the traced path from now on: 0 (default) = fp64, the reference's arithmetic
  * (all `real` are fp64, src/Makefile:2), bit-exact; 1 = fp32 study path (BASELINE configs[4]):
  * the same operations in single precision, uniforms = top 24 bits of the same draws.  It has

@@ -133,6 +133,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ort_synchronize": (C.c_int, [vp]),
         "ort_last_kernel_ms": (C.c_int, [vp, i32, C.POINTER(C.c_float)]),
         "ort_set_timing": (C.c_int, [vp, i32]),
+        "ort_kernel_times": (C.c_int, [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]),
         "ort_set_kernel_variant": (C.c_int, [vp, i32]),
         "ort_set_precision": (C.c_int, [vp, i32]),
     }
@@ -151,7 +152,7 @@ EXPORTED_SYMBOLS = ["ort_abi_version", "ort_last_error", "ort_device_count", "or
                     "ort_trace_resident", "ort_trace_rays", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
                     "ort_device_counters", "ort_synchronize", "ort_last_kernel_ms",
-                    "ort_set_timing", "ort_set_kernel_variant", "ort_set_precision"]
+                    "ort_set_timing", "ort_kernel_times", "ort_set_kernel_variant", "ort_set_precision"]
 
 
 def _check(lib, rc: int, what: str) -> None:
@@ -251,6 +252,13 @@ class Context:
 
     def set_kernel_variant(self, variant: int) -> None:
         _check(self.lib, self.lib.ort_set_kernel_variant(self._h, variant), "ort_set_kernel_variant")
+
+    def kernel_times(self, capacity: int = 64):
+        """ms of the most recent ort_trace launches (oldest first); synchronises on their events."""
+        buf = (C.c_float * capacity)()
+        n = C.c_int(0)
+        _check(self.lib, self.lib.ort_kernel_times(self._h, buf, capacity, C.byref(n)), "ort_kernel_times")
+        return [buf[i] for i in range(n.value)]
 
     def set_precision(self, precision: int) -> None:
         """0 = fp64 (reference arithmetic, default), 1 = fp32 study path."""

@@ -32,6 +32,7 @@ constexpr int kBlock = 256;
 #ifndef ORT_MIN_WAVES
 #define ORT_MIN_WAVES 1
 #endif
+constexpr int kTimingRing = 64;         // launches kept by ort_kernel_times
 constexpr int kReplicas = 8;            // image replicas, one per XCD-sized group of workgroups
 constexpr int kMaxBlocks = 256 * 8;     // 256 CUs x 8 workgroups: >> 256 workgroups fills all 8 XCDs
 
@@ -420,6 +421,8 @@ struct ort_ctx {
     int variant;                 // bit mask, see ort_set_kernel_variant
     int precision;               // 0 fp64 (reference arithmetic), 1 fp32 (study path)
     hipEvent_t ev[3][2];
+    hipEvent_t ring[kTimingRing][2];   // fused-trace launches, most recent kTimingRing
+    unsigned long long ring_count;
     bool ev_valid[3];
 };
 
@@ -468,6 +471,10 @@ int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out)
         HIP_TRY(hipEventCreate(&c->ev[k][0]));
         HIP_TRY(hipEventCreate(&c->ev[k][1]));
     }
+    for (int k = 0; k < kTimingRing; ++k) {
+        HIP_TRY(hipEventCreate(&c->ring[k][0]));
+        HIP_TRY(hipEventCreate(&c->ring[k][1]));
+    }
     HIP_TRY(hipMemcpyAsync(c->d_sys, sys, sizeof(ort_system), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_image, 0, ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, ORT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
@@ -482,6 +489,7 @@ int ort_destroy(ort_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int k = 0; k < 3; ++k) { (void)hipEventDestroy(c->ev[k][0]); (void)hipEventDestroy(c->ev[k][1]); }
+    for (int k = 0; k < kTimingRing; ++k) { (void)hipEventDestroy(c->ring[k][0]); (void)hipEventDestroy(c->ring[k][1]); }
     (void)hipFree(c->d_sys); (void)hipFree(c->own_image); (void)hipFree(c->own_counters); (void)hipFree(c->d_replicas);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -516,7 +524,9 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
     a.replicas = use_rep ? c->d_replicas : nullptr;
     if (a.n_rays == 0) return ORT_OK;
     int grid = grid_for(a.n_rays);
+    const int slot = (int)(c->ring_count % kTimingRing);
     if (c->timing && evk >= 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
+    if (c->timing && evk == 0) HIP_TRY(hipEventRecord(c->ring[slot][0], c->stream));
     const bool queued = (c->variant & 1) && mode != MODE_DEBUG && c->precision == 0;
     const bool filt = (c->variant & 2) == 0;
     if (queued) {
@@ -544,6 +554,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
     if (use_rep) hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, a.phase);
     HIP_TRY(hipGetLastError());
     if (c->timing && evk >= 0) { HIP_TRY(hipEventRecord(c->ev[evk][1], c->stream)); c->ev_valid[evk] = true; }
+    if (c->timing && evk == 0) { HIP_TRY(hipEventRecord(c->ring[slot][1], c->stream)); c->ring_count++; }
     return ORT_OK;
 }
 
@@ -694,6 +705,21 @@ int ort_set_kernel_variant(ort_ctx *c, int variant)
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
     if (variant < 0 || variant > 7) return fail(ORT_E_INVALID, "variant must be in 0..7");
     c->variant = variant;
+    return ORT_OK;
+}
+
+int ort_kernel_times(ort_ctx *c, float *ms, int capacity, int *count)
+{
+    if (!c || !ms || !count || capacity < 0) return fail(ORT_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long have = c->ring_count < (unsigned long long)kTimingRing ? c->ring_count : kTimingRing;
+    int n = (int)(have < (unsigned long long)capacity ? have : (unsigned long long)capacity);
+    for (int i = 0; i < n; ++i) {                    // oldest of the kept launches first
+        int slot = (int)((c->ring_count - (unsigned long long)n + i) % kTimingRing);
+        HIP_TRY(hipEventSynchronize(c->ring[slot][1]));
+        HIP_TRY(hipEventElapsedTime(&ms[i], c->ring[slot][0], c->ring[slot][1]));
+    }
+    *count = n;
     return ORT_OK;
 }
 

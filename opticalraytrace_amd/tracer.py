@@ -85,9 +85,10 @@ class ShardedRun:
         lo, cnt = shard_range(nphotons, self.rank, self.world)
         self._trace_shard(phase, lo, cnt, seed)
 
-    def reduce(self) -> None:
-        """Sum image + counters over ranks (RCCL all-reduce over xGMI); no-op for world == 1."""
-        if self.world > 1:
+    def reduce(self, force: bool = False) -> None:
+        """Sum image + counters over ranks (RCCL all-reduce over xGMI); no-op for world == 1
+        unless `force` (then the collective runs on the single rank: a plumbing check)."""
+        if self.world > 1 or force:
             import torch.distributed as dist
             dist.all_reduce(self.image, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(self.counters, op=dist.ReduceOp.SUM, group=self.group)
