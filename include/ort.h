@@ -48,6 +48,12 @@ extern "C" {
 #define ORT_SURF_IRIS 4      /* test-only plane: r at z = cz must be <= aperture; position restored (src/lens.f90:551-565, :632-644) */
 #define ORT_SURF_IMAGE 5     /* move to z = cz, then makeImage2D                      (src/optics_system.f90:48-49, src/imageMod.f90:19-58) */
 
+/* emitters */
+#define ORT_EMIT_RING 0      /* ring            src/sourceMod.f90:250-300 (phase 1 default) */
+#define ORT_EMIT_POINT 1     /* point           src/sourceMod.f90:12-47   (phase 2: point and crs sources) */
+#define ORT_EMIT_SPOT 2      /* create_spot     src/sourceMod.f90:122-159 (phase 2: spot source, no draws) */
+#define ORT_EMIT_CRS 3       /* point_on_bottle src/sourceMod.f90:50-89   (phase 1: crs source) */
+
 /* surface flags */
 #define ORT_F_SKIP_ON_REFLECT 1u /* a Fresnel reflection ends the ray (every surface but the plano flat face, src/lens.f90:458-459) */
 #define ORT_F_MISS_IS_HELP3 2u   /* a miss here is the reference's `error stop "Help3"` (src/lens.f90:617): counted, not fatal */
@@ -76,7 +82,7 @@ typedef struct ort_system {
                                      kernel (rays that survive surfaces [0, split) are compacted through
                                      a wave-private LDS queue); 0 or n_surfaces = single segment.
                                      Scheduling only: results do not depend on it. */
-    int32_t reserved[2];
+    int32_t emitter[2];           /* per phase: ORT_EMIT_* (src/main.f90:95-101, :132-142) */
     ort_surface surfaces[2][ORT_MAX_SURFACES];
     /* point emitter, src/sourceMod.f90:12-47 */
     double cos_theta_max;
@@ -92,6 +98,11 @@ typedef struct ort_system {
     double na_cos_min;            /* smallest x with acos(x) <= na_angle under the host libm: the
                                      NA test of src/imageMod.f90:39-44 as one compare per ray */
     double twopi;                 /* 2.*4.*atan(1.) (src/constants.f90:5) */
+    /* spot source, create_spot (src/sourceMod.f90:122-159): twopi/sqrt(nphotons), acos(cosThetaMax)/sqrt(nphotons) */
+    double spot_dphi, spot_dtheta;
+    /* crs source, point_on_bottle (src/sourceMod.f90:50-89): Gaussian sigma (spot_size after
+     * src/setupMod.f90:136), cylinder radius radiusa + thickness, bottle centre y, z */
+    double crs_sigma, crs_radius, crs_cy, crs_cz;
 } ort_system;
 
 /* per-ray status written by ort_trace_rays */

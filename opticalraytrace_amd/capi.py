@@ -7,6 +7,7 @@ every call raises.  The library is built in-tree by `__graft_entry__.build()` or
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from typing import Optional
 
@@ -22,6 +23,8 @@ NUM_COUNTERS = 8
 ST_BINNED, ST_NA_REJECT, ST_OFF_GRID, ST_LOST_BOTTLE, ST_LOST_TELESCOPE, ST_HELP3 = range(6)
 (C_LOST_RING, C_LOST_POINT, C_ISECT_RING, C_ISECT_POINT,
  C_BINNED_RING, C_BINNED_POINT, C_HELP3_RING, C_HELP3_POINT) = range(8)
+
+EMIT_RING, EMIT_POINT, EMIT_SPOT, EMIT_CRS = range(4)
 
 _ERRORS = {-1: "ORT_E_INVALID", -2: "ORT_E_NODEVICE", -3: "ORT_E_HIP", -4: "ORT_E_NOMEM"}
 
@@ -39,7 +42,7 @@ class OrtSurface(C.Structure):
 
 class OrtSystem(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("n_surfaces", C.c_int32 * 2),
-                ("ring_ellipse", C.c_int32), ("split", C.c_int32 * 2), ("reserved", C.c_int32 * 2),
+                ("ring_ellipse", C.c_int32), ("split", C.c_int32 * 2), ("emitter", C.c_int32 * 2),
                 ("surfaces", (OrtSurface * MAX_SURFACES) * 2),
                 ("cos_theta_max", C.c_double),
                 ("ring_r1", C.c_double), ("ring_r2", C.c_double),
@@ -47,7 +50,9 @@ class OrtSystem(C.Structure):
                 ("ring_bottle_ra", C.c_double), ("ring_bottle_rb", C.c_double),
                 ("ring_bottle_z", C.c_double),
                 ("bin_width", C.c_double), ("inv_bin_width", C.c_double), ("na_angle", C.c_double), ("na_cos_min", C.c_double),
-                ("twopi", C.c_double)]
+                ("twopi", C.c_double), ("spot_dphi", C.c_double), ("spot_dtheta", C.c_double),
+                ("crs_sigma", C.c_double), ("crs_radius", C.c_double), ("crs_cy", C.c_double),
+                ("crs_cz", C.c_double)]
 
 
 def pack_system(osys: OpticalSystem) -> OrtSystem:
@@ -80,6 +85,17 @@ def pack_system(osys: OpticalSystem) -> OrtSystem:
     cs.na_angle = osys.na_angle
     cs.na_cos_min = osys.na_cos_min
     cs.twopi = TWOPI
+    # emitters per phase (src/main.f90:95-101, :132-142)
+    src = osys.settings.light_source
+    cs.emitter[0] = EMIT_CRS if src == "crs" else EMIT_RING
+    cs.emitter[1] = EMIT_SPOT if src == "spot" else EMIT_POINT
+    nrays_sqrt = math.sqrt(float(osys.settings.nphotons))          # sourceMod.f90:135-141
+    if nrays_sqrt > 0:
+        cs.spot_dphi = TWOPI / nrays_sqrt
+        cs.spot_dtheta = math.acos(osys.cos_theta_max) / nrays_sqrt
+    cs.crs_sigma = osys.crs_spot_size
+    cs.crs_radius = b.radiusa + b.thickness
+    cs.crs_cy, cs.crs_cz = b.centre[1], b.centre[2]
     return cs
 
 

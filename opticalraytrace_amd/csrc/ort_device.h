@@ -245,6 +245,8 @@ template <class T> struct SystemT {
     SurfaceT<T> surfaces[2][ORT_MAX_SURFACES];
     T cos_theta_max, ring_r1, ring_r2, ring_lens_r2, ring_lens_z, ring_bottle_ra, ring_bottle_rb, ring_bottle_z;
     T bin_width, inv_bin_width, na_cos_min, twopi;
+    T spot_dphi, spot_dtheta, crs_sigma, crs_radius, crs_cy, crs_cz;
+    int32_t emitter[2];
 };
 template <class T> struct SysTypes { using Sys = SystemT<T>; using Surf = SurfaceT<T>; };
 template <> struct SysTypes<double> { using Sys = ort_system; using Surf = ort_surface; };
@@ -444,6 +446,70 @@ __device__ inline void emit_ring(const Sys &S, RayT<T> &r, D &draws)
     T ez = S.ring_lens_z - r.pos.z;
     T dist = ORT_SQRT(ex * ex + ey * ey + ez * ez);
     r.dir = vnormalise(div3(VecT<T>{ex, ey, ez}, dist));
+}
+
+// create_spot, src/sourceMod.f90:122-159: deterministic fan, no draws; n = 1-based loop index
+template <class T, class Sys>
+__device__ inline void emit_spot(const Sys &S, RayT<T> &r, uint64_t ray)
+{
+    const int n = (int)(ray + 1);
+    T phi = S.spot_dphi * (T)(n % 10);
+    T theta = S.spot_dtheta * (T)(n / 10);
+    T sinp, cosp, sint_unused, cost;
+    sincos_t<T>(phi, &sinp, &cosp);
+    sincos_t<T>(theta, &sint_unused, &cost);
+    T sint = ORT_SQRT(T(1.) - cost * cost);
+    r.dir = {sint * cosp, sint * sinp, cost};
+    r.pos = {T(0.), T(0.), T(0.)};
+}
+
+// point_on_bottle, src/sourceMod.f90:50-89 (the "crs" source of phase 1): cone direction as
+// `point`, start position = a Gaussian spot (rang, src/random_mod.f90:59-85: polar Box-Muller,
+// a variable number of draws) dropped along -z onto the cylinder radiusa + thickness.
+template <class T, class Sys, class D>
+__device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws)
+{
+    T phi = S.twopi * draws.template next_as<T>();
+    T sinp, cosp;
+    sincos_t<T>(phi, &sinp, &cosp);
+    T ran = draws.template next_as<T>();
+    T cost = (T(1.0) - ran) + ran * S.cos_theta_max;
+    T sint = ORT_SQRT(T(1.0) - cost * cost);
+    T x = T(0.), y = T(0.), s = T(1.);
+    bool more = true;
+    while (wave_any(more)) {                               // do while(s >= 1.)
+        T u1 = draws.template peek_as<T>();
+        draws.advance(more);
+        T u2 = draws.template peek_as<T>();
+        draws.advance(more);
+        T xn = T(-1.) + u1 * (T(1.) - T(-1.));             // ranu(-1., 1.)
+        T yn = T(-1.) + u2 * (T(1.) - T(-1.));
+        x = more ? xn : x;
+        y = more ? yn : y;
+        s = more ? y * y + x * x : s;
+        more = more && (s >= T(1.));
+    }
+    T cst = ORT_SQRT(T(-2.) * log(s) / s);
+    T tmp1 = T(0.) + S.crs_sigma * (x * cst);
+    T tmp2 = T(0.) + S.crs_sigma * (y * cst);
+    RayT<T> drop = {{tmp1, tmp2, T(1.0)}, {T(0.), T(0.), T(-1.)}};
+    T t;
+    bool hit;
+    intersect_quadric<false, T>(drop, T(0.), S.crs_cy, S.crs_cz, S.crs_radius, true, true, t, hit);
+    t = hit ? t : T(0.);                                   // the reference leaves t undefined on a miss
+    r.pos = vadd(drop.pos, vscale(drop.dir, t));
+    r.dir = {sint * cosp, sint * sinp, cost};
+}
+
+// the phase's emitter (wave-uniform choice; src/main.f90:95-101, :132-142)
+template <class T, class Sys, class D>
+__device__ inline void emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray)
+{
+    const int e = __builtin_amdgcn_readfirstlane(S.emitter[phase - 1]);
+    if (e == ORT_EMIT_RING) emit_ring<T>(S, r, draws);
+    else if (e == ORT_EMIT_POINT) emit_point<T>(S, r, draws);
+    else if (e == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray);
+    else emit_crs<T>(S, r, draws);
 }
 
 // ----------------------------------------------------------------------------

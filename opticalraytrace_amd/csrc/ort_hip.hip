@@ -86,6 +86,10 @@ __device__ inline void stage_system(SystemT<float> &dst, const ort_system *src)
         dst.ring_bottle_z = (float)src->ring_bottle_z;
         dst.bin_width = (float)src->bin_width; dst.inv_bin_width = (float)src->inv_bin_width;
         dst.na_cos_min = (float)src->na_cos_min; dst.twopi = (float)src->twopi;
+        dst.spot_dphi = (float)src->spot_dphi; dst.spot_dtheta = (float)src->spot_dtheta;
+        dst.crs_sigma = (float)src->crs_sigma; dst.crs_radius = (float)src->crs_radius;
+        dst.crs_cy = (float)src->crs_cy; dst.crs_cz = (float)src->crs_cz;
+        dst.emitter[0] = src->emitter[0]; dst.emitter[1] = src->emitter[1];
     }
     __syncthreads();
 }
@@ -167,14 +171,14 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             Draws d;
             if (a.u) d.init_table(a.u + ic, (int64_t)n, a.nu, a.draw_base);
             else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
-            if (!have_in) { if (a.phase == 1) emit_ring<T>(S, r, d); else emit_point<T>(S, r, d); }
+            if (!have_in) emit<T>(S, a.phase, r, d, a.first_ray + ic);
             em = r;
             walk<FILT, T>(S, surf, 0, ns, r, d, nis, st, xp, yp);
             kdraws = d.k;
         } else {
             KeyedDraws d;
             d.init_keyed(a.rng_base, a.first_ray + ic, have_in ? a.draw_base : 0);
-            if (!have_in) { if (a.phase == 1) emit_ring<T>(S, r, d); else emit_point<T>(S, r, d); }
+            if (!have_in) emit<T>(S, a.phase, r, d, a.first_ray + ic);
             walk<FILT, T>(S, surf, 0, ns, r, d, nis, st, xp, yp);
         }
         if (!act) continue;
@@ -315,8 +319,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 r.dir = {a.pos_dir_in[3 * n + ic], a.pos_dir_in[4 * n + ic], a.pos_dir_in[5 * n + ic]};
             } else {
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                if (a.phase == 1) emit_ring<double>(S, r, d);
-                else emit_point<double>(S, r, d);
+                emit<double>(S, a.phase, r, d, a.first_ray + ic);
             }
             walk<FILT, double>(S, surf, 0, split, r, d, nis, st, xp, yp);
             const bool survive = act && st < 0;
@@ -354,8 +357,7 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int
         KeyedDraws d;
         d.init_keyed(rng_base, first_ray + i, 0);
         Ray r;
-        if (phase == 1) emit_ring<double>(S, r, d);
-        else emit_point<double>(S, r, d);
+        emit<double>(S, phase, r, d, first_ray + i);
         pos_dir[0 * n + i] = r.pos.x; pos_dir[1 * n + i] = r.pos.y; pos_dir[2 * n + i] = r.pos.z;
         pos_dir[3 * n + i] = r.dir.x; pos_dir[4 * n + i] = r.dir.y; pos_dir[5 * n + i] = r.dir.z;
     }
@@ -403,6 +405,7 @@ int check_system(const ort_system *sys)
                 return fail(ORT_E_INVALID, "the image plane must be the last surface, and only the last");
         }
         if (sys->split[p] < 0 || sys->split[p] > n) return fail(ORT_E_INVALID, "split out of range");
+        if (sys->emitter[p] < ORT_EMIT_RING || sys->emitter[p] > ORT_EMIT_CRS) return fail(ORT_E_INVALID, "bad emitter");
     }
     return ORT_OK;
 }

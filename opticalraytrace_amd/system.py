@@ -84,16 +84,19 @@ class OpticalSystem:
     r2: float
     img_plane: float
     bottle_moved: bool = False
+    crs_spot_size: float = 0.0       # spot_size after setupMod.f90:136
 
     # ------------------------------------------------------------------
     @classmethod
     def from_settings(cls, settings: Settings, res_dir: Optional[str] = None) -> "OpticalSystem":
         res_dir = res_dir or resource_dir()
         s = settings
-        if s.light_source not in ("point",):
-            # the phase-2 emitters image/spot/isors/crs are outside this hot path
+        if s.light_source not in ("point", "spot", "crs"):
+            # `image` needs the per-thread decrementing histogram of emit_image;
+            # `isors` aborts in the reference itself (`error stop "no intersection with bottle!"`,
+            # src/sourceMod.f90:217) as soon as one ray reflects at the axicon (2.8 % per ray).
             raise ParamsError(f"light source {s.light_source!r} is not implemented on the "
-                              "MI355X path (point only; ring is always phase 1)")
+                              "MI355X path (point, spot and crs are)")
         wl = s.wavelength
         bottle = GlassBottle.from_file(os.path.join(res_dir, s.bottle_file), wl)
         if bottle.scatters:
@@ -110,18 +113,22 @@ class OpticalSystem:
         alpha = s.alpha * PI / 180.0                           # setupMod.f90:61
         angle = math.atan(a.radius / a.fb)                     # main.f90:51
         cos_theta_max = math.cos(angle)
+        # setupMod.f90:135-136, evaluated before the clamp below as in the reference
+        offset0 = bottle.radiusa + bottle.centre[2]
+        crs_spot_size = (s.crs_spot_size * (a.fb - offset0)) / a.fb
         moved = False
         if a.fb <= bottle.radiusa + bottle.centre[2]:          # main.f90:54-58
             bottle.centre[2] = a.fb - bottle.radiusa - 2e-3
             moved = True
-        distance = bottle.radiusa + bottle.centre[2]           # main.f90:63
+        distance = bottle.radiusa + bottle.centre[2]           # main.f90:63 (not isors)
         bessel = distance * L1_FB * math.tan(alpha * (s.n_axicon - 1)) / a.fb   # main.f90:66
         r1 = bessel - s.ring_width                             # main.f90:68-70
         half = bessel / 2.0
         r2 = half * half
         r1 = r1 * r1
         img_plane = 2.0 * (a.fb + L3[0].fb) + a.thickness + L3[0].thickness     # main.f90:81
-        return cls(s, bottle, L2, L3, cos_theta_max, distance, bessel, r1, r2, img_plane, moved)
+        return cls(s, bottle, L2, L3, cos_theta_max, distance, bessel, r1, r2, img_plane, moved,
+                   crs_spot_size)
 
     # ------------------------------------------------------------------
     def surfaces(self, phase: int) -> List[Surface]:

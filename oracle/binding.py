@@ -51,12 +51,18 @@ class OrcSystem(C.Structure):
     _fields_ = [("L2", OrcPlano * 2), ("L3", OrcDoublet * 2), ("bottle", OrcBottle)] + \
                [(k, C.c_double) for k in ("cosThetaMax", "r1", "r2", "img_plane", "fibre_offset",
                                           "image_diameter", "iris_radius")] + \
-               [(k, C.c_int32) for k in ("iris_before", "iris_after", "use_bottle", "pad")]
+               [(k, C.c_int32) for k in ("iris_before", "iris_after", "use_bottle", "source",
+                                         "nphotons", "pad2")] + \
+               [(k, C.c_double) for k in ("isors_offset", "ring_width", "spot_size")]
+
+
+SOURCE_CODES = {"point": 0, "spot": 1, "crs": 2}
 
 
 def build_oracle(force: bool = False) -> str:
     if force or not os.path.exists(ORACLE_SO) or \
-            os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "ort_oracle.c")):
+            os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(os.path.join(HERE, f))
+                                              for f in ("ort_oracle.c", "ort_oracle.h")):
         subprocess.run(["make", "-C", HERE, "oracle"], check=True, capture_output=True)
     return ORACLE_SO
 
@@ -88,6 +94,9 @@ def fill_system(osys) -> OrcSystem:
     S.fibre_offset, S.image_diameter, S.iris_radius = s.fibre_offset, s.image_diameter, s.iris_size
     S.iris_before, S.iris_after = int(s.iris == "before"), int(s.iris == "after")
     S.use_bottle = int(s.use_bottle)
+    S.source = SOURCE_CODES[s.light_source]
+    S.nphotons = s.nphotons
+    S.isors_offset, S.ring_width, S.spot_size = s.isors_offset, s.ring_width, osys.crs_spot_size
     return S
 
 
@@ -174,6 +183,9 @@ class Reference:
                            s.wavelength, s.alpha, s.n_axicon, s.ring_width, s.image_diameter,
                            s.fibre_offset, iris_mode, s.iris_size, int(s.use_bottle))
         assert rc == 0
+        L.ortref_set_source.argtypes = [C.c_int, C.c_int] + [C.c_double] * 5
+        L.ortref_set_source(SOURCE_CODES[s.light_source], s.nphotons, s.isors_offset, s.crs_spot_size,
+                            s.alpha, s.n_axicon, s.ring_width)
 
     def constants(self) -> np.ndarray:
         out = np.zeros(64)

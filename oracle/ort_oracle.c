@@ -54,6 +54,22 @@ static inline double ran2(draws_t *d)
 /* ranu, src/random_mod.f90:48-57 */
 static inline double ranu(draws_t *d, double a, double b) { return a + ran2(d) * (b - a); }
 
+/* rang, src/random_mod.f90:59-85: polar Box-Muller, a variable number of draws */
+static void rang(draws_t *d, double *x, double *y, double avg, double sigma)
+{
+    double s = 1.;
+    while (s >= 1.) {
+        *x = ranu(d, -1., 1.);
+        *y = ranu(d, -1., 1.);
+        s = (*y) * (*y) + (*x) * (*x);
+    }
+    double cst = sqrt(-2. * log(s) / s);
+    double tmp = (*x) * cst;
+    *x = avg + sigma * tmp;
+    tmp = (*y) * cst;
+    *y = avg + sigma * tmp;
+}
+
 /* ------------------------------------------------------- vector_class ---- */
 static inline orc_vec v(double x, double y, double z) { orc_vec r = {x, y, z}; return r; }
 /* vec_minus_vec :48-57, vec_add_vec :84-93 */
@@ -360,8 +376,9 @@ static int telescope(const orc_system *S, int ph, orc_vec *pos, orc_vec *dir, dr
 /* ------------------------------------------------------------ sources ---- */
 static const double PI_F = 3.14159265358979323846;   /* 4.*atan(1.), src/constants.f90:5 */
 
-/* point, src/sourceMod.f90:12-47 (offset absent at the call site main.f90:136) */
-static void emit_point(double cosThetaMax, orc_vec *pos, orc_vec *dir, draws_t *d)
+/* point, src/sourceMod.f90:12-47 (offset absent at the call site main.f90:136, bottle%centre%z
+ * at :140 for the isors source) */
+static void emit_point(double cosThetaMax, double offset, orc_vec *pos, orc_vec *dir, draws_t *d)
 {
     const double twopi = 2. * PI_F;
     double phi = twopi * ran2(d);
@@ -371,7 +388,42 @@ static void emit_point(double cosThetaMax, orc_vec *pos, orc_vec *dir, draws_t *
     double cost = (1.0 - ran) + ran * cosThetaMax;
     double sint = sqrt(1.0 - cost * cost);
     *dir = v(sint * cosp, sint * sinp, cost);
-    *pos = v(0.0, 0.0, 0.0 + 0.0);
+    *pos = v(0.0, 0.0, 0.0 + offset);
+}
+
+/* create_spot, src/sourceMod.f90:122-159: deterministic fan of rays, no draws */
+static void emit_spot(double cosThetaMax, int nrays, int n, orc_vec *pos, orc_vec *dir)
+{
+    const double twopi = 2. * PI_F;
+    double nrays_sqrt = sqrt((double)nrays);
+    double thetaMax = acos(cosThetaMax);
+    double deltaPhi = twopi / nrays_sqrt;
+    double deltaTheta = thetaMax / nrays_sqrt;
+    double phi = deltaPhi * (double)(n % 10);
+    double theta = deltaTheta * (double)(n / 10);
+    double sinp = sin(phi), cosp = cos(phi);
+    double cost = cos(theta);
+    double sint = sqrt(1. - cost * cost);
+    *dir = v(sint * cosp, sint * sinp, cost);
+    *pos = v(0., 0., 0.);
+}
+
+/* point_on_bottle, src/sourceMod.f90:50-89 (the "crs" source of phase 1) */
+static void emit_crs(const orc_system *S, orc_vec *pos, orc_vec *dir, draws_t *d)
+{
+    const double twopi = 2. * PI_F;
+    double phi = twopi * ran2(d);
+    double cosp = cos(phi), sinp = sin(phi);
+    double ran = ran2(d);
+    double cost = (1.0 - ran) + ran * S->cosThetaMax;
+    double sint = sqrt(1.0 - cost * cost);
+    double tmp1, tmp2, t = 0.;
+    rang(d, &tmp1, &tmp2, 0., S->spot_size);
+    *pos = v(tmp1, tmp2, 1.0);
+    *dir = v(0., 0., -1.);
+    (void)intersect_cylinder(*pos, *dir, &t, S->bottle.centre, S->bottle.radiusa + S->bottle.thickness);
+    *pos = vadd(*pos, vscale(*dir, t));
+    *dir = v(sint * cosp, sint * sinp, cost);
 }
 
 /* ring, src/sourceMod.f90:250-300 */
@@ -436,13 +488,18 @@ static int make_image(orc_vec dir, orc_vec pos, double diameter, int *xp_out, in
 /* ---------------------------------------------------------- loop body ---- */
 /* one iteration of src/main.f90:90-109 (phase 1) or :127-162 (phase 2) */
 static int one_ray(const orc_system *S, int phase, int have_in, orc_vec *pos, orc_vec *dir,
-                   draws_t *d, int *nis, int *xp, int *yp, orc_vec *epos, orc_vec *edir)
+                   draws_t *d, int *nis, int *xp, int *yp, orc_vec *epos, orc_vec *edir, uint64_t iray)
 {
     int ph = phase - 1, rc;
     *nis = 0;
     if (!have_in) {
-        if (phase == 1) emit_ring(S, pos, dir, d);
-        else            emit_point(S->cosThetaMax, pos, dir, d);
+        if (phase == 1) {                                   /* main.f90:95-101 */
+            if (S->source == 2) emit_crs(S, pos, dir, d);
+            else emit_ring(S, pos, dir, d);
+        } else {                                            /* main.f90:132-142 */
+            if (S->source == 1) emit_spot(S->cosThetaMax, S->nphotons, (int)(iray + 1), pos, dir);
+            else emit_point(S->cosThetaMax, 0.0, pos, dir, d);
+        }
     }
     *epos = *pos; *edir = *dir;
     if (phase == 2 && S->use_bottle) {
@@ -472,7 +529,8 @@ int orc_trace_rays(const orc_system *sys, int phase, int64_t n,
             dir = v(pos_dir_in[3 * n + i], pos_dir_in[4 * n + i], pos_dir_in[5 * n + i]);
         }
         int nis, xp = -9999, yp = -9999;
-        int st = one_ray(sys, phase, pos_dir_in != NULL, &pos, &dir, &d, &nis, &xp, &yp, &ep, &ed);
+        int st = one_ray(sys, phase, pos_dir_in != NULL, &pos, &dir, &d, &nis, &xp, &yp, &ep, &ed,
+                         first_ray + (uint64_t)i);
         if (pos_dir_out) {
             pos_dir_out[0 * n + i] = pos.x; pos_dir_out[1 * n + i] = pos.y; pos_dir_out[2 * n + i] = pos.z;
             pos_dir_out[3 * n + i] = dir.x; pos_dir_out[4 * n + i] = dir.y; pos_dir_out[5 * n + i] = dir.z;
@@ -507,7 +565,7 @@ int orc_trace(const orc_system *sys, int phase, uint64_t first, uint64_t n, uint
         d.seed = seed; d.ray = first + i; d.phase = phase; d.k = 0;
         orc_vec pos, dir, ep, ed;
         int nis, xp = 0, yp = 0;
-        int st = one_ray(sys, phase, 0, &pos, &dir, &d, &nis, &xp, &yp, &ep, &ed);
+        int st = one_ray(sys, phase, 0, &pos, &dir, &d, &nis, &xp, &yp, &ep, &ed, first + i);
         isect += (uint64_t)nis;
         if (st == ORC_LOST_BOTTLE || st == ORC_LOST_TELESCOPE || st == ORC_HELP3) lost++;
         if (st == ORC_HELP3) help3++;

@@ -50,7 +50,13 @@ typedef struct {
     orc_doublet L3[2];
     orc_bottle  bottle;
     double cosThetaMax, r1, r2, img_plane, fibre_offset, image_diameter, iris_radius;
-    int32_t iris_before, iris_after, use_bottle, pad;
+    int32_t iris_before, iris_after, use_bottle;
+    /* light source (src/setupMod.f90:85-99): 0 point, 1 spot, 2 crs.  (isors: the reference
+     * aborts — `error stop "no intersection with bottle!"`, src/sourceMod.f90:217 — as soon as a
+     * ray reflects at the axicon, 2.8 % per ray; not restated.) */
+    int32_t source;
+    int32_t nphotons, pad2;        /* create_spot needs the loop length (src/main.f90:138) */
+    double isors_offset, ring_width, spot_size;   /* spot_size after src/setupMod.f90:136 */
 } orc_system;
 
 /* per-ray status (same numbering as include/ort.h, restated) */

@@ -17,7 +17,7 @@ module ortref_api
     use iso_fortran_env, only : int64
     use vector_class
     use lensMod
-    use source,      only : point, ring
+    use source,      only : point, ring, create_spot, point_on_bottle, iSORS
     use imageMod,    only : makeImage
     use opticsystem, only : telescope
     use stackMod,    only : stack
@@ -31,6 +31,9 @@ module ortref_api
     type(glass_bottle),       save :: bot
     real,    save :: cosThetaMax, r1, r2, img_plane_1, img_diam, besselDiameter, distance
     logical, save :: use_bottle_s
+    ! source type: 0 point, 1 spot, 2 crs, 3 isors (setupMod.f90:85-99)
+    integer, save :: source_s = 0, nphotons_s = 100
+    real,    save :: isors_offset_s = 0., ring_width_s = 0., spot_size_s = 0.
 
     interface
         subroutine ortref_rng_table(u, stride, len, first_draw) bind(C, name="ortref_rng_table")
@@ -107,6 +110,31 @@ contains
         rc = 0
     end function ortref_init
 
+    ! Source selection + the source-dependent set-up lines: setupMod.f90:85-99, :132-136 and
+    ! main.f90:60-70.  Call after ortref_init.
+    subroutine ortref_set_source(source, nphotons, isors_offset, crs_spot_size, alpha_deg, n_axicon, ring_width) &
+               bind(C, name="ortref_set_source")
+        integer(c_int), value :: source, nphotons
+        real(c_double), value :: isors_offset, crs_spot_size, alpha_deg, n_axicon, ring_width
+        real :: offset, alpha
+        source_s = source
+        nphotons_s = nphotons
+        isors_offset_s = isors_offset
+        ring_width_s = ring_width
+        offset = bot%radiusa + bot%centre%z                         ! setupMod.f90:135
+        spot_size_s = (crs_spot_size*(L2a%fb - offset)) / L2a%fb    ! setupMod.f90:136
+        alpha = alpha_deg * pi / 180.
+        if (source == 3) then                                       ! main.f90:60-64
+            distance = bot%radiusa + isors_offset
+        else
+            distance = (bot%radiusa + bot%centre%z)
+        end if
+        besselDiameter = distance*97.3d-3*tan(alpha*(n_axicon - 1)) / (L2a%fb)
+        r1 = besselDiameter - ring_width
+        r2 = (besselDiameter / 2.d0)**2
+        r1 = r1**2
+    end subroutine ortref_set_source
+
     subroutine ortref_constants(out) bind(C, name="ortref_constants")
         real(c_double), intent(OUT) :: out(64)
         out = 0.
@@ -128,17 +156,19 @@ contains
         out(42) = pi
         out(43) = L3b%centre1%z; out(44) = L3b%centre2%z; out(45) = L3b%centre3%z
         out(46) = L2b%centre%z
+        out(47) = spot_size_s
     end subroutine ortref_constants
 
     ! One ray through the reference path.  status: 0 binned, 1 reached the image
     ! plane but makeImage did not bin it, 3 lost in the bottle, 4 lost in telescope.
-    subroutine one_ray(phase, have_in, pos, dir, image, status, xp, yp, emitted)
+    subroutine one_ray(phase, have_in, pos, dir, image, status, xp, yp, emitted, iray)
         integer, intent(IN) :: phase
         logical, intent(IN) :: have_in
         type(vector), intent(INOUT) :: pos, dir
         integer, intent(INOUT) :: image(-200:200, -200:200, 2)
         integer, intent(OUT) :: status, xp, yp
         real, intent(OUT) :: emitted(6)
+        integer, intent(IN) :: iray          ! 1-based loop index (create_spot uses it)
         type(stack) :: tracker
         integer(int64) :: cnt
         logical :: skip
@@ -149,12 +179,27 @@ contains
         cnt = 0_int64
         xp = -9999; yp = -9999
         if (phase == 1) then
-            if (.not. have_in) call ring(pos, dir, L2a, r1, r2, bot%radiusa, bot%radiusb, &
-                                         bot%ellipse, bot%centre%z)          ! main.f90:100
+            if (.not. have_in) then                                          ! main.f90:95-101
+                if (source_s == 3) then
+                    call iSORS(pos, dir, bot, L2a, isors_offset_s, ring_width_s, .true.)
+                elseif (source_s == 2) then
+                    call point_on_bottle(pos, dir, cosThetaMax, bot, spot_size_s)
+                else
+                    call ring(pos, dir, L2a, r1, r2, bot%radiusa, bot%radiusb, bot%ellipse, bot%centre%z)
+                end if
+            end if
             emitted = [pos%x, pos%y, pos%z, dir%x, dir%y, dir%z]
             call telescope(pos, dir, L2a, L3a, img_plane_1, cnt, tracker, 0, skip) ! main.f90:104
         else
-            if (.not. have_in) call point(pos, dir, cosThetaMax)             ! main.f90:136
+            if (.not. have_in) then                                          ! main.f90:132-142
+                if (source_s == 1) then
+                    call create_spot(pos, dir, cosThetaMax, nphotons_s, iray)
+                elseif (source_s == 3) then
+                    call point(pos, dir, cosThetaMax, bot%centre%z)
+                else
+                    call point(pos, dir, cosThetaMax)
+                end if
+            end if
             emitted = [pos%x, pos%y, pos%z, dir%x, dir%y, dir%z]
             if (use_bottle_s) then
                 call bot%forward(pos, dir, tracker, skip)                    ! main.f90:146
@@ -210,7 +255,7 @@ contains
                 pos = vector(pos_dir_in(i, 1), pos_dir_in(i, 2), pos_dir_in(i, 3))
                 dir = vector(pos_dir_in(i, 4), pos_dir_in(i, 5), pos_dir_in(i, 6))
             end if
-            call one_ray(phase, have_in /= 0, pos, dir, image, st, xp, yp, em)
+            call one_ray(phase, have_in /= 0, pos, dir, image, st, xp, yp, em, int(i))
             pos_dir_out(i, :) = [pos%x, pos%y, pos%z, dir%x, dir%y, dir%z]
             emitted_out(i, :) = em
             status(i) = st
@@ -239,12 +284,24 @@ contains
             skip = .false.
             call ortref_rng_key(seed, phase, i, 0)
             if (phase == 1) then
-                call ring(pos, dir, L2a, r1, r2, bot%radiusa, bot%radiusb, bot%ellipse, bot%centre%z)
+                if (source_s == 3) then
+                    call iSORS(pos, dir, bot, L2a, isors_offset_s, ring_width_s, .true.)
+                elseif (source_s == 2) then
+                    call point_on_bottle(pos, dir, cosThetaMax, bot, spot_size_s)
+                else
+                    call ring(pos, dir, L2a, r1, r2, bot%radiusa, bot%radiusb, bot%ellipse, bot%centre%z)
+                end if
                 call telescope(pos, dir, L2a, L3a, img_plane_1, cnt, tracker, 0, skip)
                 if (skip) cycle
                 call makeImage(image, dir, pos, img_diam, 1)
             else
-                call point(pos, dir, cosThetaMax)
+                if (source_s == 1) then
+                    call create_spot(pos, dir, cosThetaMax, nphotons_s, int(i + 1))
+                elseif (source_s == 3) then
+                    call point(pos, dir, cosThetaMax, bot%centre%z)
+                else
+                    call point(pos, dir, cosThetaMax)
+                end if
                 if (use_bottle_s) call bot%forward(pos, dir, tracker, skip)
                 if (skip) then
                     cnt = cnt + 1_int64

@@ -51,13 +51,16 @@ CONFIGS = {
     "small_f60_nobottle": dict(bottle_file="clearBottle-small.params", use_bottle=False,
                                L3_file="achromaticDoublet-f60.0mm.params",
                                L2_file="planoConvex-f49.8mm.params", fibre_offset=1e-3),
+    # SURVEY §8 f2 emitters: spot (create_spot, runner.py -s uses 100 rays) and crs (point_on_bottle)
+    "small_spot": dict(bottle_file="clearBottle-small.params", light_source="spot", nphotons=100),
+    "large_crs": dict(bottle_file="clearBottle-large.params", light_source="crs", crs_spot_size=1e-3),
 }
 
 
 def make_system(name: str):
     from opticalraytrace_amd.params import Settings
     from opticalraytrace_amd.system import OpticalSystem
-    s = Settings(nphotons=100000, make_images=True, **CONFIGS[name])
+    s = Settings(**{**dict(nphotons=100000, make_images=True), **CONFIGS[name]})
     return s, OpticalSystem.from_settings(s)
 
 

@@ -8,8 +8,8 @@ lie under /root/reference/src (flang), and reads the reference's own data files
 uniform draws, rays) and the outputs the reference produced for them:
 
   <config>.npz
-    constants      46 values of the reference's constructors / set-up lines
-    p{1,2}_u       [9][n] uniforms fed to ran2(), in draw order
+    constants      47 values of the reference's constructors / set-up lines
+    p{1,2}_u       [32][n] uniforms fed to ran2(), in draw order
     p{1,2}_emitted [6][n] ray produced by ring / point
     p{1,2}_pos_dir [6][n] ray state when the reference loop body ended
     p{1,2}_status  0 binned, 1 reached image plane but not binned, 3 lost in bottle,
@@ -37,22 +37,30 @@ from oracle.binding import Reference  # noqa: E402
 
 REF_RES = "/root/reference/res"
 N_RAYS = 192
+N_DRAWS = 32             # rows of the uniform table (the crs source draws a variable number)
+# draws the emitter of (source, phase) consumes; None = variable (crs phase 1: explicit-input
+# re-trace starts at draw 0 of a FRESH table row set instead)
+EMIT_DRAWS = {("point", 1): 4, ("point", 2): 2, ("spot", 1): 4, ("spot", 2): 0,
+              ("crs", 1): 0, ("crs", 2): 2}
 N_IMAGE = 100000
 SEED = 123456789          # src/main.f90:79
 
 
 def main():
     for ci, (name, over) in enumerate(CONFIGS.items()):
-        s = Settings(nphotons=N_IMAGE, make_images=True, **over)
+        s = Settings(**{**dict(nphotons=N_IMAGE, make_images=True), **over})
         ref = Reference(s, REF_RES)
-        out = {"constants": ref.constants()[:46]}
+        n_rays = min(N_RAYS, s.nphotons)
+        n_image = s.nphotons
+        out = {"constants": ref.constants()[:47]}
         rng = np.random.default_rng(1000 + ci)
         for phase in (1, 2):
-            u = rng.random((9, N_RAYS))
+            u = rng.random((N_DRAWS, n_rays))
             # force both Fresnel branches on some rays (u=0 reflects, u->1 refracts)
-            u[4:, :8] = 0.0
-            u[4:, 8:16] = 1.0 - 2.0 ** -53
-            r = ref.trace_rays(phase, N_RAYS, u=u)
+            if s.light_source == "point":
+                u[4:9, :8] = 0.0
+                u[4:9, 8:16] = 1.0 - 2.0 ** -53
+            r = ref.trace_rays(phase, n_rays, u=u)
             p = f"p{phase}_"
             out[p + "u"] = u
             out[p + "emitted"] = r["emitted"]
@@ -60,14 +68,14 @@ def main():
             out[p + "status"] = r["status"]
             out[p + "bin"] = r["bin_xy"]
             out[p + "ndraws"] = r["n_draws"]
-            base = 4 if phase == 1 else 2
-            rx = ref.trace_rays(phase, N_RAYS, pos_dir_in=r["emitted"], u=u, draw_base=base)
+            base = EMIT_DRAWS[(s.light_source, phase)]
+            rx = ref.trace_rays(phase, n_rays, pos_dir_in=r["emitted"], u=u, draw_base=base)
             p = f"p{phase}x_"
             out[p + "pos_dir"] = rx["pos_dir"]
             out[p + "status"] = rx["status"]
             out[p + "bin"] = rx["bin_xy"]
             out[p + "ndraws"] = rx["n_draws"]
-            img, lost = ref.trace(phase, 0, N_IMAGE, SEED)
+            img, lost = ref.trace(phase, 0, n_image, SEED)
             flat = img.reshape(-1)
             idx = np.nonzero(flat)[0].astype(np.int32)
             out[f"img{phase}_idx"] = idx

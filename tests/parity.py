@@ -51,3 +51,13 @@ def assert_rays_equal(got, want, exact=True, what=""):
         else:
             assert rel_err(g[:, reach], w[:, reach]) <= REL_TOL, \
                 f"{what}: {key} rel err {rel_err(g[:, reach], w[:, reach]):.3e} > {REL_TOL}"
+
+
+# draws the emitter of (light source, phase) consumes before the first surface
+# (crs phase 1 draws a variable number: its explicit-input fixtures restart at draw 0)
+EMIT_DRAWS = {("point", 1): 4, ("point", 2): 2, ("spot", 1): 4, ("spot", 2): 0,
+              ("crs", 1): 0, ("crs", 2): 2}
+
+
+def emit_draws(settings, phase):
+    return EMIT_DRAWS[(settings.light_source, phase)]

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import CONFIGS, make_system
-from parity import REL_TOL, SEED, assert_rays_equal, load_golden, merge_status, rel_err, sparse_image
+from parity import emit_draws, REL_TOL, SEED, assert_rays_equal, load_golden, merge_status, rel_err, sparse_image
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +46,7 @@ def test_golden_explicit_rays_bit_exact(ctxs, name, phase):
     osys, ctx = ctxs(name)
     u = g[f"p{phase}_u"]
     n = u.shape[1]
-    base = 4 if phase == 1 else 2
+    base = emit_draws(osys.settings, phase)
     got = ctx.trace_rays(phase, n, pos_dir_in=g[f"p{phase}_emitted"], u=u, draw_base=base)
     want = dict(status=g[f"p{phase}x_status"], bin_xy=g[f"p{phase}x_bin"],
                 n_draws=g[f"p{phase}x_ndraws"], pos_dir=g[f"p{phase}x_pos_dir"])
@@ -63,7 +63,9 @@ def test_golden_emitted_rays(ctxs, name, phase):
     n = u.shape[1]
     got = ctx.trace_rays(phase, n, u=u)
     em = g[f"p{phase}_emitted"]
-    assert rel_err(got["emitted"], em) <= 1e-12, rel_err(got["emitted"], em)
+    # spot: deltaTheta * k is a multiple of pi/2-ish fractions, cos(theta) ~ 1: absolute 1e-15
+    assert rel_err(got["emitted"], em) <= 1e-12 or np.abs(got["emitted"] - em).max() < 1e-15, \
+        rel_err(got["emitted"], em)
     st_g, st_w = merge_status(got["status"]), g[f"p{phase}_status"]
     assert np.array_equal(st_g, st_w)
     assert np.array_equal(got["n_draws"], g[f"p{phase}_ndraws"])

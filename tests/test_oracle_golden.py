@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import CONFIGS, make_system
-from parity import SEED, assert_rays_equal, load_golden, merge_status, sparse_image
+from parity import emit_draws, SEED, assert_rays_equal, load_golden, merge_status, sparse_image
 from oracle.binding import Oracle
 
 
@@ -12,7 +12,7 @@ from oracle.binding import Oracle
 @pytest.mark.parametrize("phase", [1, 2])
 def test_oracle_matches_golden_rays(name, phase):
     g = load_golden(name)
-    _, osys = make_system(name)
+    settings, osys = make_system(name)
     orc = Oracle(osys)
     u = g[f"p{phase}_u"]
     n = u.shape[1]
@@ -22,13 +22,13 @@ def test_oracle_matches_golden_rays(name, phase):
     assert np.array_equal(got["emitted"], g[f"p{phase}_emitted"]), "emitted rays not bit-exact"
     assert_rays_equal(got, want, exact=True, what=f"{name} phase {phase}")
     # explicit-input variant (no emitter on the path)
-    base = 4 if phase == 1 else 2
+    base = emit_draws(settings, phase)
     gotx = orc.trace_rays(phase, n, pos_dir_in=g[f"p{phase}_emitted"], u=u, draw_base=base)
     wantx = dict(status=g[f"p{phase}x_status"], bin_xy=g[f"p{phase}x_bin"],
                  n_draws=g[f"p{phase}x_ndraws"], pos_dir=g[f"p{phase}x_pos_dir"])
     assert_rays_equal(gotx, wantx, exact=True, what=f"{name} phase {phase} explicit")
     # both Fresnel branches were forced in the fixture
-    if name not in ("ellipse",):
+    if name not in ("ellipse",) and settings.light_source == "point":
         st = merge_status(g[f"p{phase}_status"])
         assert (st[:8] != 0).all(), "u=0 rays must reflect somewhere and be lost or rejected"
 
@@ -36,12 +36,12 @@ def test_oracle_matches_golden_rays(name, phase):
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_oracle_matches_golden_images(name):
     g = load_golden(name)
-    _, osys = make_system(name)
+    settings, osys = make_system(name)
     orc = Oracle(osys)
     img = np.zeros((2, 401, 401), np.int32)
     cnt = np.zeros(8, np.uint64)
     for phase in (1, 2):
-        orc.trace(phase, 0, 100000, SEED, img, cnt)
+        orc.trace(phase, 0, settings.nphotons, SEED, img, cnt)
     want = sparse_image(g["img1_idx"], g["img1_cnt"]) + sparse_image(g["img2_idx"], g["img2_cnt"])
     assert np.array_equal(img, want)
     assert int(cnt[0]) == int(g["img1_lost"]) and int(cnt[1]) == int(g["img2_lost"])
