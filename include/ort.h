@@ -58,6 +58,9 @@ extern "C" {
 #define ORT_F_SKIP_ON_REFLECT 1u /* a Fresnel reflection ends the ray (every surface but the plano flat face, src/lens.f90:458-459) */
 #define ORT_F_MISS_IS_HELP3 2u   /* a miss here is the reference's `error stop "Help3"` (src/lens.f90:617): counted, not fatal */
 #define ORT_F_BOTTLE 4u          /* losses at this surface are bottle losses (src/main.f90:150-151) */
+#define ORT_F_TRACK 8u           /* the ray-path tracker pushes the position after this surface
+                                    (src/main.f90:147, src/optics_system.f90:29,39,50) */
+#define ORT_MAX_PATH 6           /* emission + bottle + L1 + L2 + image plane (+ spare) */
 
 /* One optical surface as staged into LDS (80 B). */
 typedef struct ort_surface {
@@ -170,6 +173,15 @@ int ort_trace_rays(ort_ctx *ctx, int phase, int64_t n,
                    uint64_t seed, uint64_t first_ray,
                    double *pos_dir_out, double *emitted_out, int32_t *status,
                    int32_t *bin_xy, int32_t *n_isect, int32_t *n_draws);
+
+/* Ray-path tracker (reference src/stackMod.f90, `use_tracker`): for rays [first_ray,
+ * first_ray+n) of `phase` with keyed draws, the positions the reference pushes on its stack —
+ * after emission (src/main.f90:103,144), after bottle%forward (:147), after each lens of
+ * telescope and at the image plane (src/optics_system.f90:29,39,50) — plus, for a ray that is
+ * lost, the position where it ended.  path is [n][ORT_MAX_PATH][3] (host), npath[n] the number
+ * of points, status[n] the ORT_ST_* outcome.  No side effect on the image.  Synchronous. */
+int ort_trace_paths(ort_ctx *ctx, int phase, int64_t n, uint64_t seed, uint64_t first_ray,
+                    double *path, int32_t *npath, int32_t *status);
 
 /* Accumulator access.  ort_read replaces reading `image`, `rcount`, `pcount`
  * after the loops (src/main.f90:175-185); synchronises the stream.

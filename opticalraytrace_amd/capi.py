@@ -142,6 +142,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ort_trace_resident": (C.c_int, [vp, i32, u64, u64, u64, i32, vp]),
         "ort_trace_rays": (C.c_int, [vp, i32, i64, _DP, i32, _DP, i32, u64, u64,
                                      _DP, _DP, _IP, _IP, _IP, _IP]),
+        "ort_trace_paths": (C.c_int, [vp, i32, i64, u64, u64, _DP, _IP, _IP]),
         "ort_read": (C.c_int, [vp, _IP, C.POINTER(C.c_uint64)]),
         "ort_attach_buffers": (C.c_int, [vp, vp, vp]),
         "ort_device_image": (C.c_int, [vp, C.POINTER(vp)]),
@@ -165,7 +166,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = ["ort_abi_version", "ort_last_error", "ort_device_count", "ort_create",
                     "ort_destroy", "ort_set_system", "ort_reset", "ort_trace", "ort_emit",
-                    "ort_trace_resident", "ort_trace_rays", "ort_read", "ort_attach_buffers",
+                    "ort_trace_resident", "ort_trace_rays", "ort_trace_paths", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
                     "ort_device_counters", "ort_synchronize", "ort_last_kernel_ms",
                     "ort_set_timing", "ort_kernel_times", "ort_set_kernel_variant", "ort_set_precision"]
@@ -305,6 +306,22 @@ class Context:
             _dptr(out["pos_dir"]), _dptr(out["emitted"]), _iptr(out["status"]),
             _iptr(out["bin_xy"]), _iptr(out["n_isect"]), _iptr(out["n_draws"])), "ort_trace_rays")
         return out
+
+
+MAX_PATH = 6
+
+
+def _trace_paths(self, phase: int, n: int, seed: int = 0, first_ray: int = 0):
+    """Tracker entry: (path [n][6][3], npath [n], status [n]) for keyed rays."""
+    path = np.zeros((n, MAX_PATH, 3))
+    npath = np.zeros(n, np.int32)
+    status = np.zeros(n, np.int32)
+    _check(self.lib, self.lib.ort_trace_paths(self._h, phase, n, seed, first_ray, _dptr(path),
+                                              _iptr(npath), _iptr(status)), "ort_trace_paths")
+    return path, npath, status
+
+
+Context.trace_paths = _trace_paths
 
 
 def device_count() -> int:

@@ -52,6 +52,8 @@ struct TraceArgs {
     // debug outputs (any may be null)
     double *pos_dir_out, *emitted_out;
     int32_t *status, *bin_xy, *n_isect, *n_draws;
+    double *path;                // [n][ORT_MAX_PATH][3] or null (tracker)
+    int32_t *npath;
 };
 
 // cooperative copy of the system into LDS, 8 bytes per thread per pass
@@ -173,7 +175,28 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
             if (!have_in) emit<T>(S, a.phase, r, d, a.first_ray + ic);
             em = r;
-            walk<FILT, T>(S, surf, 0, ns, r, d, nis, st, xp, yp);
+            if (a.path) {
+                // tracker: the walk of `walk`, recording the pushes of src/stackMod.f90
+                int np = 0;
+                double *pp = a.path + (size_t)ic * ORT_MAX_PATH * 3;
+                auto push = [&](bool c) {
+                    if (c && act && np < ORT_MAX_PATH) {
+                        pp[np * 3 + 0] = r.pos.x; pp[np * 3 + 1] = r.pos.y; pp[np * 3 + 2] = r.pos.z;
+                        np++;
+                    }
+                };
+                push(true);                                          // main.f90:103,144
+                for (int k = 0; k < ns; ++k) {
+                    if (!wave_any(st < 0)) break;
+                    const bool was_live = st < 0;
+                    surface_step<FILT, T>(S, surf[k], r, d, nis, st, xp, yp);
+                    const bool track = (__builtin_amdgcn_readfirstlane((int)surf[k].flags) & ORT_F_TRACK) != 0;
+                    push(was_live && (st >= 0 || track));   // where it ended, or a tracked surface passed alive
+                }
+                if (act) a.npath[ic] = np;
+            } else {
+                walk<FILT, T>(S, surf, 0, ns, r, d, nis, st, xp, yp);
+            }
             kdraws = d.k;
         } else {
             KeyedDraws d;
@@ -654,6 +677,42 @@ done:
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(d_in); (void)hipFree(d_u); (void)hipFree(d_out); (void)hipFree(d_em);
     (void)hipFree(d_st); (void)hipFree(d_bin); (void)hipFree(d_nis); (void)hipFree(d_nd);
+    return rc;
+}
+
+int ort_trace_paths(ort_ctx *c, int phase, int64_t n, uint64_t seed, uint64_t first_ray,
+                    double *path, int32_t *npath, int32_t *status)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    if (phase != 1 && phase != 2) return fail(ORT_E_INVALID, "phase must be 1 (ring) or 2 (point)");
+    if (n < 0 || !path || !npath) return fail(ORT_E_INVALID, "bad arguments");
+    if (n == 0) return ORT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t N = (size_t)n;
+    double *d_path = nullptr;
+    int32_t *d_np = nullptr, *d_st = nullptr;
+    int rc = ORT_OK;
+#define TRY_GOTO(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(ORT_E_HIP, #expr, e_); goto done; } } while (0)
+    TRY_GOTO(hipMalloc(&d_path, N * ORT_MAX_PATH * 3 * sizeof(double)));
+    TRY_GOTO(hipMalloc(&d_np, N * sizeof(int32_t)));
+    TRY_GOTO(hipMalloc(&d_st, N * sizeof(int32_t)));
+    TRY_GOTO(hipMemsetAsync(d_path, 0, N * ORT_MAX_PATH * 3 * sizeof(double), c->stream));
+    {
+        TraceArgs a;
+        memset(&a, 0, sizeof a);
+        a.first_ray = first_ray; a.n_rays = (uint64_t)n; a.rng_base = stream_base(seed, phase);
+        a.phase = phase; a.path = d_path; a.npath = d_np; a.status = d_st;
+        rc = launch_trace(c, MODE_DEBUG, a, -1);
+        if (rc) goto done;
+    }
+    TRY_GOTO(hipMemcpyAsync(path, d_path, N * ORT_MAX_PATH * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TRY_GOTO(hipMemcpyAsync(npath, d_np, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (status) TRY_GOTO(hipMemcpyAsync(status, d_st, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    TRY_GOTO(hipStreamSynchronize(c->stream));
+done:
+#undef TRY_GOTO
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_path); (void)hipFree(d_np); (void)hipFree(d_st);
     return rc;
 }
 

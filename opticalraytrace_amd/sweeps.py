@@ -5,9 +5,9 @@
 Same flags, same loops, same settings defaults and the same `data/<folder>/` outputs as
 runner.py (`-p` :136-155, `-i` :158-186, `-o` :189-208, `-l` :232-261); every simulation is
 one `run_settings` call on ONE reused GPU context instead of one
-`./install.sh -n 32 -f <settings>` process (runner.py:26-47).  `-s` (spot diagrams, needs the
-tracker), `-b` (Bessel image source) and the iSORS comparison use emitters outside this path
-and are refused with a message.
+`./install.sh -n 32 -f <settings>` process (runner.py:26-47).  `-s` (spot diagrams: spot source
++ ray-path tracker dumps, runner.py:113-133) is supported too; `-b` (Bessel image source) and
+the iSORS comparison use emitters outside this path and are refused with a message.
 """
 from __future__ import annotations
 
@@ -59,6 +59,15 @@ class Sweep:
         return res
 
     # ---- runner.py experiments -------------------------------------------------
+    def spot_diagrams(self, bottles=BOTTLES) -> None:      # -s, runner.py:113-133
+        for i, (bottle, use) in enumerate(bottles):
+            keep, self.nphotons = self.nphotons, 100
+            try:
+                self.run(f"test_{i}.params", use_tracker=True, light_source="spot", bottle_file=bottle,
+                         use_bottle=use, data_folder="spot-diag")
+            finally:
+                self.nphotons = keep
+
     def point_images(self, bottles=BOTTLES) -> None:       # -p, runner.py:136-155
         for i, (bottle, use) in enumerate(bottles):
             self.run(f"test_{i}.params", light_source="point", make_images=True,
@@ -99,7 +108,7 @@ class Sweep:
 def main(argv: Optional[Iterable[str]] = None) -> int:
     ap = argparse.ArgumentParser(usage="%(prog)s [OPTION]", description=__doc__,
                                  formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("-s", "--spot", action="store_true", help="(not on this path)")
+    ap.add_argument("-s", "--spot", action="store_true", help="Create spot diagrams.")
     ap.add_argument("-p", "--point", action="store_true", help="Create point/ring images.")
     ap.add_argument("-b", "--bessel", action="store_true", help="(not on this path)")
     ap.add_argument("-o", "--offset", action="store_true", help="Run offset experiment on large bottle.")
@@ -111,13 +120,14 @@ def main(argv: Optional[Iterable[str]] = None) -> int:
     ap.add_argument("--res-dir", default=None)
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args(argv)
-    if args.spot or args.bessel:
-        print("-s / -b need the spot / image emitters (SURVEY §8 f2): not on the MI355X hot path",
-              file=sys.stderr)
+    if args.bessel:
+        print("-b needs the image emitter (SURVEY §8 f2): not on the MI355X hot path", file=sys.stderr)
         return 2
     sw = Sweep(args.nphotons, args.res_dir, args.data_dir, args.device, verbose=True,
                settings_dir=os.path.join(args.data_dir, "settings"))
     try:
+        if args.spot or args.all:
+            sw.spot_diagrams()
         if args.point or args.all:
             sw.point_images()
         if args.offset or args.all:

@@ -26,7 +26,7 @@ NA_SINE = 0.22                     # src/imageMod.f90:40
 
 # surface kinds / flags: numeric values of include/ort.h
 SURF_PLANE, SURF_SPHERE, SURF_CYLINDER, SURF_ELLIPSE, SURF_IRIS, SURF_IMAGE = range(6)
-F_SKIP_ON_REFLECT, F_MISS_IS_HELP3, F_BOTTLE = 1, 2, 4
+F_SKIP_ON_REFLECT, F_MISS_IS_HELP3, F_BOTTLE, F_TRACK = 1, 2, 4, 8
 MAX_SURFACES = 12
 
 
@@ -167,6 +167,16 @@ class OpticalSystem:
             out.append(Surface(SURF_IRIS, l3.centre3_z + l3.R3, aperture=l3.radius * s.iris_size,
                                name="iris after"))
         out.append(Surface(SURF_IMAGE, self.img_plane + s.fibre_offset, name="image plane"))  # optics_system.f90:48
+        # ray-path tracker pushes (stackMod): after bottle%forward (main.f90:147), after each
+        # lens of telescope and at the image plane (optics_system.f90:29,39,50)
+        last = {}
+        for k, sf in enumerate(out):
+            group = ("bottle" if sf.name.startswith("bottle") else
+                     "L2" if sf.name.startswith("L2") else
+                     "image" if sf.kind == SURF_IMAGE else "L3")
+            last[group] = k
+        for k in last.values():
+            out[k].flags |= F_TRACK
         assert len(out) <= MAX_SURFACES
         return out
 

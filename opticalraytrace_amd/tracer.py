@@ -201,6 +201,42 @@ def append_stats(folder: str, system: OpticalSystem, res: RunResult) -> str:
     return path
 
 
+# ---------------------------------------------------------------------------
+# ray-path tracker dumps: src/stackMod.f90:24-52, src/main.f90:72-74,103-107,121-124,144-160
+# ---------------------------------------------------------------------------
+BLANK = "  \n"          # `write(u,*)" "`
+
+
+def format_paths(path: np.ndarray, npath: np.ndarray, status: np.ndarray) -> str:
+    """Text of a `*-ringtrace.dat` / `*-pointtrace.dat` file: per ray the pushed positions popped
+    off the stack (last first) as `3(F10.7,1x)`, then three blank records; a ray lost in
+    `telescope` leaves only the three blank records (write_empty), a ray lost in the bottle
+    leaves its two points and six blank records (main.f90:150-155)."""
+    from .capi import ST_HELP3, ST_LOST_BOTTLE, ST_LOST_TELESCOPE
+    out = []
+    for p, k, st in zip(path, npath, status):
+        if st in (ST_LOST_TELESCOPE, ST_HELP3):
+            out.append(BLANK * 3)
+            continue
+        for x, y, z in p[:k][::-1]:
+            out.append(f"{x:10.7f} {y:10.7f} {z:10.7f}\n")
+        out.append(BLANK * (6 if st == ST_LOST_BOTTLE else 3))
+    return "".join(out)
+
+
+def write_tracker_files(tracer: "RayTracer", system: OpticalSystem, folder: str,
+                        seed: int = DEFAULT_SEED) -> Tuple[str, str]:
+    """`use_tracker`: dump the paths of the run's rays (at most 1e4, setupMod.f90:75)."""
+    n = system.settings.nphotons
+    stem = os.path.join(folder, output_basename(system))
+    names = (stem + "-ringtrace.dat", stem + "-pointtrace.dat")
+    for phase, name in zip((1, 2), names):
+        path, npath, status = tracer.ctx.trace_paths(phase, n, seed=seed, first_ray=0)
+        with open(name, "w") as f:
+            f.write(format_paths(path, npath, status))
+    return names
+
+
 def run_settings(settings: Settings, res_dir: Optional[str] = None, data_dir: str = "data",
                  device: int = 0, verbose: bool = True, tracer: Optional[RayTracer] = None) -> RunResult:
     """One simulation = one execution of `bin/raytrace <settings>` for the hot path: build the
@@ -223,8 +259,17 @@ def run_settings(settings: Settings, res_dir: Optional[str] = None, data_dir: st
     if verbose:                                             # main.f90:180-181
         print(f"Ring  transmitted:  {res.ring_transmitted:8.2f}%")
         print(f"Point transmitted:  {res.point_transmitted:8.2f}%")
-    if settings.make_images:                                # main.f90:183-185
-        write_images(res.image, os.path.join(folder, output_basename(system) + "_image"))
+    if settings.use_tracker:                                # main.f90:72-74, :121-124
+        t = tracer if not own else None
+        if t is None:
+            t = RayTracer(system, device=device)
+        try:
+            write_tracker_files(t, system, folder)
+        finally:
+            if own:
+                t.close()
+    elif settings.make_images:                              # main.f90:183-185; tracker deselects images
+        write_images(res.image, os.path.join(folder, output_basename(system) + "_image"))   # (setupMod.f90:76-82)
     return res
 
 

@@ -124,6 +124,38 @@ def refprog():
         shutil.rmtree(tmp)
 
 
+def refprog_tracker():
+    """Ray-path tracker dumps of the unmodified reference program for the spot source
+    (runner.py -s defaults: 100 rays, tracker on): the emitter is deterministic, so every ray
+    that survives in both runs has the same path to the 7 printed decimals."""
+    import shutil
+    import subprocess
+    import tempfile
+    from oracle.binding import REF_PROG
+    tmp = tempfile.mkdtemp(prefix="ortref_")
+    for d in ("bin", "res", "data"):
+        os.makedirs(os.path.join(tmp, d))
+    for f in os.listdir(REF_RES):
+        if f.endswith(".params") and f != "settings.params":
+            shutil.copy(os.path.join(REF_RES, f), os.path.join(tmp, "res", f))
+    np.ones((512, 512)).tofile(os.path.join(tmp, "res", "ones.dat"))
+    Settings(nphotons=100, use_tracker=True, make_images=True, light_source="spot",
+             bottle_file="clearBottle-small.params", image_source="ones.dat",
+             data_folder="spot-diag").write(os.path.join(tmp, "res", "cfg.params"))
+    subprocess.run([REF_PROG, "cfg.params"], cwd=os.path.join(tmp, "bin"), capture_output=True, check=True)
+    folder = os.path.join(tmp, "data", "spot-diag")
+    pt = [f for f in os.listdir(folder) if f.endswith("-pointtrace.dat")][0]
+    rg = [f for f in os.listdir(folder) if f.endswith("-ringtrace.dat")][0]
+    np.savez_compressed(os.path.join(HERE, "refprog_tracker_small_spot.npz"),
+                        pointtrace=np.array(open(os.path.join(folder, pt)).read()),
+                        ringtrace=np.array(open(os.path.join(folder, rg)).read()),
+                        pointtrace_name=np.array(pt),
+                        stats=np.array(open(os.path.join(folder, "trans-stats.dat")).read()))
+    shutil.rmtree(tmp)
+    print("refprog tracker", pt)
+
+
 if __name__ == "__main__":
     main()
     refprog()
+    refprog_tracker()
