@@ -53,6 +53,8 @@ extern "C" {
 #define ORT_EMIT_POINT 1     /* point           src/sourceMod.f90:12-47   (phase 2: point and crs sources) */
 #define ORT_EMIT_SPOT 2      /* create_spot     src/sourceMod.f90:122-159 (phase 2: spot source, no draws) */
 #define ORT_EMIT_CRS 3       /* point_on_bottle src/sourceMod.f90:50-89   (phase 1: crs source) */
+#define ORT_EMIT_IMAGE 4     /* emit_image/emit src/sourceMod.f90:303-361 (phase 2: image source; needs ort_set_image_source) */
+#define ORT_IMAGE_SOURCE_CELLS (512 * 512)
 
 /* surface flags */
 #define ORT_F_SKIP_ON_REFLECT 1u /* a Fresnel reflection ends the ray (every surface but the plano flat face, src/lens.f90:458-459) */
@@ -106,6 +108,8 @@ typedef struct ort_system {
     /* crs source, point_on_bottle (src/sourceMod.f90:50-89): Gaussian sigma (spot_size after
      * src/setupMod.f90:136), cylinder radius radiusa + thickness, bottle centre y, z */
     double crs_sigma, crs_radius, crs_cy, crs_cz;
+    /* image source, emit (src/sourceMod.f90:325-361): lens%radius**2 and lens%fb of the 843 nm L2 */
+    double img_lens_r2, img_lens_z;
 } ort_system;
 
 /* per-ray status written by ort_trace_rays */
@@ -140,6 +144,11 @@ int ort_device_count(int *count);
 int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out);
 int ort_destroy(ort_ctx *ctx);
 int ort_set_system(ort_ctx *ctx, const ort_system *sys);
+/* Histogram of the `image` light source (reference imgin, src/sourceMod.f90:363-408) as its
+ * cumulative sum in the order emit_image scans the cells (:313-321): cdf[0] = 0,
+ * cdf[s+1] = cdf[s] + count of cell s, ORT_IMAGE_SOURCE_CELLS + 1 host values.  Ray i of the
+ * point loop starts in the cell with cdf[s] <= i < cdf[s+1]. */
+int ort_set_image_source(ort_ctx *ctx, const int64_t *cdf);
 int ort_reset(ort_ctx *ctx);                       /* image = 0, counters = 0 (src/main.f90:39-41) */
 
 /* The hot loop.  Replaces one OpenMP `do i = 1, nphotons` loop of

@@ -24,7 +24,7 @@ ST_BINNED, ST_NA_REJECT, ST_OFF_GRID, ST_LOST_BOTTLE, ST_LOST_TELESCOPE, ST_HELP
 (C_LOST_RING, C_LOST_POINT, C_ISECT_RING, C_ISECT_POINT,
  C_BINNED_RING, C_BINNED_POINT, C_HELP3_RING, C_HELP3_POINT) = range(8)
 
-EMIT_RING, EMIT_POINT, EMIT_SPOT, EMIT_CRS = range(4)
+EMIT_RING, EMIT_POINT, EMIT_SPOT, EMIT_CRS, EMIT_IMAGE = range(5)
 
 _ERRORS = {-1: "ORT_E_INVALID", -2: "ORT_E_NODEVICE", -3: "ORT_E_HIP", -4: "ORT_E_NOMEM"}
 
@@ -52,7 +52,7 @@ class OrtSystem(C.Structure):
                 ("bin_width", C.c_double), ("inv_bin_width", C.c_double), ("na_angle", C.c_double), ("na_cos_min", C.c_double),
                 ("twopi", C.c_double), ("spot_dphi", C.c_double), ("spot_dtheta", C.c_double),
                 ("crs_sigma", C.c_double), ("crs_radius", C.c_double), ("crs_cy", C.c_double),
-                ("crs_cz", C.c_double)]
+                ("crs_cz", C.c_double), ("img_lens_r2", C.c_double), ("img_lens_z", C.c_double)]
 
 
 def pack_system(osys: OpticalSystem) -> OrtSystem:
@@ -88,7 +88,10 @@ def pack_system(osys: OpticalSystem) -> OrtSystem:
     # emitters per phase (src/main.f90:95-101, :132-142)
     src = osys.settings.light_source
     cs.emitter[0] = EMIT_CRS if src == "crs" else EMIT_RING
-    cs.emitter[1] = EMIT_SPOT if src == "spot" else EMIT_POINT
+    cs.emitter[1] = {"spot": EMIT_SPOT, "image": EMIT_IMAGE}.get(src, EMIT_POINT)
+    l2p = osys.L2[1]                          # main.f90:133: emit_image(imgin, pos, dir, L2) after the 843 nm rebuild
+    cs.img_lens_r2 = l2p.radius * l2p.radius
+    cs.img_lens_z = l2p.fb
     nrays_sqrt = math.sqrt(float(osys.settings.nphotons))          # sourceMod.f90:135-141
     if nrays_sqrt > 0:
         cs.spot_dphi = TWOPI / nrays_sqrt
@@ -137,6 +140,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ort_destroy": (C.c_int, [vp]),
         "ort_set_system": (C.c_int, [vp, C.POINTER(OrtSystem)]),
         "ort_reset": (C.c_int, [vp]),
+        "ort_set_image_source": (C.c_int, [vp, C.POINTER(C.c_int64)]),
         "ort_trace": (C.c_int, [vp, i32, u64, u64, u64]),
         "ort_emit": (C.c_int, [vp, i32, u64, u64, u64, vp]),
         "ort_trace_resident": (C.c_int, [vp, i32, u64, u64, u64, i32, vp]),
@@ -165,7 +169,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ["ort_abi_version", "ort_last_error", "ort_device_count", "ort_create",
-                    "ort_destroy", "ort_set_system", "ort_reset", "ort_trace", "ort_emit",
+                    "ort_destroy", "ort_set_system", "ort_set_image_source", "ort_reset", "ort_trace", "ort_emit",
                     "ort_trace_resident", "ort_trace_rays", "ort_trace_paths", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
                     "ort_device_counters", "ort_synchronize", "ort_last_kernel_ms",
@@ -199,6 +203,7 @@ class Context:
                                              C.c_void_p(stream) if stream else None,
                                              C.byref(self._h)), "ort_create")
         self.device = device
+        self._stage_image_source(osys)
 
     def close(self) -> None:
         if self._h:
@@ -222,6 +227,16 @@ class Context:
         self.system = osys
         self._csys = pack_system(osys)
         _check(self.lib, self.lib.ort_set_system(self._h, C.byref(self._csys)), "ort_set_system")
+        self._stage_image_source(osys)
+
+    def _stage_image_source(self, osys: OpticalSystem) -> None:
+        if osys.settings.light_source != "image":
+            return
+        from .image_source import cdf, histogram, load_image
+        counts = histogram(load_image(osys.image_source_path), osys.settings.nphotons, osys.image_seed)
+        table = np.ascontiguousarray(cdf(counts), dtype=np.int64)
+        _check(self.lib, self.lib.ort_set_image_source(self._h, table.ctypes.data_as(C.POINTER(C.c_int64))),
+               "ort_set_image_source")
 
     def reset(self) -> None:
         _check(self.lib, self.lib.ort_reset(self._h), "ort_reset")

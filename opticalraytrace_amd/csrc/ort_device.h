@@ -245,7 +245,7 @@ template <class T> struct SystemT {
     SurfaceT<T> surfaces[2][ORT_MAX_SURFACES];
     T cos_theta_max, ring_r1, ring_r2, ring_lens_r2, ring_lens_z, ring_bottle_ra, ring_bottle_rb, ring_bottle_z;
     T bin_width, inv_bin_width, na_cos_min, twopi;
-    T spot_dphi, spot_dtheta, crs_sigma, crs_radius, crs_cy, crs_cz;
+    T spot_dphi, spot_dtheta, crs_sigma, crs_radius, crs_cy, crs_cz, img_lens_r2, img_lens_z;
     int32_t emitter[2];
 };
 template <class T> struct SysTypes { using Sys = SystemT<T>; using Surf = SurfaceT<T>; };
@@ -501,15 +501,54 @@ __device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws)
     r.dir = {sint * cosp, sint * sinp, cost};
 }
 
-// the phase's emitter (wave-uniform choice; src/main.f90:95-101, :132-142)
+// emit_image + emit, src/sourceMod.f90:303-361: ray `ray` (serial order) starts in the histogram
+// cell s with cdf[s] <= ray < cdf[s+1] (binary search in the 2 MB table, L2-resident), at a
+// uniform point of the 9.8 um cell, aimed at a uniform point of the lens disc.  Returns false
+// when the histogram is exhausted (the reference re-uses a stale ray there).
 template <class T, class Sys, class D>
-__device__ inline void emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray)
+__device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r, D &draws, uint64_t ray)
+{
+    const long long key = (long long)ray;
+    const bool have = cdf != nullptr && key < cdf[ORT_IMAGE_SOURCE_CELLS];
+    int lo = 0, hi = ORT_IMAGE_SOURCE_CELLS;                 // cdf[lo] <= key < cdf[hi]
+    if (cdf != nullptr) {
+        for (int it = 0; it < 18; ++it) {                    // 2^18 cells
+            const int mid = (lo + hi) >> 1;
+            const bool up = cdf[mid] <= key;
+            lo = up ? mid : lo;
+            hi = up ? hi : mid;
+        }
+    }
+    const int i = lo % 512 + 1, j = lo / 512 + 1;            // first, second index of imgin
+    const T dx = T(5000e-6) / T(512.);
+    T a = ((T)i - T(1.)) * dx, b = (T)i * dx;
+    T x = (a + draws.template next_as<T>() * (b - a)) - T(2500e-6);
+    a = ((T)j - T(1.)) * dx; b = (T)j * dx;
+    T y = (a + draws.template next_as<T>() * (b - a)) - T(2500e-6);
+    r.pos = {x, y, T(0.)};
+    T rr = T(0.) + draws.template next_as<T>() * (S.img_lens_r2 - T(0.));
+    T theta = draws.template next_as<T>() * S.twopi;
+    T st, ct;
+    sincos_t<T>(theta, &st, &ct);
+    T sq = ORT_SQRT(rr);
+    T ex = sq * ct - r.pos.x, ey = sq * st - r.pos.y, ez = S.img_lens_z - r.pos.z;
+    T dist = ORT_SQRT(ex * ex + ey * ey + ez * ez);
+    r.dir = vnormalise(div3(VecT<T>{ex, ey, ez}, dist));
+    return have;
+}
+
+// the phase's emitter (wave-uniform choice; src/main.f90:95-101, :132-142).  Returns false for
+// a ray the source cannot emit (image source exhausted).
+template <class T, class Sys, class D>
+__device__ inline bool emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf)
 {
     const int e = __builtin_amdgcn_readfirstlane(S.emitter[phase - 1]);
     if (e == ORT_EMIT_RING) emit_ring<T>(S, r, draws);
     else if (e == ORT_EMIT_POINT) emit_point<T>(S, r, draws);
     else if (e == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray);
-    else emit_crs<T>(S, r, draws);
+    else if (e == ORT_EMIT_CRS) emit_crs<T>(S, r, draws);
+    else return emit_image<T>(S, cdf, r, draws, ray);
+    return true;
 }
 
 // ----------------------------------------------------------------------------

@@ -52,6 +52,7 @@ struct TraceArgs {
     // debug outputs (any may be null)
     double *pos_dir_out, *emitted_out;
     int32_t *status, *bin_xy, *n_isect, *n_draws;
+    const long long *img_cdf;    // image-source table or null
     double *path;                // [n][ORT_MAX_PATH][3] or null (tracker)
     int32_t *npath;
 };
@@ -91,6 +92,7 @@ __device__ inline void stage_system(SystemT<float> &dst, const ort_system *src)
         dst.spot_dphi = (float)src->spot_dphi; dst.spot_dtheta = (float)src->spot_dtheta;
         dst.crs_sigma = (float)src->crs_sigma; dst.crs_radius = (float)src->crs_radius;
         dst.crs_cy = (float)src->crs_cy; dst.crs_cz = (float)src->crs_cz;
+        dst.img_lens_r2 = (float)src->img_lens_r2; dst.img_lens_z = (float)src->img_lens_z;
         dst.emitter[0] = src->emitter[0]; dst.emitter[1] = src->emitter[1];
     }
     __syncthreads();
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             Draws d;
             if (a.u) d.init_table(a.u + ic, (int64_t)n, a.nu, a.draw_base);
             else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
-            if (!have_in) emit<T>(S, a.phase, r, d, a.first_ray + ic);
+            if (!have_in && !emit<T>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             em = r;
             if (a.path) {
                 // tracker: the walk of `walk`, recording the pushes of src/stackMod.f90
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
         } else {
             KeyedDraws d;
             d.init_keyed(a.rng_base, a.first_ray + ic, have_in ? a.draw_base : 0);
-            if (!have_in) emit<T>(S, a.phase, r, d, a.first_ray + ic);
+            if (!have_in && !emit<T>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             walk<FILT, T>(S, surf, 0, ns, r, d, nis, st, xp, yp);
         }
         if (!act) continue;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 r.dir = {a.pos_dir_in[3 * n + ic], a.pos_dir_in[4 * n + ic], a.pos_dir_in[5 * n + ic]};
             } else {
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                emit<double>(S, a.phase, r, d, a.first_ray + ic);
+                if (!emit<double>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             }
             walk<FILT, double>(S, surf, 0, split, r, d, nis, st, xp, yp);
             const bool survive = act && st < 0;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
 
 __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int phase,
                                                       uint64_t first_ray, uint64_t n, uint64_t rng_base,
-                                                      double *pos_dir)
+                                                      double *pos_dir, const long long *img_cdf)
 {
     __shared__ ort_system S;
     stage_system(S, sys);
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int
         KeyedDraws d;
         d.init_keyed(rng_base, first_ray + i, 0);
         Ray r;
-        emit<double>(S, phase, r, d, first_ray + i);
+        emit<double>(S, phase, r, d, first_ray + i, img_cdf);
         pos_dir[0 * n + i] = r.pos.x; pos_dir[1 * n + i] = r.pos.y; pos_dir[2 * n + i] = r.pos.z;
         pos_dir[3 * n + i] = r.dir.x; pos_dir[4 * n + i] = r.dir.y; pos_dir[5 * n + i] = r.dir.z;
     }
@@ -428,7 +430,7 @@ int check_system(const ort_system *sys)
                 return fail(ORT_E_INVALID, "the image plane must be the last surface, and only the last");
         }
         if (sys->split[p] < 0 || sys->split[p] > n) return fail(ORT_E_INVALID, "split out of range");
-        if (sys->emitter[p] < ORT_EMIT_RING || sys->emitter[p] > ORT_EMIT_CRS) return fail(ORT_E_INVALID, "bad emitter");
+        if (sys->emitter[p] < ORT_EMIT_RING || sys->emitter[p] > ORT_EMIT_IMAGE) return fail(ORT_E_INVALID, "bad emitter");
     }
     return ORT_OK;
 }
@@ -442,6 +444,7 @@ struct ort_ctx {
     ort_system *d_sys;
     int32_t *d_image, *own_image;
     int32_t *d_replicas;         // kReplicas zeroed images (scratch between trace and fold)
+    long long *d_img_cdf;        // image-source table (ORT_IMAGE_SOURCE_CELLS + 1) or null
     unsigned long long *d_counters, *own_counters;
     bool timing;
     int variant;                 // bit mask, see ort_set_kernel_variant
@@ -516,7 +519,7 @@ int ort_destroy(ort_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (int k = 0; k < 3; ++k) { (void)hipEventDestroy(c->ev[k][0]); (void)hipEventDestroy(c->ev[k][1]); }
     for (int k = 0; k < kTimingRing; ++k) { (void)hipEventDestroy(c->ring[k][0]); (void)hipEventDestroy(c->ring[k][1]); }
-    (void)hipFree(c->d_sys); (void)hipFree(c->own_image); (void)hipFree(c->own_counters); (void)hipFree(c->d_replicas);
+    (void)hipFree(c->d_sys); (void)hipFree(c->own_image); (void)hipFree(c->own_counters); (void)hipFree(c->d_replicas); (void)hipFree(c->d_img_cdf);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ORT_OK;
@@ -530,6 +533,20 @@ int ort_set_system(ort_ctx *c, const ort_system *sys)
     HIP_TRY(hipSetDevice(c->device));
     // the copy source must stay valid until the copy has run: synchronise
     HIP_TRY(hipMemcpyAsync(c->d_sys, sys, sizeof(ort_system), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORT_OK;
+}
+
+int ort_set_image_source(ort_ctx *c, const int64_t *cdf)
+{
+    if (!c || !cdf) return fail(ORT_E_INVALID, "NULL argument");
+    if (cdf[0] != 0) return fail(ORT_E_INVALID, "cdf[0] must be 0");
+    for (int s = 0; s < ORT_IMAGE_SOURCE_CELLS; ++s)
+        if (cdf[s + 1] < cdf[s]) return fail(ORT_E_INVALID, "cdf must be non-decreasing");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)(ORT_IMAGE_SOURCE_CELLS + 1) * sizeof(long long);
+    if (!c->d_img_cdf) HIP_TRY(hipMalloc(&c->d_img_cdf, bytes));
+    HIP_TRY(hipMemcpyAsync(c->d_img_cdf, cdf, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ORT_OK;
 }
@@ -548,6 +565,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
     a.sys = c->d_sys; a.image = c->d_image; a.counters = c->d_counters;
     const bool use_rep = (c->variant & 4) == 0 && mode != MODE_DEBUG;
     a.replicas = use_rep ? c->d_replicas : nullptr;
+    a.img_cdf = c->d_img_cdf;
     if (a.n_rays == 0) return ORT_OK;
     int grid = grid_for(a.n_rays);
     const int slot = (int)(c->ring_count % kTimingRing);
@@ -620,7 +638,8 @@ int ort_emit(ort_ctx *c, int phase, uint64_t first_ray, uint64_t n_rays, uint64_
     HIP_TRY(hipSetDevice(c->device));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2][0], c->stream));
     hipLaunchKernelGGL(emit_kernel, dim3(grid_for(n_rays)), dim3(kBlock), 0, c->stream,
-                       c->d_sys, phase, first_ray, n_rays, stream_base(seed, phase), d_pos_dir);
+                       c->d_sys, phase, first_ray, n_rays, stream_base(seed, phase), d_pos_dir,
+                       (const long long *)c->d_img_cdf);
     HIP_TRY(hipGetLastError());
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[2][1], c->stream)); c->ev_valid[2] = true; }
     return ORT_OK;

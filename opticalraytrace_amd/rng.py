@@ -1,0 +1,31 @@
+"""ORT-RNG-v1 on the host (numpy), for the few draws the host itself consumes
+(the image-source histogram rounding, reference src/sourceMod.f90:396-407).
+
+    base = mix64(seed ^ (GOLDEN * phase));  z = base + GOLDEN * ((ray << 24) + k + 1)
+    u    = (mix64(z) >> 11) * 2^-53          (mix64 = SplitMix64 finaliser)
+
+Same definition as csrc/ort_device.h (device) — restated, not shared.
+"""
+import numpy as np
+
+GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+
+
+def mix64(z):
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = z ^ (z >> np.uint64(30))
+        z = z * np.uint64(0xBF58476D1CE4E5B9)
+        z = z ^ (z >> np.uint64(27))
+        z = z * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniforms(seed: int, phase: int, ray: int, draws) -> np.ndarray:
+    """u for draw indices `draws` (array) of key (seed, phase, ray)."""
+    k = np.asarray(draws, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        base = mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ (GOLDEN * np.uint64(phase)))
+        z = base + GOLDEN * ((np.uint64(ray) << np.uint64(24)) + k + np.uint64(1))
+    return (mix64(z) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53

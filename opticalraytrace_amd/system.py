@@ -85,18 +85,19 @@ class OpticalSystem:
     img_plane: float
     bottle_moved: bool = False
     crs_spot_size: float = 0.0       # spot_size after setupMod.f90:136
+    image_source_path: str = ""      # setupMod.f90:120-121 (read only for the `image` source)
+    image_seed: int = 123456789      # keys the histogram's rounding draws (image_source.py)
 
     # ------------------------------------------------------------------
     @classmethod
     def from_settings(cls, settings: Settings, res_dir: Optional[str] = None) -> "OpticalSystem":
         res_dir = res_dir or resource_dir()
         s = settings
-        if s.light_source not in ("point", "spot", "crs"):
-            # `image` needs the per-thread decrementing histogram of emit_image;
+        if s.light_source not in ("point", "spot", "crs", "image"):
             # `isors` aborts in the reference itself (`error stop "no intersection with bottle!"`,
             # src/sourceMod.f90:217) as soon as one ray reflects at the axicon (2.8 % per ray).
             raise ParamsError(f"light source {s.light_source!r} is not implemented on the "
-                              "MI355X path (point, spot and crs are)")
+                              "MI355X path (point, spot, crs and image are)")
         wl = s.wavelength
         bottle = GlassBottle.from_file(os.path.join(res_dir, s.bottle_file), wl)
         if bottle.scatters:
@@ -128,7 +129,7 @@ class OpticalSystem:
         r1 = r1 * r1
         img_plane = 2.0 * (a.fb + L3[0].fb) + a.thickness + L3[0].thickness     # main.f90:81
         return cls(s, bottle, L2, L3, cos_theta_max, distance, bessel, r1, r2, img_plane, moved,
-                   crs_spot_size)
+                   crs_spot_size, os.path.join(res_dir, s.image_source))
 
     # ------------------------------------------------------------------
     def surfaces(self, phase: int) -> List[Surface]:

@@ -53,10 +53,11 @@ class OrcSystem(C.Structure):
                                           "image_diameter", "iris_radius")] + \
                [(k, C.c_int32) for k in ("iris_before", "iris_after", "use_bottle", "source",
                                          "nphotons", "pad2")] + \
-               [(k, C.c_double) for k in ("isors_offset", "ring_width", "spot_size")]
+               [(k, C.c_double) for k in ("isors_offset", "ring_width", "spot_size")] + \
+               [("img_counts", C.POINTER(C.c_int32))]
 
 
-SOURCE_CODES = {"point": 0, "spot": 1, "crs": 2}
+SOURCE_CODES = {"point": 0, "spot": 1, "crs": 2, "image": 4}
 
 
 def build_oracle(force: bool = False) -> str:
@@ -124,7 +125,16 @@ class Oracle:
         L.orc_trace.restype = C.c_int
         L.orc_trace.argtypes = [C.POINTER(OrcSystem), C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
                                 _IP, C.POINTER(C.c_uint64), C.c_int]
+        L.orc_init_emit_image.argtypes = [_DP, C.c_int32, C.c_uint64, _IP]
         self.sys = fill_system(osys) if osys is not None else None
+        self._counts = None
+        if osys is not None and osys.settings.light_source == "image":
+            # the oracle builds its own histogram from the image file (its own init_emit_image)
+            img = np.fromfile(osys.image_source_path, np.float64)
+            assert img.size == 512 * 512
+            self._counts = np.zeros(512 * 512, np.int32)
+            L.orc_init_emit_image(_dp(img), osys.settings.nphotons, osys.image_seed, _ip(self._counts))
+            self.sys.img_counts = self._counts.ctypes.data_as(C.POINTER(C.c_int32))
 
     def uniform(self, seed, phase, ray, draw) -> float:
         return self.lib.orc_uniform(seed, phase, ray, draw)
@@ -164,7 +174,7 @@ def reference_available() -> bool:
 class Reference:
     """The reference's own Fortran path (oracle/_ref/libort_ref.so)."""
 
-    def __init__(self, settings, res_dir: str):
+    def __init__(self, settings, res_dir: str, image_seed: int = 123456789):
         self.lib = C.CDLL(REF_SO)
         L = self.lib
         L.ortref_init.restype = C.c_int
@@ -186,6 +196,12 @@ class Reference:
         L.ortref_set_source.argtypes = [C.c_int, C.c_int] + [C.c_double] * 5
         L.ortref_set_source(SOURCE_CODES[s.light_source], s.nphotons, s.isors_offset, s.crs_spot_size,
                             s.alpha, s.n_axicon, s.ring_width)
+        self.counts = None
+        if s.light_source == "image":
+            L.ortref_image_source.argtypes = [C.c_char_p, C.c_int, C.c_int64, _IP]
+            self.counts = np.zeros((512, 512), np.int32)      # Fortran imgin(512,512): [second][first] here
+            L.ortref_image_source(os.path.join(res_dir, s.image_source).encode(), s.nphotons,
+                                  image_seed, _ip(self.counts))
 
     def constants(self) -> np.ndarray:
         out = np.zeros(64)

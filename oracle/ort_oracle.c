@@ -426,6 +426,76 @@ static void emit_crs(const orc_system *S, orc_vec *pos, orc_vec *dir, draws_t *d
     *dir = v(sint * cosp, sint * sinp, cost);
 }
 
+/* init_emit_image, src/sourceMod.f90:363-408 */
+void orc_init_emit_image(const double *img, int32_t nphotons, uint64_t seed, int32_t *counts_scan)
+{
+    /* read(u) imgout fills imgout(a,b) = img[a + 512 b]; imgout = transpose(imgout) (:386) */
+    double tot = 0.;
+    for (int b = 0; b < 512; b++)                       /* sum(imgout): array element order */
+        for (int a = 0; a < 512; a++) tot += img[(size_t)b + 512u * (size_t)a];
+    draws_t d;
+    memset(&d, 0, sizeof d);
+    d.seed = seed; d.ray = 0; d.phase = 0; d.k = 0;
+    for (int i = 0; i < 512; i++) {                     /* do i = 1, 512 ; do j = 1, 512 (:396-397) */
+        for (int j = 0; j < 512; j++) {
+            double pix = img[(size_t)j + 512u * (size_t)i];        /* transposed imgout(i,j) */
+            double tmp = ((double)nphotons * pix) / tot;
+            double diff = tmp - (double)(int)tmp;
+            int c;
+            if (ran2(&d) < diff && diff > 0) c = (int)tmp + 1;
+            else c = (int)tmp;
+            /* imgin(i,j); emit_image scans `do i2 ; do j2 : img(j2,i2)`: first index inner */
+            counts_scan[(size_t)i + 512u * (size_t)j] = c;
+        }
+    }
+}
+
+/* emit, src/sourceMod.f90:325-361, for histogram cell (i = first index, j = second index), 1-based */
+static void emit_cell(const orc_plano *lens, int i, int j, orc_vec *pos, orc_vec *dir, draws_t *d)
+{
+    const double twopi = 2. * PI_F;
+    double dx = 5000e-6 / 512.;
+    double x = ranu(d, ((double)i - 1.) * dx, (double)i * dx) - 2500e-6;
+    double y = ranu(d, ((double)j - 1.) * dx, (double)j * dx) - 2500e-6;
+    *pos = v(x, y, 0.0);
+    double r = ranu(d, 0., lens->radius * lens->radius);
+    double theta = ran2(d) * twopi;
+    double st, ct;
+    sincos(theta, &st, &ct);                            /* as flang lowers this pair, cf. emit_ring */
+    orc_vec lp = v(sqrt(r) * ct, sqrt(r) * st, lens->fb);
+    double ex = lp.x - pos->x, ey = lp.y - pos->y, ez = lp.z - pos->z;
+    double dist = sqrt(ex * ex + ey * ey + ez * ez);
+    *dir = v((lp.x - pos->x) / dist, (lp.y - pos->y) / dist, (lp.z - pos->z) / dist);
+    *dir = vmagnitude(*dir);
+}
+
+/* emit_image, src/sourceMod.f90:303-323, for the ray with serial index `iray`: the first cell in
+ * scan order whose count is not yet used up = the cell whose cumulative count exceeds iray.
+ * Returns 0 when the histogram is exhausted (the reference then re-uses stale pos/dir). */
+static int emit_image_ray(const orc_system *S, const uint64_t *cdf, uint64_t iray, orc_vec *pos,
+                          orc_vec *dir, draws_t *d)
+{
+    /* cdf[s] = rays emitted by cells 0..s-1; find the last s with cdf[s] <= iray < cdf[s+1] */
+    if (iray >= cdf[512 * 512]) return 0;
+    int lo = 0, hi = 512 * 512;                         /* cdf[lo] <= iray < cdf[hi] */
+    while (hi - lo > 1) {
+        int mid = (lo + hi) / 2;
+        if (cdf[mid] <= iray) lo = mid; else hi = mid;
+    }
+    emit_cell(&S->L2[1], lo % 512 + 1, lo / 512 + 1, pos, dir, d);
+    return 1;
+}
+
+static uint64_t *build_cdf(const orc_system *S)
+{
+    if (!S->img_counts) return NULL;
+    uint64_t *cdf = malloc((512 * 512 + 1) * sizeof(uint64_t));
+    cdf[0] = 0;
+    for (int s = 0; s < 512 * 512; s++)
+        cdf[s + 1] = cdf[s] + (uint64_t)(S->img_counts[s] > 0 ? S->img_counts[s] : 0);
+    return cdf;
+}
+
 /* ring, src/sourceMod.f90:250-300 */
 static void emit_ring(const orc_system *S, orc_vec *pos, orc_vec *dir, draws_t *d)
 {
@@ -488,7 +558,8 @@ static int make_image(orc_vec dir, orc_vec pos, double diameter, int *xp_out, in
 /* ---------------------------------------------------------- loop body ---- */
 /* one iteration of src/main.f90:90-109 (phase 1) or :127-162 (phase 2) */
 static int one_ray(const orc_system *S, int phase, int have_in, orc_vec *pos, orc_vec *dir,
-                   draws_t *d, int *nis, int *xp, int *yp, orc_vec *epos, orc_vec *edir, uint64_t iray)
+                   draws_t *d, int *nis, int *xp, int *yp, orc_vec *epos, orc_vec *edir, uint64_t iray,
+                   const uint64_t *cdf)
 {
     int ph = phase - 1, rc;
     *nis = 0;
@@ -497,7 +568,9 @@ static int one_ray(const orc_system *S, int phase, int have_in, orc_vec *pos, or
             if (S->source == 2) emit_crs(S, pos, dir, d);
             else emit_ring(S, pos, dir, d);
         } else {                                            /* main.f90:132-142 */
-            if (S->source == 1) emit_spot(S->cosThetaMax, S->nphotons, (int)(iray + 1), pos, dir);
+            if (S->source == 4) {
+                if (!emit_image_ray(S, cdf, iray, pos, dir, d)) { *epos = *pos; *edir = *dir; return ORC_LOST_TELESCOPE; }
+            } else if (S->source == 1) emit_spot(S->cosThetaMax, S->nphotons, (int)(iray + 1), pos, dir);
             else emit_point(S->cosThetaMax, 0.0, pos, dir, d);
         }
     }
@@ -518,6 +591,7 @@ int orc_trace_rays(const orc_system *sys, int phase, int64_t n,
                    int32_t *bin_xy, int32_t *n_isect, int32_t *n_draws)
 {
     if (!sys || (phase != 1 && phase != 2) || n < 0) return -1;
+    uint64_t *cdf = build_cdf(sys);
     for (int64_t i = 0; i < n; i++) {
         draws_t d;
         memset(&d, 0, sizeof d);
@@ -530,7 +604,7 @@ int orc_trace_rays(const orc_system *sys, int phase, int64_t n,
         }
         int nis, xp = -9999, yp = -9999;
         int st = one_ray(sys, phase, pos_dir_in != NULL, &pos, &dir, &d, &nis, &xp, &yp, &ep, &ed,
-                         first_ray + (uint64_t)i);
+                         first_ray + (uint64_t)i, cdf);
         if (pos_dir_out) {
             pos_dir_out[0 * n + i] = pos.x; pos_dir_out[1 * n + i] = pos.y; pos_dir_out[2 * n + i] = pos.z;
             pos_dir_out[3 * n + i] = dir.x; pos_dir_out[4 * n + i] = dir.y; pos_dir_out[5 * n + i] = dir.z;
@@ -544,6 +618,7 @@ int orc_trace_rays(const orc_system *sys, int phase, int64_t n,
         if (n_isect) n_isect[i] = nis;
         if (n_draws) n_draws[i] = d.k;
     }
+    free(cdf);
     return 0;
 }
 
@@ -553,6 +628,7 @@ int orc_trace(const orc_system *sys, int phase, uint64_t first, uint64_t n, uint
     if (!sys || (phase != 1 && phase != 2) || !image || !counters) return -1;
     uint64_t lost = 0, isect = 0, binned = 0, help3 = 0;
     int32_t *layer = image + (size_t)(phase - 1) * 401 * 401;
+    uint64_t *cdf = build_cdf(sys);
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #else
@@ -565,7 +641,7 @@ int orc_trace(const orc_system *sys, int phase, uint64_t first, uint64_t n, uint
         d.seed = seed; d.ray = first + i; d.phase = phase; d.k = 0;
         orc_vec pos, dir, ep, ed;
         int nis, xp = 0, yp = 0;
-        int st = one_ray(sys, phase, 0, &pos, &dir, &d, &nis, &xp, &yp, &ep, &ed, first + i);
+        int st = one_ray(sys, phase, 0, &pos, &dir, &d, &nis, &xp, &yp, &ep, &ed, first + i, cdf);
         isect += (uint64_t)nis;
         if (st == ORC_LOST_BOTTLE || st == ORC_LOST_TELESCOPE || st == ORC_HELP3) lost++;
         if (st == ORC_HELP3) help3++;
@@ -575,6 +651,7 @@ int orc_trace(const orc_system *sys, int phase, uint64_t first, uint64_t n, uint
             layer[(xp + 200) + 401 * (yp + 200)]++;
         }
     }
+    free(cdf);
     counters[phase - 1] += lost;
     counters[2 + phase - 1] += isect;
     counters[4 + phase - 1] += binned;

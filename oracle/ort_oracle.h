@@ -57,6 +57,9 @@ typedef struct {
     int32_t source;
     int32_t nphotons, pad2;        /* create_spot needs the loop length (src/main.f90:138) */
     double isors_offset, ring_width, spot_size;   /* spot_size after src/setupMod.f90:136 */
+    /* image source (source == 4): imgin of src/sourceMod.f90:363-408 in the order emit_image scans
+     * it (:313-321: second index outer, first index inner), 512*512 counts; NULL otherwise */
+    const int32_t *img_counts;
 } orc_system;
 
 /* per-ray status (same numbering as include/ort.h, restated) */
@@ -76,6 +79,12 @@ double orc_sellmeier(double wave, double b1, double b2, double b3, double c1, do
 double orc_cauchy(double wave, double a, double b, double c);
 double orc_dispersion(double wave, double a, double b, double c);
 double orc_uniform(uint64_t seed, int32_t phase, uint64_t ray, int32_t draw);
+
+/* init_emit_image, src/sourceMod.f90:363-408, serial semantics (nphotonsLocal = nphotons):
+ * img is the 512x512 float64 file content as read (first index fastest); rounding draw k of
+ * the (i, j) loop is ORT-RNG-v1(seed, phase 0, ray 0, k).  counts_scan receives imgin in the
+ * order emit_image scans it. */
+void orc_init_emit_image(const double *img, int32_t nphotons, uint64_t seed, int32_t *counts_scan);
 
 /* Parity entry.  SoA [6][n] (x,y,z,dx,dy,dz).  pos_dir_in NULL => emit with the
  * phase's source.  u NULL => ORT-RNG-v1 keyed on (seed, phase, first_ray+i);

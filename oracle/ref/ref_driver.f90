@@ -17,7 +17,7 @@ module ortref_api
     use iso_fortran_env, only : int64
     use vector_class
     use lensMod
-    use source,      only : point, ring, create_spot, point_on_bottle, iSORS
+    use source,      only : point, ring, create_spot, point_on_bottle, iSORS, emit_image, init_emit_image
     use imageMod,    only : makeImage
     use opticsystem, only : telescope
     use stackMod,    only : stack
@@ -34,6 +34,9 @@ module ortref_api
     ! source type: 0 point, 1 spot, 2 crs, 3 isors (setupMod.f90:85-99)
     integer, save :: source_s = 0, nphotons_s = 100
     real,    save :: isors_offset_s = 0., ring_width_s = 0., spot_size_s = 0.
+    ! image source (source_s == 4): histogram built by init_emit_image, and the working copy
+    ! emit_image decrements (main.f90:88 firstprivate(imgin))
+    integer, save :: imgin_s(512, 512) = 0, imgwork_s(512, 512) = 0
 
     interface
         subroutine ortref_rng_table(u, stride, len, first_draw) bind(C, name="ortref_rng_table")
@@ -135,6 +138,27 @@ contains
         r1 = r1**2
     end subroutine ortref_set_source
 
+    ! image source: setupMod.f90:120-121 -> init_emit_image (sourceMod.f90:363-408) with the
+    ! 262144 rounding draws keyed as (seed, phase 0, ray 0, draw k); serial semantics
+    ! (nphotonsLocal = nphotons: one thread).  counts_out receives imgin(512,512).
+    subroutine ortref_image_source(path, nphotons, seed, counts_out) bind(C, name="ortref_image_source")
+        use omp_lib
+        character(kind=c_char), intent(IN) :: path(*)
+        integer(c_int), value :: nphotons
+        integer(c_int64_t), value :: seed
+        integer(c_int), intent(OUT) :: counts_out(512, 512)
+        integer :: nlocal, nthr
+        nthr = omp_get_max_threads()
+        call omp_set_num_threads(1)
+        call ortref_rng_key(seed, 0, 0_c_int64_t, 0)
+        call init_emit_image(cstr(path), imgin_s, nphotons, nlocal)
+        call omp_set_num_threads(nthr)
+        nphotons_s = nphotons
+        source_s = 4
+        imgwork_s = imgin_s
+        counts_out = imgin_s
+    end subroutine ortref_image_source
+
     subroutine ortref_constants(out) bind(C, name="ortref_constants")
         real(c_double), intent(OUT) :: out(64)
         out = 0.
@@ -192,7 +216,9 @@ contains
             call telescope(pos, dir, L2a, L3a, img_plane_1, cnt, tracker, 0, skip) ! main.f90:104
         else
             if (.not. have_in) then                                          ! main.f90:132-142
-                if (source_s == 1) then
+                if (source_s == 4) then
+                    call emit_image(imgwork_s, pos, dir, L2b)
+                elseif (source_s == 1) then
                     call create_spot(pos, dir, cosThetaMax, nphotons_s, iray)
                 elseif (source_s == 3) then
                     call point(pos, dir, cosThetaMax, bot%centre%z)
@@ -249,6 +275,7 @@ contains
 
         allocate(image(-200:200, -200:200, 2))
         image = 0
+        imgwork_s = imgin_s          ! the histogram walk restarts with every call (serial order)
         do i = 1, n
             call ortref_rng_table(c_loc(u(i, 1)), n, nu, draw_base)
             if (have_in /= 0) then

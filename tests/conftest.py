@@ -54,14 +54,44 @@ CONFIGS = {
     # SURVEY §8 f2 emitters: spot (create_spot, runner.py -s uses 100 rays) and crs (point_on_bottle)
     "small_spot": dict(bottle_file="clearBottle-small.params", light_source="spot", nphotons=100),
     "large_crs": dict(bottle_file="clearBottle-large.params", light_source="crs", crs_spot_size=1e-3),
+    # image source (emit_image): a synthetic integer-valued 512 x 512 source image, see source_image()
+    "large_image": dict(bottle_file="clearBottle-large.params", light_source="image",
+                        image_source="synthetic-source.dat", nphotons=60000),
 }
 
 
+def source_image():
+    """Deterministic stand-in for bpm.py's Bessel image (the reference ships none): an
+    integer-valued ring + core, so that sum(image) is exact in any summation order."""
+    import numpy as np
+    y, x = np.mgrid[0:512, 0:512]
+    r = np.hypot(x - 255.5, (y - 255.5) * 1.1)
+    img = np.floor(40.0 * np.exp(-((r - 90.0) / 14.0) ** 2) + 25.0 * np.exp(-(r / 9.0) ** 2)
+                   + ((x * 7 + y * 13) % 5 == 0))
+    return img.astype(np.float64)
+
+
+def res_dir_with_image(src_res: str) -> str:
+    """A res/ directory = the .params files of `src_res` + synthetic-source.dat (the image
+    source file lives next to the settings' other files, setupMod.f90:120-121)."""
+    import shutil
+    import tempfile
+    d = os.path.join(tempfile.gettempdir(), "ort_res_" + str(abs(hash(src_res)) % 100000) + "_" + str(os.getpid()))
+    if not os.path.exists(os.path.join(d, "synthetic-source.dat")):
+        os.makedirs(d, exist_ok=True)
+        for f in os.listdir(src_res):
+            if f.endswith(".params"):
+                shutil.copy(os.path.join(src_res, f), os.path.join(d, f))
+        source_image().tofile(os.path.join(d, "synthetic-source.dat"))
+    return d
+
+
 def make_system(name: str):
-    from opticalraytrace_amd.params import Settings
+    from opticalraytrace_amd.params import Settings, resource_dir
     from opticalraytrace_amd.system import OpticalSystem
     s = Settings(**{**dict(nphotons=100000, make_images=True), **CONFIGS[name]})
-    return s, OpticalSystem.from_settings(s)
+    res = res_dir_with_image(resource_dir()) if s.light_source == "image" else None
+    return s, OpticalSystem.from_settings(s, res)
 
 
 @pytest.fixture(scope="session", params=list(CONFIGS))

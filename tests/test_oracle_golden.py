@@ -41,6 +41,16 @@ def test_oracle_matches_golden_images(name):
     img = np.zeros((2, 401, 401), np.int32)
     cnt = np.zeros(8, np.uint64)
     for phase in (1, 2):
+        if settings.light_source == "image" and phase == 2:
+            # sequential source: the fixture holds the image of table-mode rays (make_golden.py)
+            n = settings.nphotons
+            ub = np.random.default_rng(int(g["img2_u_seed"])).random((10, n))
+            rb = orc.trace_rays(2, n, u=ub)
+            ok = rb["status"] == 0
+            np.add.at(img[1], (rb["bin_xy"][1][ok] + 200, rb["bin_xy"][0][ok] + 200), 1)
+            cnt[1] += np.uint64((rb["status"] >= 3).sum())
+            cnt[5] += np.uint64(ok.sum())
+            continue
         orc.trace(phase, 0, settings.nphotons, SEED, img, cnt)
     want = sparse_image(g["img1_idx"], g["img1_cnt"]) + sparse_image(g["img2_idx"], g["img2_cnt"])
     assert np.array_equal(img, want)
@@ -81,3 +91,18 @@ def test_oracle_partition_invariance():
     for lo, n in [(0, 1), (1, 9999), (10000, 20000)]:
         orc.trace(2, lo, n, SEED, b, cb)
     assert np.array_equal(a, b) and np.array_equal(ca, cb)
+
+
+def test_image_source_histogram_matches_reference():
+    """init_emit_image: the host's histogram (product code), the oracle's and the compiled
+    reference's imgin agree cell for cell (same keyed rounding draws)."""
+    from opticalraytrace_amd.image_source import cdf, histogram, load_image
+    g = load_golden("large_image")
+    settings, osys = make_system("large_image")
+    counts = histogram(load_image(osys.image_source_path), settings.nphotons, osys.image_seed)
+    orc = Oracle(osys)
+    assert np.array_equal(counts, orc._counts)
+    # the fixture holds the Fortran imgin(512,512) as the C-order view [second][first] = scan order
+    assert np.array_equal(counts.reshape(512, 512), g["imgin_counts"])
+    c = cdf(counts)
+    assert c[0] == 0 and c[-1] == counts.sum() and abs(int(c[-1]) - settings.nphotons) < 600

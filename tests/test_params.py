@@ -121,12 +121,11 @@ def test_settings_round_trip_in_runner_layout(tmp_path):
 
 
 def test_unsupported_sources_fail_loudly():
-    """`image` (decrementing histogram) and `isors` (the reference itself aborts, sourceMod.f90:217)
-    are refused instead of silently traced as something else; point / spot / crs are built."""
-    for src in ("image", "isors"):
-        with pytest.raises(ParamsError):
-            OpticalSystem.from_settings(Settings(light_source=src))
-    for src in ("point", "spot", "crs"):
+    """`isors` (the reference itself aborts, sourceMod.f90:217) is refused instead of silently
+    traced as something else; point / spot / crs / image are built."""
+    with pytest.raises(ParamsError):
+        OpticalSystem.from_settings(Settings(light_source="isors"))
+    for src in ("point", "spot", "crs", "image"):
         OpticalSystem.from_settings(Settings(light_source=src, nphotons=100))
 
 
