@@ -539,10 +539,18 @@ __device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r
 
 // the phase's emitter (wave-uniform choice; src/main.f90:95-101, :132-142).  Returns false for
 // a ray the source cannot emit (image source exhausted).
-template <class T, class Sys, class D>
+// ANYSRC = false instantiates only the two default emitters (ring for phase 1, point for phase
+// 2): the bulk kernels are compiled once for that case so that the rarely used emitters do not
+// cost registers (143 vs 121 VGPRs, i.e. 3 vs 4 waves per SIMD) on the path that is benchmarked.
+template <class T, bool ANYSRC, class Sys, class D>
 __device__ inline bool emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf)
 {
     const int e = __builtin_amdgcn_readfirstlane(S.emitter[phase - 1]);
+    if (!ANYSRC) {
+        if (phase == 1) emit_ring<T>(S, r, draws);
+        else emit_point<T>(S, r, draws);
+        return true;
+    }
     if (e == ORT_EMIT_RING) emit_ring<T>(S, r, draws);
     else if (e == ORT_EMIT_POINT) emit_point<T>(S, r, draws);
     else if (e == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray);

@@ -140,7 +140,7 @@ __device__ inline void walk(const Sys &S, const Surf *surf, int k0, int k1, RayT
 }
 
 // FILT: filtered predicates (ort_device.h); false = every predicate evaluated literally.
-template <int MODE, bool FILT, class T>
+template <int MODE, bool FILT, class T, bool ANYSRC>
 __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs a)
 {
     __shared__ typename SysTypes<T>::Sys S;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             Draws d;
             if (a.u) d.init_table(a.u + ic, (int64_t)n, a.nu, a.draw_base);
             else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
-            if (!have_in && !emit<T>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
+            if (!have_in && !emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             em = r;
             if (a.path) {
                 // tracker: the walk of `walk`, recording the pushes of src/stackMod.f90
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
         } else {
             KeyedDraws d;
             d.init_keyed(a.rng_base, a.first_ray + ic, have_in ? a.draw_base : 0);
-            if (!have_in && !emit<T>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
+            if (!have_in && !emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             walk<FILT, T>(S, surf, 0, ns, r, d, nis, st, xp, yp);
         }
         if (!act) continue;
@@ -263,7 +263,7 @@ __device__ inline int lane_prefix(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-template <int MODE, bool FILT>
+template <int MODE, bool FILT, bool ANYSRC>
 __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(TraceArgs a)
 {
     __shared__ ort_system S;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 r.dir = {a.pos_dir_in[3 * n + ic], a.pos_dir_in[4 * n + ic], a.pos_dir_in[5 * n + ic]};
             } else {
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                if (!emit<double>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
+                if (!emit<double, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             }
             walk<FILT, double>(S, surf, 0, split, r, d, nis, st, xp, yp);
             const bool survive = act && st < 0;
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int
         KeyedDraws d;
         d.init_keyed(rng_base, first_ray + i, 0);
         Ray r;
-        emit<double>(S, phase, r, d, first_ray + i, img_cdf);
+        emit<double, true>(S, phase, r, d, first_ray + i, img_cdf);
         pos_dir[0 * n + i] = r.pos.x; pos_dir[1 * n + i] = r.pos.y; pos_dir[2 * n + i] = r.pos.z;
         pos_dir[3 * n + i] = r.dir.x; pos_dir[4 * n + i] = r.dir.y; pos_dir[5 * n + i] = r.dir.z;
     }
@@ -449,6 +449,7 @@ struct ort_ctx {
     bool timing;
     int variant;                 // bit mask, see ort_set_kernel_variant
     int precision;               // 0 fp64 (reference arithmetic), 1 fp32 (study path)
+    int emitter[2];              // host copy of ort_system.emitter
     hipEvent_t ev[3][2];
     hipEvent_t ring[kTimingRing][2];   // fused-trace launches, most recent kTimingRing
     unsigned long long ring_count;
@@ -504,6 +505,7 @@ int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out)
         HIP_TRY(hipEventCreate(&c->ring[k][0]));
         HIP_TRY(hipEventCreate(&c->ring[k][1]));
     }
+    c->emitter[0] = sys->emitter[0]; c->emitter[1] = sys->emitter[1];
     HIP_TRY(hipMemcpyAsync(c->d_sys, sys, sizeof(ort_system), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_image, 0, ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, ORT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
@@ -531,6 +533,7 @@ int ort_set_system(ort_ctx *c, const ort_system *sys)
     int rc = check_system(sys);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    c->emitter[0] = sys->emitter[0]; c->emitter[1] = sys->emitter[1];
     // the copy source must stay valid until the copy has run: synchronise
     HIP_TRY(hipMemcpyAsync(c->d_sys, sys, sizeof(ort_system), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -580,19 +583,28 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
         if (blocks < (uint64_t)grid) grid = (int)blocks;
     }
 #define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
+    // the default emitters (ring / point) have their own, leaner instantiation
+    const bool anysrc = c->emitter[a.phase - 1] != (a.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT);
     if (c->precision == 1) {
         // fp32 study path (BASELINE configs[4]): lockstep kernel, literal predicates
-        if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, false, float>));
-        else if (mode == MODE_RESIDENT) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, float>));
-        else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, float>));
-    } else if (mode == MODE_FUSED) {
-        if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true>)); else ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, false>)); }
-        else { if (filt) ORT_LAUNCH((trace_kernel<MODE_FUSED, true, double>)); else ORT_LAUNCH((trace_kernel<MODE_FUSED, false, double>)); }
-    } else if (mode == MODE_RESIDENT) {
-        if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true>)); else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, false>)); }
-        else { if (filt) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true, double>)); else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, double>)); }
+        if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, false, float, true>));
+        else if (mode == MODE_RESIDENT) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, float, true>));
+        else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, float, true>));
+    } else if (mode == MODE_DEBUG) {
+        if (filt) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, double, true>));
+        else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, double, true>));
+    } else if (anysrc || !filt || !queued) {
+        // alternate emitters and the A/B variants share the generic instantiations
+        if (mode == MODE_FUSED) {
+            if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true>)); else ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, false, true>)); }
+            else { if (filt) ORT_LAUNCH((trace_kernel<MODE_FUSED, true, double, true>)); else ORT_LAUNCH((trace_kernel<MODE_FUSED, false, double, true>)); }
+        } else {
+            if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true>)); else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, false, true>)); }
+            else { if (filt) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true, double, true>)); else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, double, true>)); }
+        }
     } else {
-        if (filt) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, double>)); else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, double>));
+        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false>));
+        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false>));
     }
 #undef ORT_LAUNCH
     if (use_rep) hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, a.phase);
