@@ -19,6 +19,7 @@ ABI_VERSION = 1
 IMAGE_N = 401
 IMAGE_BINS = 2 * IMAGE_N * IMAGE_N
 NUM_COUNTERS = 8
+MAX_PATH = 6                 # ORT_MAX_PATH
 
 ST_BINNED, ST_NA_REJECT, ST_OFF_GRID, ST_LOST_BOTTLE, ST_LOST_TELESCOPE, ST_HELP3 = range(6)
 (C_LOST_RING, C_LOST_POINT, C_ISECT_RING, C_ISECT_POINT,
@@ -301,6 +302,15 @@ class Context:
         _check(self.lib, self.lib.ort_last_kernel_ms(self._h, kind, C.byref(ms)), "ort_last_kernel_ms")
         return ms.value
 
+    def trace_paths(self, phase: int, n: int, seed: int = 0, first_ray: int = 0):
+        """Tracker entry: (path [n][MAX_PATH][3], npath [n], status [n]) for keyed rays."""
+        path = np.zeros((n, MAX_PATH, 3))
+        npath = np.zeros(n, np.int32)
+        status = np.zeros(n, np.int32)
+        _check(self.lib, self.lib.ort_trace_paths(self._h, phase, n, seed, first_ray, _dptr(path),
+                                                  _iptr(npath), _iptr(status)), "ort_trace_paths")
+        return path, npath, status
+
     def trace_rays(self, phase: int, n: int, pos_dir_in: Optional[np.ndarray] = None,
                    u: Optional[np.ndarray] = None, draw_base: int = 0, seed: int = 0,
                    first_ray: int = 0):
@@ -321,22 +331,6 @@ class Context:
             _dptr(out["pos_dir"]), _dptr(out["emitted"]), _iptr(out["status"]),
             _iptr(out["bin_xy"]), _iptr(out["n_isect"]), _iptr(out["n_draws"])), "ort_trace_rays")
         return out
-
-
-MAX_PATH = 6
-
-
-def _trace_paths(self, phase: int, n: int, seed: int = 0, first_ray: int = 0):
-    """Tracker entry: (path [n][6][3], npath [n], status [n]) for keyed rays."""
-    path = np.zeros((n, MAX_PATH, 3))
-    npath = np.zeros(n, np.int32)
-    status = np.zeros(n, np.int32)
-    _check(self.lib, self.lib.ort_trace_paths(self._h, phase, n, seed, first_ray, _dptr(path),
-                                              _iptr(npath), _iptr(status)), "ort_trace_paths")
-    return path, npath, status
-
-
-Context.trace_paths = _trace_paths
 
 
 def device_count() -> int:

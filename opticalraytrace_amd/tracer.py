@@ -250,26 +250,19 @@ def run_settings(settings: Settings, res_dir: Optional[str] = None, data_dir: st
         tracer.set_system(system)
     try:
         res = tracer.run()
+        folder = os.path.join(data_dir, settings.data_folder)
+        os.makedirs(folder, exist_ok=True)                  # setupMod.f90:124-131
+        if settings.use_tracker:                            # main.f90:72-74, :121-124
+            write_tracker_files(tracer, system, folder)
     finally:
         if own:
             tracer.close()
-    folder = os.path.join(data_dir, settings.data_folder)
-    os.makedirs(folder, exist_ok=True)                      # setupMod.f90:124-131
     append_stats(folder, system, res)
     if verbose:                                             # main.f90:180-181
         print(f"Ring  transmitted:  {res.ring_transmitted:8.2f}%")
         print(f"Point transmitted:  {res.point_transmitted:8.2f}%")
-    if settings.use_tracker:                                # main.f90:72-74, :121-124
-        t = tracer if not own else None
-        if t is None:
-            t = RayTracer(system, device=device)
-        try:
-            write_tracker_files(t, system, folder)
-        finally:
-            if own:
-                t.close()
-    elif settings.make_images:                              # main.f90:183-185; tracker deselects images
-        write_images(res.image, os.path.join(folder, output_basename(system) + "_image"))   # (setupMod.f90:76-82)
+    if settings.make_images and not settings.use_tracker:   # main.f90:183-185; the tracker
+        write_images(res.image, os.path.join(folder, output_basename(system) + "_image"))   # deselects images (setupMod.f90:76-82)
     return res
 
 
