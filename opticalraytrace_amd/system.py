@@ -100,9 +100,6 @@ class OpticalSystem:
                               "MI355X path (point, spot, crs and image are)")
         wl = s.wavelength
         bottle = GlassBottle.from_file(os.path.join(res_dir, s.bottle_file), wl)
-        if bottle.scatters:
-            raise ParamsError("bottle with mua/mus != 0: in-bottle scattering "
-                              "(src/lens.f90:262-282) is outside this hot path (SURVEY §8 f3)")
         L2, L3 = [], []
         for w in (wl, POINT_WAVELENGTH):
             l2 = PlanoConvex.from_file(os.path.join(res_dir, s.L2_file), w)

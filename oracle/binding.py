@@ -44,7 +44,8 @@ class OrcDoublet(C.Structure):
 class OrcBottle(C.Structure):
     _fields_ = [(k, C.c_double) for k in
                 ("nbottle", "ncontents", "thickness", "radiusa", "radiusb")] + \
-               [("centre", OrcVec), ("ellipse", C.c_int32), ("pad", C.c_int32)]
+               [("centre", OrcVec), ("ellipse", C.c_int32), ("pad", C.c_int32)] + \
+               [(k, C.c_double) for k in ("mua_b", "mus_b", "mua_c", "mus_c")]
 
 
 class OrcSystem(C.Structure):
@@ -90,6 +91,7 @@ def fill_system(osys) -> OrcSystem:
         b.nbottle, b.ncontents, b.thickness, b.radiusa, b.radiusb
     B.centre = OrcVec(*b.centre)
     B.ellipse = 1 if b.ellipse else 0
+    B.mua_b, B.mus_b, B.mua_c, B.mus_c = b.mua_b, b.mus_b, b.mua_c, b.mus_c
     s = osys.settings
     S.cosThetaMax, S.r1, S.r2, S.img_plane = osys.cos_theta_max, osys.r1, osys.r2, osys.img_plane
     S.fibre_offset, S.image_diameter, S.iris_radius = s.fibre_offset, s.image_diameter, s.iris_size

@@ -70,6 +70,8 @@ static void rang(draws_t *d, double *x, double *y, double avg, double sigma)
     *y = avg + sigma * tmp;
 }
 
+static const double PI_F = 3.14159265358979323846;   /* 4.*atan(1.), src/constants.f90:5 */
+
 /* ------------------------------------------------------- vector_class ---- */
 static inline orc_vec v(double x, double y, double z) { orc_vec r = {x, y, z}; return r; }
 /* vec_minus_vec :48-57, vec_add_vec :84-93 */
@@ -234,7 +236,121 @@ double orc_dispersion(double wave, double a, double b, double c)
     return a - b * wave2 + (c / wave2);
 }
 
-/* bottle_forward_sub, src/lens.f90:230-350 (scatter branches inactive) */
+/* tauint, src/surfaces.f90:13-50: optical depth to the next event inside the cylinder.
+ * Returns 0 ok (dist = distance to the event, *tflag = 1 when that is the cylinder wall),
+ * 1 for the reference's `error stop "no intersection"` (:33-39). */
+static int tauint(orc_vec pos, orc_vec dir, double mua, double mus, orc_vec centre, double radius,
+                  double *dist, int *tflag, draws_t *d, int *nis)
+{
+    double mu_tot = mua + mus;
+    double tau = -log(ran2(d));
+    *tflag = 0;
+    int flag = intersect_cylinder(pos, dir, dist, centre, radius);
+    (*nis)++;
+    if (!flag) return 1;
+    double tauradius = *dist * mu_tot;
+    if (tau < tauradius) *dist = tau / mu_tot;
+    else *tflag = 1;
+    return 0;
+}
+
+/* stokes, src/stokes.f90:7-166: Henyey-Greenstein direction update (hgg /= 0 at both call
+ * sites, src/lens.f90:269,320; the isotropic branch :31-48 is restated for completeness) */
+static void stokes(orc_vec *dir, double hgg, draws_t *d)
+{
+    const double TWOPI = 2. * PI_F, PI = PI_F;
+    double nxp = dir->x, nyp = dir->y, nzp = dir->z;
+    double cost = dir->z;
+    double sint = sqrt(1. - cost * cost);
+    double g2 = hgg * hgg;
+    double phi = atan2(dir->y, dir->x);
+    double cosp, sinp;
+    if (hgg == 0.0) {
+        cost = 2. * ran2(d) - 1.;
+        sint = (1. - cost * cost);
+        if (sint <= 0.) sint = 0.; else sint = sqrt(sint);
+        phi = TWOPI * ran2(d);
+        sinp = sin(phi); cosp = cos(phi);
+        nxp = sint * cosp; nyp = sint * sinp; nzp = cost;
+    } else {
+        double costp = cost, sintp = sint, phip = phi;
+        double w = (1. - g2) / (1. - hgg + 2. * hgg * ran2(d));
+        double bmu = ((1. + g2) - w * w) / (2. * hgg);
+        double cosb2 = bmu * bmu;
+        if (fabs(bmu) > 1.) {
+            if (bmu > 1.) { bmu = 1.; cosb2 = 1.; }
+            else { bmu = -1.; cosb2 = 1.; }
+        }
+        double sinbt = sqrt(1. - cosb2);
+        double ri1 = TWOPI * ran2(d);
+        double cosi2 = 0., sini2 = 0., cosdph;
+        if (ri1 > PI) {
+            double ri3 = TWOPI - ri1;
+            double cosi3 = cos(ri3), sini3 = sin(ri3);
+            if (bmu == 1. || bmu == -1.) goto done;
+            cost = costp * bmu + sintp * sinbt * cosi3;
+            if (fabs(cost) < 1.) {
+                sint = fabs(sqrt(1. - cost * cost));
+                sini2 = sini3 * sintp / sint;
+                double bott = sint * sinbt;
+                cosi2 = costp / bott - cost * bmu / bott;
+            } else {
+                sint = 0.; sini2 = 0.;
+                if (cost >= 1.) cosi2 = -1.;
+                if (cost <= -1.) cosi2 = 1.;
+            }
+            cosdph = -cosi2 * cosi3 + sini2 * sini3 * bmu;
+            if (fabs(cosdph) > 1.) cosdph = (cosdph > 1.) ? 1. : -1.;
+            phi = phip + acos(cosdph);
+            if (phi > TWOPI) phi = phi - TWOPI;
+            if (phi < 0.) phi = phi + TWOPI;
+        } else {
+            double cosi1 = cos(ri1), sini1 = sin(ri1);
+            if (bmu == 1. || bmu == -1.) goto done;
+            cost = costp * bmu + sintp * sinbt * cosi1;
+            if (fabs(cost) < 1.) {
+                sint = fabs(sqrt(1. - cost * cost));
+                sini2 = sini1 * sintp / sint;
+                double bott = sint * sinbt;
+                cosi2 = costp / bott - cost * bmu / bott;
+            } else {
+                sint = 0.; sini2 = 0.;
+                if (cost >= 1.) cosi2 = -1.;
+                if (cost <= -1.) cosi2 = 1.;
+            }
+            cosdph = -cosi1 * cosi2 + sini1 * sini2 * bmu;
+            if (fabs(cosdph) > 1.) cosdph = (cosdph > 1.) ? 1. : -1.;
+            phi = phip - acos(cosdph);
+            if (phi > TWOPI) phi = phi - TWOPI;
+            if (phi < 0.) phi = phi + TWOPI;
+        }
+        cosp = cos(phi); sinp = sin(phi);
+        nxp = sint * cosp; nyp = sint * sinp; nzp = cost;
+    }
+done:
+    *dir = v(nxp, nyp, nzp);
+}
+
+/* the scattering walk of src/lens.f90:262-282 (contents) / :312-333 (wall): t enters as the
+ * distance to the wall and leaves as the distance of the last leg.  Returns 0 go on, 1 skip
+ * (absorbed, or heading back), 2 "no intersection". */
+static int scatter_walk(orc_vec *pos, orc_vec *dir, double *t, double mua, double mus, double hgg,
+                        orc_vec centre, double radius, draws_t *d, int *nis)
+{
+    int tflag = 0;
+    if (tauint(*pos, *dir, mua, mus, centre, radius, t, &tflag, d, nis)) return 2;
+    while (!tflag) {
+        *pos = vadd(*pos, vscale(*dir, *t));
+        if (ran2(d) < mus / (mus + mua)) stokes(dir, hgg, d);
+        else return 1;                                             /* absorbed */
+        if (tauint(*pos, *dir, mua, mus, centre, radius, t, &tflag, d, nis)) return 2;
+        if (sqrt(pos->x * pos->x + pos->z * pos->z) >= radius) break;   /* sic: x and z (:276, :327) */
+    }
+    if (dir->z < 0.) return 1;
+    return 0;
+}
+
+/* bottle_forward_sub, src/lens.f90:230-350.  Returns 0 ok, 1 skip, 2 "no intersection". */
 static int bottle_forward(const orc_bottle *B, orc_vec *pos, orc_vec *dir, draws_t *d, int *nis)
 {
     double t;
@@ -251,6 +367,11 @@ static int bottle_forward(const orc_bottle *B, orc_vec *pos, orc_vec *dir, draws
     (*nis)++;
     if (!flag) return 1;
 
+    if (B->mua_c + B->mus_c != 0.0) {                                   /* scatter_c, :218-219, :262-282 */
+        int rc = scatter_walk(pos, dir, &t, B->mua_c, B->mus_c, .65, B->centre,
+                              B->radiusa - B->thickness, d, nis);
+        if (rc) return rc;
+    }
     *pos = vadd(*pos, vscale(*dir, t));
     orig = *pos;
     orig.x = B->centre.x;
@@ -264,6 +385,10 @@ static int bottle_forward(const orc_bottle *B, orc_vec *pos, orc_vec *dir, draws
     (*nis)++;
     if (!flag) return 1;
 
+    if (B->mua_b + B->mus_b != 0.0) {                                   /* scatter_b, :312-333 */
+        int rc = scatter_walk(pos, dir, &t, B->mua_b, B->mus_b, 0.9, B->centre, B->radiusa, d, nis);
+        if (rc) return rc;
+    }
     *pos = vadd(*pos, vscale(*dir, t));
     orig = *pos;
     orig.x = B->centre.x;
@@ -374,7 +499,6 @@ static int telescope(const orc_system *S, int ph, orc_vec *pos, orc_vec *dir, dr
 }
 
 /* ------------------------------------------------------------ sources ---- */
-static const double PI_F = 3.14159265358979323846;   /* 4.*atan(1.), src/constants.f90:5 */
 
 /* point, src/sourceMod.f90:12-47 (offset absent at the call site main.f90:136, bottle%centre%z
  * at :140 for the isors source) */
@@ -576,7 +700,9 @@ static int one_ray(const orc_system *S, int phase, int have_in, orc_vec *pos, or
     }
     *epos = *pos; *edir = *dir;
     if (phase == 2 && S->use_bottle) {
-        if (bottle_forward(&S->bottle, pos, dir, d, nis)) return ORC_LOST_BOTTLE;
+        rc = bottle_forward(&S->bottle, pos, dir, d, nis);
+        if (rc == 2) return ORC_NO_INTERSECTION;
+        if (rc) return ORC_LOST_BOTTLE;
     }
     rc = telescope(S, ph, pos, dir, d, nis);
     if (rc == 1) return ORC_LOST_TELESCOPE;
@@ -643,7 +769,7 @@ int orc_trace(const orc_system *sys, int phase, uint64_t first, uint64_t n, uint
         int nis, xp = 0, yp = 0;
         int st = one_ray(sys, phase, 0, &pos, &dir, &d, &nis, &xp, &yp, &ep, &ed, first + i, cdf);
         isect += (uint64_t)nis;
-        if (st == ORC_LOST_BOTTLE || st == ORC_LOST_TELESCOPE || st == ORC_HELP3) lost++;
+        if (st == ORC_LOST_BOTTLE || st == ORC_LOST_TELESCOPE || st == ORC_HELP3 || st == ORC_NO_INTERSECTION) lost++;
         if (st == ORC_HELP3) help3++;
         if (st == ORC_BINNED) {
             binned++;

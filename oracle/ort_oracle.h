@@ -34,12 +34,13 @@ typedef struct {
     orc_vec centre1, centre2, centre3;
 } orc_doublet;
 
-/* type glass_bottle (src/lens.f90:40-48); scattering members omitted: every
- * shipped bottle has mua = mus = 0 (src/lens.f90:195-219) */
+/* type glass_bottle (src/lens.f90:40-48).  Every shipped bottle has mua = mus = 0
+ * (src/lens.f90:195-219); the scattering members drive src/lens.f90:262-282, :312-333. */
 typedef struct {
     double nbottle, ncontents, thickness, radiusa, radiusb;
     orc_vec centre;
     int32_t ellipse, pad;
+    double mua_b, mus_b, mua_c, mus_c;   /* wall (_b) and contents (_c) absorption / scattering [1/m] */
 } orc_bottle;
 
 /* run state of src/main.f90 + module setup globals read by telescope
@@ -69,7 +70,8 @@ enum {
     ORC_OFF_GRID = 2,        /* reached the image plane, |bin| > 200 or pos > 1000 */
     ORC_LOST_BOTTLE = 3,     /* skip in bottle%forward (counted, phase 2) */
     ORC_LOST_TELESCOPE = 4,  /* skip in telescope (counted) */
-    ORC_HELP3 = 5            /* doublet face 3 missed: reference aborts (lens.f90:617) */
+    ORC_HELP3 = 5,           /* doublet face 3 missed: reference aborts (lens.f90:617) */
+    ORC_NO_INTERSECTION = 6  /* tauint found no cylinder crossing: reference aborts (surfaces.f90:38) */
 };
 
 /* counters[8]: 0 lost ring (rcount), 1 lost point (pcount), 2 intersections ring,
