@@ -62,9 +62,10 @@ extern "C" {
 #define ORT_F_BOTTLE 4u          /* losses at this surface are bottle losses (src/main.f90:150-151) */
 #define ORT_F_TRACK 8u           /* the ray-path tracker pushes the position after this surface
                                     (src/main.f90:147, src/optics_system.f90:29,39,50) */
+#define ORT_F_SCATTER 16u        /* random walk in the medium before this surface (tauint + stokes) */
 #define ORT_MAX_PATH 6           /* emission + bottle + L1 + L2 + image plane (+ spare) */
 
-/* One optical surface as staged into LDS (80 B). */
+/* One optical surface as staged into LDS (112 B). */
 typedef struct ort_surface {
     double cx, cy, cz;   /* centre (sphere / cylinder / ellipse) or plane z in cz */
     double radius;       /* sphere / cylinder radius; ellipse semi-axis along z */
@@ -72,6 +73,9 @@ typedef struct ort_surface {
     double n1, n2;       /* refractive index before / after the surface */
     double eta;          /* n1 / n2, rounded once on the host (IEEE division: same bits as on the device) */
     double aperture;     /* reject when sqrt(x^2+y^2) > aperture after the move; < 0: no test */
+    /* medium BEFORE the surface when ORT_F_SCATTER (bottle contents / wall, src/lens.f90:262-282,
+     * :312-333): absorption, scattering [1/m], Henyey-Greenstein g, cylinder radius tauint uses */
+    double mua, mus, hgg, scat_radius;
     int32_t kind;        /* ORT_SURF_* */
     uint32_t flags;      /* ORT_F_* */
 } ort_surface;
@@ -119,6 +123,7 @@ typedef struct ort_system {
 #define ORT_ST_LOST_BOTTLE 3
 #define ORT_ST_LOST_TELESCOPE 4
 #define ORT_ST_HELP3 5
+#define ORT_ST_NO_INTERSECTION 6  /* tauint found no wall: reference aborts (src/surfaces.f90:33-39); counted as lost */
 
 /* counters[ORT_NUM_COUNTERS] */
 #define ORT_C_LOST_RING 0     /* rcount, src/main.f90:40, optics_system.f90:32,42 */
@@ -140,7 +145,8 @@ int ort_device_count(int *count);
 /* Context = one device's image accumulator + counters + staged system.
  * Replaces the allocation and zeroing in src/main.f90:35-41 and the lens
  * objects handed to the loop (src/main.f90:43). `stream` is a hipStream_t
- * passed as void* (NULL = the context creates its own). */
+ * passed as void*; NULL = the device's default (null) stream.  Every launch, copy and
+ * memset of the context is issued on that stream, in call order. */
 int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out);
 int ort_destroy(ort_ctx *ctx);
 int ort_set_system(ort_ctx *ctx, const ort_system *sys);

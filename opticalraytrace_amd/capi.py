@@ -21,7 +21,7 @@ IMAGE_BINS = 2 * IMAGE_N * IMAGE_N
 NUM_COUNTERS = 8
 MAX_PATH = 6                 # ORT_MAX_PATH
 
-ST_BINNED, ST_NA_REJECT, ST_OFF_GRID, ST_LOST_BOTTLE, ST_LOST_TELESCOPE, ST_HELP3 = range(6)
+ST_BINNED, ST_NA_REJECT, ST_OFF_GRID, ST_LOST_BOTTLE, ST_LOST_TELESCOPE, ST_HELP3, ST_NO_INTERSECTION = range(7)
 (C_LOST_RING, C_LOST_POINT, C_ISECT_RING, C_ISECT_POINT,
  C_BINNED_RING, C_BINNED_POINT, C_HELP3_RING, C_HELP3_POINT) = range(8)
 
@@ -38,7 +38,9 @@ class OrtSurface(C.Structure):
     _fields_ = [("cx", C.c_double), ("cy", C.c_double), ("cz", C.c_double),
                 ("radius", C.c_double), ("radius_b", C.c_double),
                 ("n1", C.c_double), ("n2", C.c_double), ("eta", C.c_double),
-                ("aperture", C.c_double), ("kind", C.c_int32), ("flags", C.c_uint32)]
+                ("aperture", C.c_double), ("mua", C.c_double), ("mus", C.c_double),
+                ("hgg", C.c_double), ("scat_radius", C.c_double),
+                ("kind", C.c_int32), ("flags", C.c_uint32)]
 
 
 class OrtSystem(C.Structure):
@@ -71,6 +73,7 @@ def pack_system(osys: OpticalSystem) -> OrtSystem:
             d.n1, d.n2 = s.n1, s.n2
             d.eta = s.n1 / s.n2               # surfaces.f90:279,352: n1/n2 (IEEE division)
             d.aperture = s.aperture
+            d.mua, d.mus, d.hgg, d.scat_radius = s.mua, s.mus, s.hgg, s.scat_radius
             d.kind, d.flags = s.kind, s.flags
     l2 = osys.L2[0]
     b = osys.bottle

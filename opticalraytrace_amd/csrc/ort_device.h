@@ -236,7 +236,7 @@ __device__ inline double rsq_approx(double s)
 // The staged system as the kernels see it.  For T = double this is ort_system itself (the
 // device copy is staged byte for byte); for T = float a converted copy is staged.
 template <class T> struct SurfaceT {
-    T cx, cy, cz, radius, radius_b, n1, n2, eta, aperture;
+    T cx, cy, cz, radius, radius_b, n1, n2, eta, aperture, mua, mus, hgg, scat_radius;
     int32_t kind;
     uint32_t flags;
 };
@@ -401,7 +401,115 @@ __device__ inline bool outside_aperture(T x, T y, T A, bool live)
     return out;
 }
 
+// ----------------------------------------------------------------------------
+// In-bottle scattering: tauint (src/surfaces.f90:13-50), the
+// Henyey-Greenstein direction update `stokes` (src/stokes.f90:7-166, hgg /= 0 at both call
+// sites) and the random walk of src/lens.f90:262-282 / :312-333 — all predicated: `on` marks
+// the lanes still walking; every draw is consumed only by those lanes.
+// ----------------------------------------------------------------------------
 template <class T> __device__ inline void sincos_t(T x, T *s, T *c);
+
+// one leg: optical depth tau = -log(u) against the distance to the cylinder wall.
+// ok = false is the reference's `error stop "no intersection"`.
+template <bool FILT, class T, class D>
+__device__ inline void tauint(const RayT<T> &r, T mua, T mus, T cy, T cz, T radius, bool on, D &draws,
+                              T &dist, bool &at_wall, bool &ok, int &nis)
+{
+    const T mu_tot = mua + mus;
+    const T u = draws.template peek_as<T>();
+    draws.advance(on);
+    const T tau = -log(u);
+    T d;
+    bool hit;
+    intersect_quadric<FILT, T>(r, T(0.), cy, cz, radius, true, on, d, hit);
+    nis += on ? 1 : 0;
+    const T tauradius = d * mu_tot;
+    const bool inside = tau < tauradius;
+    dist = inside ? tau / mu_tot : d;
+    at_wall = !inside;
+    ok = hit;
+}
+
+template <class T, class D>
+__device__ inline void stokes_hg(VecT<T> &dir, T hgg, T twopi, bool on, D &draws)
+{
+    const T pi = twopi * T(0.5);
+    const T costp = dir.z;
+    const T sintp = ORT_SQRT(T(1.) - costp * costp);
+    const T g2 = hgg * hgg;
+    const T phip = atan2(dir.y, dir.x);
+    const T u1 = draws.template peek_as<T>();
+    draws.advance(on);
+    const T w = (T(1.) - g2) / (T(1.) - hgg + T(2.) * hgg * u1);
+    T bmu = ((T(1.) + g2) - w * w) / (T(2.) * hgg);
+    T cosb2 = bmu * bmu;
+    const bool clamp = fabs(bmu) > T(1.);
+    bmu = clamp ? (bmu > T(1.) ? T(1.) : T(-1.)) : bmu;
+    cosb2 = clamp ? T(1.) : cosb2;
+    const T sinbt = ORT_SQRT(T(1.) - cosb2);
+    const T u2 = draws.template peek_as<T>();
+    draws.advance(on);
+    const T ri1 = twopi * u2;
+    const bool upper = ri1 > pi;                         // :75 — the two branches mirror each other
+    const T ang = upper ? twopi - ri1 : ri1;
+    T sa, ca;
+    sincos_t<T>(ang, &sa, &ca);
+    const bool keep = (bmu == T(1.)) || (bmu == T(-1.));   // goto 100: direction unchanged
+    T cost = costp * bmu + sintp * sinbt * ca;
+    const bool mid = fabs(cost) < T(1.);
+    const T sint_m = fabs(ORT_SQRT(T(1.) - cost * cost));
+    const T bott = sint_m * sinbt;
+    const T sint = mid ? sint_m : T(0.);
+    const T sini2 = mid ? sa * sintp / sint_m : T(0.);
+    const T cosi2 = mid ? costp / bott - cost * bmu / bott : (cost >= T(1.) ? T(-1.) : T(1.));
+    T cosdph = -cosi2 * ca + sini2 * sa * bmu;
+    cosdph = fabs(cosdph) > T(1.) ? (cosdph > T(1.) ? T(1.) : T(-1.)) : cosdph;
+    const T ac = acos(cosdph);
+    T phi = upper ? phip + ac : phip - ac;
+    phi = phi > twopi ? phi - twopi : phi;
+    phi = phi < T(0.) ? phi + twopi : phi;
+    T sp, cp;
+    sincos_t<T>(phi, &sp, &cp);
+    const VecT<T> nd = {sint * cp, sint * sp, cost};
+    dir = vselect(on && !keep, nd, dir);
+}
+
+// walk of lens.f90:262-282 / :312-333.  `t` enters as the distance to the wall (from the
+// surface's own intersection) and leaves as the length of the last leg; lanes that end here get
+// `ended` = ORT_ST_LOST_BOTTLE (absorbed / heading back) or ORT_ST_NO_INTERSECTION.
+template <bool FILT, class T, class Surf, class D>
+__device__ inline void scatter_walk(const Surf &s, T twopi, RayT<T> &r, T &t, bool on, D &draws, int &nis,
+                                    int &ended)
+{
+    T dist;
+    bool at_wall, ok;
+    tauint<FILT, T>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, on, draws, dist, at_wall, ok, nis);
+    ended = (on && !ok) ? ORT_ST_NO_INTERSECTION : ended;
+    t = on ? dist : t;
+    bool alive = on && ok;                               // not yet ended inside the walk
+    bool walking = alive && !at_wall;
+    const T albedo = s.mus / (s.mus + s.mua);
+    while (wave_any(walking)) {
+        r.pos = vselect(walking, vadd(r.pos, vscale(r.dir, t)), r.pos);
+        const T u = draws.template peek_as<T>();
+        draws.advance(walking);
+        const bool absorbed = walking && !(u < albedo);
+        ended = absorbed ? ORT_ST_LOST_BOTTLE : ended;
+        alive = alive && !absorbed;
+        walking = walking && !absorbed;
+        stokes_hg<T>(r.dir, s.hgg, twopi, walking, draws);
+        tauint<FILT, T>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, walking, draws, dist, at_wall, ok, nis);
+        const bool lostw = walking && !ok;
+        ended = lostw ? ORT_ST_NO_INTERSECTION : ended;
+        alive = alive && !lostw;
+        t = (walking && ok) ? dist : t;
+        const bool out = ORT_SQRT(r.pos.x * r.pos.x + r.pos.z * r.pos.z) >= s.scat_radius;   // sic: x, z
+        walking = walking && ok && !out && !at_wall;
+    }
+    const bool back = alive && (r.dir.z < T(0.));
+    ended = back ? ORT_ST_LOST_BOTTLE : ended;
+}
+
 template <> __device__ inline void sincos_t<double>(double x, double *s, double *c) { sincos(x, s, c); }
 template <> __device__ inline void sincos_t<float>(float x, float *s, float *c) { sincosf(x, s, c); }
 
@@ -618,7 +726,9 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
 //   bottle   src/lens.f90:230-350      plano   :425-481     doublet :531-645
 //   image    src/optics_system.f90:48-49 + imageMod
 // ----------------------------------------------------------------------------
-template <bool FILT, class T, class Sys, class Surf, class D>
+// EXT = false compiles the step without the in-bottle scattering walk (the lean instantiation
+// of the bulk kernels; the host picks it when no surface carries ORT_F_SCATTER).
+template <bool FILT, class T, bool EXT, class Sys, class Surf, class D>
 __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &draws,
                                     int &nis, int &st, int &xp, int &yp)
 {
@@ -637,6 +747,11 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
         const bool cyl = kind != ORT_SURF_SPHERE;
         if (kind == ORT_SURF_ELLIPSE) intersect_ellipse<FILT, T>(r, s.cy, s.cz, s.radius, s.radius_b, live, t, hit);
         else intersect_quadric<FILT, T>(r, s.cx, s.cy, s.cz, s.radius, cyl, live, t, hit);
+        int walk_end = -1;
+        if (EXT && (flags & ORT_F_SCATTER)) {               // wave-uniform
+            scatter_walk<FILT, T>(s, S.twopi, r, t, live && hit, draws, nis, walk_end);
+            hit = hit && walk_end < 0;
+        }
         const VecT<T> moved = vadd(r.pos, vscale(r.dir, t));
         r.pos = vselect(live && hit, moved, r.pos);
         bool out = false;
@@ -644,6 +759,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
         // normal = centre - pos, with orig%x = centre%x for the bottle (lens.f90:288-290)
         N = vnormalise(VecT<T>{cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z});
         ended = !hit ? ((flags & ORT_F_MISS_IS_HELP3) ? ORT_ST_HELP3 : lost) : (out ? lost : -1);
+        ended = walk_end >= 0 ? walk_end : ended;
         proceed = live && hit && !out;
     } else {
         // plane kinds: d = (z_plane - pos%z) / dir%z ; pos = pos + dir*d

@@ -77,6 +77,7 @@ __device__ inline void stage_system(SystemT<float> &dst, const ort_system *src)
         b.cx = (float)a.cx; b.cy = (float)a.cy; b.cz = (float)a.cz; b.radius = (float)a.radius;
         b.radius_b = (float)a.radius_b; b.n1 = (float)a.n1; b.n2 = (float)a.n2; b.eta = (float)a.eta;
         b.aperture = (float)a.aperture; b.kind = a.kind; b.flags = a.flags;
+        b.mua = (float)a.mua; b.mus = (float)a.mus; b.hgg = (float)a.hgg; b.scat_radius = (float)a.scat_radius;
     }
     if (threadIdx.x == 0) {
         dst.n_surfaces[0] = src->n_surfaces[0]; dst.n_surfaces[1] = src->n_surfaces[1];
@@ -129,13 +130,13 @@ __global__ __launch_bounds__(256) void fold_kernel(int32_t *image, int32_t *repl
 
 // One lockstep pass of a wave over surfaces [k0, k1): every lane steps with its `st`
 // predicate; the loop leaves as soon as no lane of the wave is alive (uniform branch).
-template <bool FILT, class T, class Sys, class Surf, class D>
+template <bool FILT, class T, bool EXT, class Sys, class Surf, class D>
 __device__ inline void walk(const Sys &S, const Surf *surf, int k0, int k1, RayT<T> &r, D &draws,
                             int &nis, int &st, int &xp, int &yp)
 {
     for (int k = k0; k < k1; ++k) {
         if (!wave_any(st < 0)) break;
-        surface_step<FILT, T>(S, surf[k], r, draws, nis, st, xp, yp);
+        surface_step<FILT, T, EXT>(S, surf[k], r, draws, nis, st, xp, yp);
     }
 }
 
@@ -191,20 +192,20 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
                 for (int k = 0; k < ns; ++k) {
                     if (!wave_any(st < 0)) break;
                     const bool was_live = st < 0;
-                    surface_step<FILT, T>(S, surf[k], r, d, nis, st, xp, yp);
+                    surface_step<FILT, T, true>(S, surf[k], r, d, nis, st, xp, yp);
                     const bool track = (__builtin_amdgcn_readfirstlane((int)surf[k].flags) & ORT_F_TRACK) != 0;
                     push(was_live && (st >= 0 || track));   // where it ended, or a tracked surface passed alive
                 }
                 if (act) a.npath[ic] = np;
             } else {
-                walk<FILT, T>(S, surf, 0, ns, r, d, nis, st, xp, yp);
+                walk<FILT, T, ANYSRC>(S, surf, 0, ns, r, d, nis, st, xp, yp);
             }
             kdraws = d.k;
         } else {
             KeyedDraws d;
             d.init_keyed(a.rng_base, a.first_ray + ic, have_in ? a.draw_base : 0);
             if (!have_in && !emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
-            walk<FILT, T>(S, surf, 0, ns, r, d, nis, st, xp, yp);
+            walk<FILT, T, ANYSRC>(S, surf, 0, ns, r, d, nis, st, xp, yp);
         }
         if (!act) continue;
         if (MODE == MODE_DEBUG) {
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 d.z = (uint64_t)__double_as_longlong(q[6][slot]);
             }
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
-            walk<FILT, double>(S, surf, split, ns, r, d, nis, st, xp, yp);
+            walk<FILT, double, ANYSRC>(S, surf, split, ns, r, d, nis, st, xp, yp);
             if (act) finish(st, nis, xp, yp);
             __builtin_amdgcn_wave_barrier();
         } else if (have_new) {
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
                 if (!emit<double, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             }
-            walk<FILT, double>(S, surf, 0, split, r, d, nis, st, xp, yp);
+            walk<FILT, double, ANYSRC>(S, surf, 0, split, r, d, nis, st, xp, yp);
             const bool survive = act && st < 0;
             const unsigned long long mask = __ballot(survive);
             if (survive) {
@@ -450,11 +451,21 @@ struct ort_ctx {
     int variant;                 // bit mask, see ort_set_kernel_variant
     int precision;               // 0 fp64 (reference arithmetic), 1 fp32 (study path)
     int emitter[2];              // host copy of ort_system.emitter
+    bool scatter;                // some surface carries ORT_F_SCATTER
     hipEvent_t ev[3][2];
     hipEvent_t ring[kTimingRing][2];   // fused-trace launches, most recent kTimingRing
     unsigned long long ring_count;
     bool ev_valid[3];
 };
+
+static void note_system(ort_ctx *c, const ort_system *sys)
+{
+    c->emitter[0] = sys->emitter[0]; c->emitter[1] = sys->emitter[1];
+    c->scatter = false;
+    for (int p = 0; p < 2; ++p)
+        for (int k = 0; k < sys->n_surfaces[p]; ++k)
+            if (sys->surfaces[p][k].flags & ORT_F_SCATTER) c->scatter = true;
+}
 
 extern "C" {
 
@@ -488,8 +499,10 @@ int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out)
     memset(c, 0, sizeof *c);
     c->device = device;
     c->variant = 1;
-    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
-    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    // NULL = the device's default (null) stream, like every HIP API: work is then ordered with
+    // whatever else the caller runs there (torch's default stream, RCCL's stream dependencies)
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
     HIP_TRY(hipMalloc(&c->d_sys, sizeof(ort_system)));
     HIP_TRY(hipMalloc(&c->own_image, ORT_IMAGE_BINS * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->own_counters, ORT_NUM_COUNTERS * sizeof(unsigned long long)));
@@ -505,7 +518,7 @@ int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out)
         HIP_TRY(hipEventCreate(&c->ring[k][0]));
         HIP_TRY(hipEventCreate(&c->ring[k][1]));
     }
-    c->emitter[0] = sys->emitter[0]; c->emitter[1] = sys->emitter[1];
+    note_system(c, sys);
     HIP_TRY(hipMemcpyAsync(c->d_sys, sys, sizeof(ort_system), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_image, 0, ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, ORT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
@@ -533,7 +546,7 @@ int ort_set_system(ort_ctx *c, const ort_system *sys)
     int rc = check_system(sys);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    c->emitter[0] = sys->emitter[0]; c->emitter[1] = sys->emitter[1];
+    note_system(c, sys);
     // the copy source must stay valid until the copy has run: synchronise
     HIP_TRY(hipMemcpyAsync(c->d_sys, sys, sizeof(ort_system), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -584,7 +597,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
     }
 #define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
     // the default emitters (ring / point) have their own, leaner instantiation
-    const bool anysrc = c->emitter[a.phase - 1] != (a.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT);
+    const bool anysrc = c->emitter[a.phase - 1] != (a.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT) || c->scatter;
     if (c->precision == 1) {
         // fp32 study path (BASELINE configs[4]): lockstep kernel, literal predicates
         if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, false, float, true>));

@@ -26,7 +26,7 @@ NA_SINE = 0.22                     # src/imageMod.f90:40
 
 # surface kinds / flags: numeric values of include/ort.h
 SURF_PLANE, SURF_SPHERE, SURF_CYLINDER, SURF_ELLIPSE, SURF_IRIS, SURF_IMAGE = range(6)
-F_SKIP_ON_REFLECT, F_MISS_IS_HELP3, F_BOTTLE, F_TRACK = 1, 2, 4, 8
+F_SKIP_ON_REFLECT, F_MISS_IS_HELP3, F_BOTTLE, F_TRACK, F_SCATTER = 1, 2, 4, 8, 16
 MAX_SURFACES = 12
 
 
@@ -68,6 +68,10 @@ class Surface:
     cy: float = 0.0
     radius_b: float = 0.0
     name: str = ""
+    mua: float = 0.0
+    mus: float = 0.0
+    hgg: float = 0.0
+    scat_radius: float = 0.0
 
 
 @dataclass
@@ -148,6 +152,17 @@ class OpticalSystem:
                                    flags=F_SKIP_ON_REFLECT | F_BOTTLE, cx=cx, cy=cy, name="bottle inner"))
                 out.append(Surface(SURF_CYLINDER, cz, b.radiusa, b.nbottle, 1.0,
                                    flags=F_SKIP_ON_REFLECT | F_BOTTLE, cx=cx, cy=cy, name="bottle outer"))
+            # in-bottle scattering (lens.f90:218-219): contents before the inner wall (g = .65,
+            # :262-282), glass before the outer wall (g = 0.9, :312-333); tauint always walks
+            # inside the CIRCULAR cylinder radiusa - thickness / radiusa
+            if b.mua_c + b.mus_c != 0.0:
+                out[0].flags |= F_SCATTER
+                out[0].mua, out[0].mus, out[0].hgg = b.mua_c, b.mus_c, 0.65
+                out[0].scat_radius = b.radiusa - b.thickness
+            if b.mua_b + b.mus_b != 0.0:
+                out[1].flags |= F_SCATTER
+                out[1].mua, out[1].mus, out[1].hgg = b.mua_b, b.mus_b, 0.9
+                out[1].scat_radius = b.radiusa
         # plano-convex, flat face first: lens.f90:446-459 (reflection flag ignored)
         out.append(Surface(SURF_PLANE, l2.flat_z, 0.0, l2.n1, l2.n2, aperture=l2.radius, name="L2 flat"))
         out.append(Surface(SURF_SPHERE, l2.centre_z, l2.curve_radius, l2.n2, l2.n1,

@@ -57,7 +57,14 @@ CONFIGS = {
     # image source (emit_image): a synthetic integer-valued 512 x 512 source image, see source_image()
     "large_image": dict(bottle_file="clearBottle-large.params", light_source="image",
                         image_source="synthetic-source.dat", nphotons=60000),
+    # in-bottle scattering (no shipped bottle scatters; coefficients chosen so that a
+    # ray scatters a few times: contents mua 20 / mus 150, wall mua 30 / mus 400 [1/m])
+    "small_scatter_c": dict(bottle_file="scatterBottle-contents.params"),
+    "small_scatter_bc": dict(bottle_file="scatterBottle-both.params"),
 }
+
+SCATTER_BOTTLES = {"scatterBottle-contents.params": [0.0, 0.0, 20.0, 150.0],
+                   "scatterBottle-both.params": [10.0, 300.0, 5.0, 80.0]}
 
 
 def source_image():
@@ -82,15 +89,23 @@ def res_dir_with_image(src_res: str) -> str:
         for f in os.listdir(src_res):
             if f.endswith(".params"):
                 shutil.copy(os.path.join(src_res, f), os.path.join(d, f))
+        base = open(os.path.join(d, "clearBottle-small.params")).read().splitlines()[:12]
+        for name, mu in SCATTER_BOTTLES.items():            # 16-value bottle files (lens.f90:195-208)
+            with open(os.path.join(d, name), "w") as f:
+                f.write("\n".join(base + [repr(m) for m in mu]) + "\n")
         source_image().tofile(os.path.join(d, "synthetic-source.dat"))
     return d
+
+
+def needs_extended_res(settings) -> bool:
+    return settings.light_source == "image" or settings.bottle_file in SCATTER_BOTTLES
 
 
 def make_system(name: str):
     from opticalraytrace_amd.params import Settings, resource_dir
     from opticalraytrace_amd.system import OpticalSystem
     s = Settings(**{**dict(nphotons=100000, make_images=True), **CONFIGS[name]})
-    res = res_dir_with_image(resource_dir()) if s.light_source == "image" else None
+    res = res_dir_with_image(resource_dir()) if needs_extended_res(s) else None
     return s, OpticalSystem.from_settings(s, res)
 
 

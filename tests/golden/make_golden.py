@@ -31,13 +31,13 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(HERE))
 
-from conftest import CONFIGS, res_dir_with_image  # noqa: E402
+from conftest import CONFIGS, needs_extended_res, res_dir_with_image  # noqa: E402
 from opticalraytrace_amd.params import Settings  # noqa: E402
 from oracle.binding import Reference  # noqa: E402
 
 REF_RES = "/root/reference/res"
 N_RAYS = 192
-N_DRAWS = 32             # rows of the uniform table (the crs source draws a variable number)
+# rows of the uniform table: 16, or 48 / 160 for the sources / bottles that draw a variable number
 # draws the emitter of (source, phase) consumes; None = variable (crs phase 1: explicit-input
 # re-trace starts at draw 0 of a FRESH table row set instead)
 EMIT_DRAWS = {("point", 1): 4, ("point", 2): 2, ("spot", 1): 4, ("spot", 2): 0,
@@ -49,13 +49,14 @@ SEED = 123456789          # src/main.f90:79
 def main():
     for ci, (name, over) in enumerate(CONFIGS.items()):
         s = Settings(**{**dict(nphotons=N_IMAGE, make_images=True), **over})
-        ref = Reference(s, res_dir_with_image(REF_RES) if s.light_source == "image" else REF_RES)
+        ref = Reference(s, res_dir_with_image(REF_RES) if needs_extended_res(s) else REF_RES)
         n_rays = min(N_RAYS, s.nphotons)
         n_image = s.nphotons
         out = {"constants": ref.constants()[:47]}
         rng = np.random.default_rng(1000 + ci)
         for phase in (1, 2):
-            u = rng.random((N_DRAWS, n_rays))
+            n_draws = 160 if s.bottle_file.startswith("scatterBottle") else (48 if s.light_source == "crs" else 16)
+            u = rng.random((n_draws, n_rays))
             # force both Fresnel branches on some rays (u=0 reflects, u->1 refracts)
             if s.light_source == "point":
                 u[4:9, :8] = 0.0

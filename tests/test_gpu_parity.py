@@ -50,7 +50,10 @@ def test_golden_explicit_rays_bit_exact(ctxs, name, phase):
     got = ctx.trace_rays(phase, n, pos_dir_in=g[f"p{phase}_emitted"], u=u, draw_base=base)
     want = dict(status=g[f"p{phase}x_status"], bin_xy=g[f"p{phase}x_bin"],
                 n_draws=g[f"p{phase}x_ndraws"], pos_dir=g[f"p{phase}x_pos_dir"])
-    assert_rays_equal(got, want, exact=True, what=f"{name} phase {phase}")
+    # in-bottle scattering goes through log / atan2 / sincos / acos (ocml vs glibc, <= 2 ulp):
+    # every discrete outcome and draw count still matches, the state to 1e-10 (measured 7e-13)
+    exact = not (osys.bottle.scatters and phase == 2)
+    assert_rays_equal(got, want, exact=exact, what=f"{name} phase {phase}")
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
@@ -350,3 +353,34 @@ def test_image_source_on_the_gpu(ctxs):
     orc.trace(2, 0, n, SEED, wimg, wc); orc.trace(1, 0, n, SEED, wimg, wc)
     assert np.abs(img.astype(np.int64) - wimg).sum() <= 4
     assert np.abs(cnt.astype(np.int64) - wc.astype(np.int64)).max() <= 2
+
+
+@pytest.mark.parametrize("name", ["small_scatter_c", "small_scatter_bc"])
+def test_scattering_bottle_vs_oracle(ctxs, name):
+    """the random walk in the bottle (tauint + Henyey-Greenstein) for 50k keyed rays —
+    draw counts and outcomes against the oracle, the image up to a small flip budget."""
+    osys, ctx = ctxs(name)
+    orc = _oracle(osys)
+    n = 50000
+    want = orc.trace_rays(2, n, seed=SEED, first_ray=0)
+    got = ctx.trace_rays(2, n, seed=SEED, first_ray=0)
+    same = got["status"] == want["status"]
+    assert same.mean() > 0.9999, (~same).sum()
+    assert np.array_equal(got["n_draws"][same], want["n_draws"][same])
+    assert np.array_equal(got["n_isect"][same], want["n_isect"][same])
+    assert want["n_draws"].max() > 20                     # rays really scatter several times
+    reach = same & (want["status"] <= 2)
+    # The walk goes through log / atan2 / sincos / acos (ocml vs glibc differ by <= 2 ulp) and
+    # stokes divides by sint*sinbt, which amplifies an ulp by up to ~1e6 for near-forward
+    # scattering: per ray, position error relative to the 10 mm image and direction error
+    a, b = got["pos_dir"][:, reach], want["pos_dir"][:, reach]
+    err = np.maximum(np.abs(a[:3] - b[:3]).max(0) / 1e-2, np.abs(a[3:] - b[3:]).max(0))
+    assert (err <= REL_TOL).mean() > 0.999, (err > REL_TOL).sum()
+    assert err.max() < 1e-6
+    ctx.reset()
+    ctx.trace(2, 0, n, SEED)
+    img, cnt = ctx.read()
+    wimg = np.zeros((2, 401, 401), np.int32); wc = np.zeros(8, np.uint64)
+    orc.trace(2, 0, n, SEED, wimg, wc)
+    assert np.abs(img.astype(np.int64) - wimg).sum() <= 8
+    assert np.abs(cnt.astype(np.int64) - wc.astype(np.int64)).max() <= 8

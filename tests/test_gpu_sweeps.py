@@ -47,3 +47,21 @@ def test_runner_sweeps_on_one_context(hip_library, tmp_path):
     for iris in ("before", "after"):
         t = [by[("clearBottle-small.params", True, iris, z)].point_transmitted for z in (1.0, 0.8, 0.6, 0.4, 0.2)]
         assert all(a >= b for a, b in zip(t, t[1:])), (iris, t)
+
+
+def test_repeated_runs_are_ordered_with_torch_resets(hip_library):
+    """reset() (torch zero_ on the current stream) -> trace -> read must be stream-ordered: the
+    context runs on the stream torch hands over (the null stream when that is torch's current
+    stream), so 40 back-to-back runs give 40 identical results."""
+    from conftest import make_system
+    from opticalraytrace_amd.tracer import RayTracer
+    _, osys = make_system("small")
+    t = RayTracer(osys)
+    try:
+        first = t.run(20000)
+        for _ in range(40):
+            r = t.run(20000)
+            assert np.array_equal(r.counters, first.counters)
+            assert np.array_equal(r.image, first.image)
+    finally:
+        t.close()
