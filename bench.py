@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--phase", type=int, default=2, help="2 = point loop (configs[1]); 1 = ring loop")
     ap.add_argument("--cpu-rays", type=int, default=20_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast", action="store_true", help="skip the informational fast-fp64 leg")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and all-reduce even with one rank (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -135,6 +136,35 @@ def main():
     # per-launch kernel durations from the HIP events each launch recorded on the tracer's stream
     kernel_ms = tracer.ctx.kernel_times(min(args.steps, 64))
 
+    # informational, outside `value`: the same run in the opt-in fast fp64 mode (csrc/ort_fastd.h)
+    fast = None
+    if not args.no_fast:
+        saved_img, saved_cnt = tracer.image.clone(), tracer.counters.clone()
+        tracer.ctx.set_precision(2)
+        for k in range(2):
+            step(k)
+        fence()
+        tracer.reset()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + k)
+        tracer.reduce(force=use_dist)
+        fence()
+        el_fast = time.perf_counter() - t1
+        if use_dist:
+            tm = torch.tensor([el_fast], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el_fast = float(tm.item())
+        fr = tracer.result(total_rays * args.steps)
+        fast = {"value": int(fr.counters[ci]) / el_fast, "unit": "intersections/s",
+                "ms_per_step": el_fast / args.steps * 1e3,
+                "image_l1_vs_exact": int((fr.image.astype("int64") - saved_img.cpu().numpy()).__abs__().sum()),
+                "note": "ort_set_precision(2): FMA contraction + Newton reciprocal/rsqrt; ~1e-15 relative "
+                        "from the exact path, not bit-identical (profiles/r01/fastd_study.json)"}
+        tracer.ctx.set_precision(0)
+        tracer.image.copy_(saved_img)
+        tracer.counters.copy_(saved_cnt)
+
     res = tracer.result(total_rays * args.steps)   # counters of the whole timed run, summed over ranks
     isect_total = int(res.counters[ci])
     binned_total = int(res.counters[cb])
@@ -196,6 +226,8 @@ def main():
             "frac": ach_tf / FP64_VEC_PEAK_TFLOPS, "flop_per_intersection": FLOP_PER_INTERSECTION,
         },
     }
+    if fast is not None:
+        out["fast_fp64"] = fast
     if cpu is not None:
         out["cpu_baseline"] = cpu
         if cpu.get("value"):

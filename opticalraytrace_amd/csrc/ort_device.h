@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/ort.h"
+#include "ort_fastd.h"
 
 namespace ort {
 
@@ -158,6 +159,11 @@ __device__ inline bool wave_any(bool p) { return __ballot(p) != 0ull; }
 // returns the same scaled denominator for all three numerators (always, outside
 // the subnormal/overflow corners), so each quotient is bit-for-bit `x / t`.
 __device__ inline VecT<float> div3(VecT<float> v, float t) { return {v.x / t, v.y / t, v.z / t}; }
+__device__ inline VecT<fastd> div3(VecT<fastd> v, fastd t)
+{
+    const double r = rcp_nr2(t.v);
+    return {fastd(v.x.v * r), fastd(v.y.v * r), fastd(v.z.v * r)};
+}
 
 __device__ inline Vec div3(Vec v, double t)
 {
@@ -197,6 +203,11 @@ template <class T> __device__ inline VecT<T> vnormalise(VecT<T> a)
     T tmp = ORT_SQRT(a.x * a.x + a.y * a.y + a.z * a.z);
     return div3(a, tmp);
 }
+template <> __device__ inline VecT<fastd> vnormalise<fastd>(VecT<fastd> a)
+{
+    const double y = rsq_nr2((a.x * a.x + a.y * a.y + a.z * a.z).v);      // multiply by 1/|a| directly
+    return {fastd(a.x.v * y), fastd(a.y.v * y), fastd(a.z.v * y)};
+}
 
 template <class T> struct RayT { VecT<T> pos, dir; };
 using Ray = RayT<double>;
@@ -232,6 +243,8 @@ __device__ inline double rsq_approx(double s)
     double e = __builtin_fma(-h, y, 0.5);
     return __builtin_fma(y, e, y);
 }
+__device__ inline fastd rcp_approx(fastd y) { return fastd(rcp_approx(y.v)); }
+__device__ inline fastd rsq_approx(fastd s) { return fastd(rsq_approx(s.v)); }
 
 // The staged system as the kernels see it.  For T = double this is ort_system itself (the
 // device copy is staged byte for byte); for T = float a converted copy is staged.
@@ -250,11 +263,16 @@ template <class T> struct SystemT {
 };
 template <class T> struct SysTypes { using Sys = SystemT<T>; using Surf = SurfaceT<T>; };
 template <> struct SysTypes<double> { using Sys = ort_system; using Surf = ort_surface; };
+template <> struct SysTypes<fastd> { using Sys = ort_system; using Surf = ort_surface; };   // doubles convert implicitly
 
 template <class T> __device__ inline bool aperture_present(T a);
 template <> __device__ inline bool aperture_present<double>(double a)
 {
     return __builtin_amdgcn_readfirstlane(__double2hiint(a)) >= 0;
+}
+template <> __device__ inline bool aperture_present<fastd>(fastd a)
+{
+    return __builtin_amdgcn_readfirstlane(__double2hiint(a.v)) >= 0;
 }
 template <> __device__ inline bool aperture_present<float>(float a)
 {
@@ -369,12 +387,12 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
     const T c2 = ORT_SQRT(k);                            // NaN beyond total reflection: unused there
     bool reflected = false, decided = false;
     if constexpr (FILT) {
-        double a1 = n1 * c1, b1 = n2 * c2, a2 = n1 * c2, b2 = n2 * c1;
-        double f1 = (a1 - b1) * rcp_approx(a1 + b1);
-        double f2 = (a2 - b2) * rcp_approx(a2 + b2);
-        double R = 0.5 * (f1 * f1 + f2 * f2);
+        T a1 = n1 * c1, b1 = n2 * c2, a2 = n1 * c2, b2 = n2 * c1;
+        T f1 = (a1 - b1) * rcp_approx(a1 + b1);
+        T f2 = (a2 - b2) * rcp_approx(a2 + b2);
+        T R = T(0.5) * (f1 * f1 + f2 * f2);
         // NaN anywhere -> undecided; c1 >= 1, k ~ 0 or < 0 (total reflection) -> literal path
-        decided = (k > 1e-6) && (c1 < 1.0) && (fabs(u - R) > 1e-10);
+        decided = (k > T(1e-6)) && (c1 < T(1.0)) && (fabs(u - R) > T(1e-10));
         reflected = u < R;
     }
     if (wave_any(live && !decided)) {
@@ -511,6 +529,7 @@ __device__ inline void scatter_walk(const Surf &s, T twopi, RayT<T> &r, T &t, bo
 }
 
 template <> __device__ inline void sincos_t<double>(double x, double *s, double *c) { sincos(x, s, c); }
+template <> __device__ inline void sincos_t<fastd>(fastd x, fastd *s, fastd *c) { sincos(x.v, &s->v, &c->v); }
 template <> __device__ inline void sincos_t<float>(float x, float *s, float *c) { sincosf(x, s, c); }
 
 // ----------------------------------------------------------------------------
@@ -681,16 +700,16 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
     bool na_decided = false, reject = false;
     if constexpr (FILT) {
         // x = dir_z / |dir| up to 1e-13; the literal form below rounds it five more times
-        double xa = r.dir.z * rsq_approx(vdot(r.dir, r.dir));
-        na_decided = fabs(xa - S.na_cos_min) > 1e-10;
-        reject = xa < S.na_cos_min;
+        T xa = r.dir.z * rsq_approx(vdot(r.dir, r.dir));
+        na_decided = fabs(xa - T(S.na_cos_min)) > T(1e-10);
+        reject = xa < T(S.na_cos_min);
     }
     if (wave_any(live && !na_decided)) {
         VecT<T> d = vnormalise(r.dir);
         d = vscale(d, T(-1.));
         T top = (T(0.) * d.x) + (T(0.) * d.y) + (T(-1.) * d.z);
         T bottom = ORT_SQRT(vdot(d, d)) * T(1.0);
-        bool rl = (top / bottom) < S.na_cos_min;
+        bool rl = (top / bottom) < T(S.na_cos_min);
         reject = na_decided ? reject : rl;
     }
     T fx = T(0.), fy = T(0.);
@@ -698,14 +717,14 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
     if constexpr (FILT) {
         // floor(x / binwid) from one multiply unless the quotient is within 1e-6 of an integer
         // (|q * 2.3e-16| < 1e-9 for |q| < 4e6)
-        double qx = r.pos.x * S.inv_bin_width, qy = r.pos.y * S.inv_bin_width;
+        T qx = r.pos.x * T(S.inv_bin_width), qy = r.pos.y * T(S.inv_bin_width);
         fx = floor(qx); fy = floor(qy);
-        double gx = qx - fx, gy = qy - fy;
-        bin_decided = gx > 1e-6 && gx < 1. - 1e-6 && gy > 1e-6 && gy < 1. - 1e-6 &&
-                      fabs(qx) < 1e6 && fabs(qy) < 1e6;
+        T gx = qx - fx, gy = qy - fy;
+        bin_decided = gx > T(1e-6) && gx < T(1. - 1e-6) && gy > T(1e-6) && gy < T(1. - 1e-6) &&
+                      fabs(qx) < T(1e6) && fabs(qy) < T(1e6);
     }
     if (wave_any(live && !reject && !bin_decided)) {
-        T lx = floor(r.pos.x / S.bin_width), ly = floor(r.pos.y / S.bin_width);
+        T lx = floor(r.pos.x / T(S.bin_width)), ly = floor(r.pos.y / T(S.bin_width));
         fx = bin_decided ? fx : lx;
         fy = bin_decided ? fy : ly;
     }

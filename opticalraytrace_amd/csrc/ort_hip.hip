@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
                 double *pp = a.path + (size_t)ic * ORT_MAX_PATH * 3;
                 auto push = [&](bool c) {
                     if (c && act && np < ORT_MAX_PATH) {
-                        pp[np * 3 + 0] = r.pos.x; pp[np * 3 + 1] = r.pos.y; pp[np * 3 + 2] = r.pos.z;
+                        pp[np * 3 + 0] = (double)r.pos.x; pp[np * 3 + 1] = (double)r.pos.y; pp[np * 3 + 2] = (double)r.pos.z;
                         np++;
                     }
                 };
@@ -210,14 +210,14 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
         if (!act) continue;
         if (MODE == MODE_DEBUG) {
             if (a.pos_dir_out) {
-                a.pos_dir_out[0 * n + i] = r.pos.x; a.pos_dir_out[1 * n + i] = r.pos.y;
-                a.pos_dir_out[2 * n + i] = r.pos.z; a.pos_dir_out[3 * n + i] = r.dir.x;
-                a.pos_dir_out[4 * n + i] = r.dir.y; a.pos_dir_out[5 * n + i] = r.dir.z;
+                a.pos_dir_out[0 * n + i] = (double)r.pos.x; a.pos_dir_out[1 * n + i] = (double)r.pos.y;
+                a.pos_dir_out[2 * n + i] = (double)r.pos.z; a.pos_dir_out[3 * n + i] = (double)r.dir.x;
+                a.pos_dir_out[4 * n + i] = (double)r.dir.y; a.pos_dir_out[5 * n + i] = (double)r.dir.z;
             }
             if (a.emitted_out) {
-                a.emitted_out[0 * n + i] = em.pos.x; a.emitted_out[1 * n + i] = em.pos.y;
-                a.emitted_out[2 * n + i] = em.pos.z; a.emitted_out[3 * n + i] = em.dir.x;
-                a.emitted_out[4 * n + i] = em.dir.y; a.emitted_out[5 * n + i] = em.dir.z;
+                a.emitted_out[0 * n + i] = (double)em.pos.x; a.emitted_out[1 * n + i] = (double)em.pos.y;
+                a.emitted_out[2 * n + i] = (double)em.pos.z; a.emitted_out[3 * n + i] = (double)em.dir.x;
+                a.emitted_out[4 * n + i] = (double)em.dir.y; a.emitted_out[5 * n + i] = (double)em.dir.z;
             }
             if (a.status) a.status[i] = st;
             if (a.bin_xy) { a.bin_xy[i] = xp; a.bin_xy[n + i] = yp; }
@@ -264,7 +264,7 @@ __device__ inline int lane_prefix(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-template <int MODE, bool FILT, bool ANYSRC>
+template <int MODE, bool FILT, bool ANYSRC, class T>
 __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(TraceArgs a)
 {
     __shared__ ort_system S;
@@ -318,16 +318,16 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
             const int slot = (qhead + lane) & (kQueueCap - 1);
             qhead = (qhead + m) & (kQueueCap - 1);
             qcount -= m;
-            Ray r = {{0., 0., 0.}, {0., 0., 1.}};
+            RayT<T> r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}};
             KeyedDraws d;
             d.z = 0;
             if (act) {
-                r.pos = {q[0][slot], q[1][slot], q[2][slot]};
-                r.dir = {q[3][slot], q[4][slot], q[5][slot]};
+                r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
+                r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
                 d.z = (uint64_t)__double_as_longlong(q[6][slot]);
             }
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
-            walk<FILT, double, ANYSRC>(S, surf, split, ns, r, d, nis, st, xp, yp);
+            walk<FILT, T, ANYSRC>(S, surf, split, ns, r, d, nis, st, xp, yp);
             if (act) finish(st, nis, xp, yp);
             __builtin_amdgcn_wave_barrier();
         } else if (have_new) {
@@ -336,24 +336,24 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
             const bool act = i < hi;
             next += 64;
             const uint64_t ic = act ? i : hi - 1;        // clamped: idle lanes recompute the last ray, unused
-            Ray r;
+            RayT<T> r;
             KeyedDraws d;
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
             if (MODE == MODE_RESIDENT) {
                 d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
-                r.pos = {a.pos_dir_in[0 * n + ic], a.pos_dir_in[1 * n + ic], a.pos_dir_in[2 * n + ic]};
-                r.dir = {a.pos_dir_in[3 * n + ic], a.pos_dir_in[4 * n + ic], a.pos_dir_in[5 * n + ic]};
+                r.pos = {T(a.pos_dir_in[0 * n + ic]), T(a.pos_dir_in[1 * n + ic]), T(a.pos_dir_in[2 * n + ic])};
+                r.dir = {T(a.pos_dir_in[3 * n + ic]), T(a.pos_dir_in[4 * n + ic]), T(a.pos_dir_in[5 * n + ic])};
             } else {
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                if (!emit<double, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
+                if (!emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             }
-            walk<FILT, double, ANYSRC>(S, surf, 0, split, r, d, nis, st, xp, yp);
+            walk<FILT, T, ANYSRC>(S, surf, 0, split, r, d, nis, st, xp, yp);
             const bool survive = act && st < 0;
             const unsigned long long mask = __ballot(survive);
             if (survive) {
                 const int slot = (qhead + qcount + lane_prefix(mask)) & (kQueueCap - 1);
-                q[0][slot] = r.pos.x; q[1][slot] = r.pos.y; q[2][slot] = r.pos.z;
-                q[3][slot] = r.dir.x; q[4][slot] = r.dir.y; q[5][slot] = r.dir.z;
+                q[0][slot] = (double)r.pos.x; q[1][slot] = (double)r.pos.y; q[2][slot] = (double)r.pos.z;
+                q[3][slot] = (double)r.dir.x; q[4][slot] = (double)r.dir.y; q[5][slot] = (double)r.dir.z;
                 q[6][slot] = __longlong_as_double((long long)d.z);
                 isect += (unsigned)nis;                    // counted so far; segment 2 adds the rest
             } else if (act) {
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int
         d.init_keyed(rng_base, first_ray + i, 0);
         Ray r;
         emit<double, true>(S, phase, r, d, first_ray + i, img_cdf);
-        pos_dir[0 * n + i] = r.pos.x; pos_dir[1 * n + i] = r.pos.y; pos_dir[2 * n + i] = r.pos.z;
-        pos_dir[3 * n + i] = r.dir.x; pos_dir[4 * n + i] = r.dir.y; pos_dir[5 * n + i] = r.dir.z;
+        pos_dir[0 * n + i] = (double)r.pos.x; pos_dir[1 * n + i] = (double)r.pos.y; pos_dir[2 * n + i] = (double)r.pos.z;
+        pos_dir[3 * n + i] = (double)r.dir.x; pos_dir[4 * n + i] = (double)r.dir.y; pos_dir[5 * n + i] = (double)r.dir.z;
     }
 }
 
@@ -587,7 +587,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
     const int slot = (int)(c->ring_count % kTimingRing);
     if (c->timing && evk >= 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
     if (c->timing && evk == 0) HIP_TRY(hipEventRecord(c->ring[slot][0], c->stream));
-    const bool queued = (c->variant & 1) && mode != MODE_DEBUG && c->precision == 0;
+    const bool queued = (c->variant & 1) && mode != MODE_DEBUG && c->precision != 1;
     const bool filt = (c->variant & 2) == 0;
     if (queued) {
         // every wave walks a 64-aligned contiguous range: no more waves than 64-ray batches
@@ -598,7 +598,17 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
 #define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
     // the default emitters (ring / point) have their own, leaner instantiation
     const bool anysrc = c->emitter[a.phase - 1] != (a.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT) || c->scatter;
-    if (c->precision == 1) {
+    if (c->precision == 2) {
+        // fast fp64 (ort_fastd.h): FMA contraction, Newton divide / Goldschmidt sqrt; ~1e-13 from exact
+        if (mode == MODE_DEBUG) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, fastd, true>));
+        else if (anysrc) {
+            if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true, fastd>));
+            else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true, fastd>));
+        } else {
+            if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, fastd>));
+            else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, fastd>));
+        }
+    } else if (c->precision == 1) {
         // fp32 study path (BASELINE configs[4]): lockstep kernel, literal predicates
         if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, false, float, true>));
         else if (mode == MODE_RESIDENT) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, float, true>));
@@ -609,15 +619,15 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
     } else if (anysrc || !filt || !queued) {
         // alternate emitters and the A/B variants share the generic instantiations
         if (mode == MODE_FUSED) {
-            if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true>)); else ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, false, true>)); }
+            if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true, double>)); else ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, false, true, double>)); }
             else { if (filt) ORT_LAUNCH((trace_kernel<MODE_FUSED, true, double, true>)); else ORT_LAUNCH((trace_kernel<MODE_FUSED, false, double, true>)); }
         } else {
-            if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true>)); else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, false, true>)); }
+            if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true, double>)); else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, false, true, double>)); }
             else { if (filt) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true, double, true>)); else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, double, true>)); }
         }
     } else {
-        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false>));
-        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false>));
+        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, double>));
+        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, double>));
     }
 #undef ORT_LAUNCH
     if (use_rep) hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, a.phase);
@@ -832,7 +842,7 @@ int ort_kernel_times(ort_ctx *c, float *ms, int capacity, int *count)
 int ort_set_precision(ort_ctx *c, int precision)
 {
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
-    if (precision != 0 && precision != 1) return fail(ORT_E_INVALID, "precision must be 0 (fp64) or 1 (fp32)");
+    if (precision < 0 || precision > 2) return fail(ORT_E_INVALID, "precision must be 0 (fp64 exact), 1 (fp32) or 2 (fp64 fast)");
     c->precision = precision;
     return ORT_OK;
 }

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--bottle", default="clearBottle-large.params")
     ap.add_argument("--variants", default="0,1,2,3")
     ap.add_argument("--phases", default="2,1")
+    ap.add_argument("--precision", type=int, default=0)
     args = ap.parse_args()
     global VARIANTS
     VARIANTS = [int(v) for v in args.variants.split(',')]
@@ -28,6 +29,7 @@ def main():
     osys = OpticalSystem.from_settings(s)
     ctx = capi.Context(osys)
     ctx.set_timing(True)
+    ctx.set_precision(args.precision)
     res = {}
     for rnd in range(args.rounds + 1):
         for phase in [int(p) for p in args.phases.split(',')]:
