@@ -1,20 +1,26 @@
 // ort_hip.hip — HIP kernels (gfx950 / CDNA4, wave64) and the C ABI of include/ort.h.
 //
-// Kernels
-//   trace_kernel<MODE>   one thread per ray inside 64-lane wavefronts, grid-stride
-//                        over the global ray index range; the whole ort_system
-//                        (surface list + emitter + image constants, ~2 KB) is staged
-//                        into LDS once per workgroup; the ray (pos, dir) lives in
-//                        VGPRs from emission to binning; the image is an int32
-//                        histogram in HBM updated with global atomics; the run
-//                        counters are reduced per workgroup in LDS and added once.
-//     MODE_FUSED     emit in-kernel (src/main.f90:90-109 / :127-162 whole body)
-//     MODE_RESIDENT  ray bundle read from HBM, SoA fp64 [6][n], coalesced
-//     MODE_DEBUG     parity entry: per-ray outputs, no binning side effect
-//   emit_kernel          fills an SoA bundle with the phase's source
+// Kernels (device functions: ort_device.h; the arithmetic type T is double = the reference's
+// arithmetic, bit-exact; float = fp32 study path; fastd = opt-in fast fp64, ort_fastd.h)
+//   trace_queue_kernel<MODE, FILT, EXT, T>   the production kernel.  One wavefront = one ray
+//       bundle over a contiguous range of global ray indices; the 2.7 KB ort_system (surface
+//       lists + emitter + image constants) is staged into LDS once per workgroup; a ray lives
+//       in VGPRs from emission to binning; survivors of the first surface segment are
+//       compacted through a wave-private LDS queue so that the second segment runs on full
+//       wavefronts; hits are binned with global int32 atomics into one of 8 image replicas
+//       (fold_kernel adds them into the image afterwards); counters are reduced per workgroup.
+//         MODE_FUSED     emit in-kernel (src/main.f90:90-109 / :127-162 whole loop body)
+//         MODE_RESIDENT  ray bundle read from HBM, SoA fp64 [6][n], coalesced
+//         FILT           filtered predicates (decisions from bounded approximations)
+//         EXT            also compiles the rarely used emitters (spot, crs, image) and the
+//                        in-bottle scattering walk; the default instantiation leaves them out
+//   trace_kernel<MODE, FILT, T, EXT>         plain lockstep thread-per-ray walk: the parity /
+//       debug entry (MODE_DEBUG: per-ray outputs, tracker paths, no side effect), the fp32
+//       path and the A/B baseline of the queued kernel
+//   fold_kernel, emit_kernel
 //
-// No MFMA: there is no contraction anywhere on this path; the kernel
-// is bound by fp64 VALU issue (divide / sqrt sequences), not by HBM.
+// No MFMA: there is no contraction anywhere on this path; the kernel is bound by
+// fp64 VALU issue (IEEE divide / sqrt expansions), not by HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
