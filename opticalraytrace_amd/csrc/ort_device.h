@@ -158,14 +158,15 @@ __device__ inline bool wave_any(bool p) { return __ballot(p) != 0ull; }
 // with the denominator-only half shared; it is taken only when v_div_scale
 // returns the same scaled denominator for all three numerators (always, outside
 // the subnormal/overflow corners), so each quotient is bit-for-bit `x / t`.
-__device__ inline VecT<float> div3(VecT<float> v, float t) { return {v.x / t, v.y / t, v.z / t}; }
-__device__ inline VecT<fastd> div3(VecT<fastd> v, fastd t)
+// `need` marks the lanes whose quotient is used: only those can force the fallback.
+__device__ inline VecT<float> div3(VecT<float> v, float t, bool = true) { return {v.x / t, v.y / t, v.z / t}; }
+__device__ inline VecT<fastd> div3(VecT<fastd> v, fastd t, bool = true)
 {
     const double r = rcp_nr2(t.v);
     return {fastd(v.x.v * r), fastd(v.y.v * r), fastd(v.z.v * r)};
 }
 
-__device__ inline Vec div3(Vec v, double t)
+__device__ inline Vec div3(Vec v, double t, bool need = true)
 {
 #if defined(ORT_ABL_FASTDIV)
     return {ORT_DIV(v.x, t), ORT_DIV(v.y, t), ORT_DIV(v.z, t)};
@@ -188,7 +189,7 @@ __device__ inline Vec div3(Vec v, double t)
     q.x = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-d0, m0, n0), r, m0, f0), t, v.x);
     q.y = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-d0, m1, n1), r, m1, f1), t, v.y);
     q.z = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-d0, m2, n2), r, m2, f2), t, v.z);
-    if (wave_any(!shared)) {        // NaN or extreme exponents: plain divisions for those lanes
+    if (wave_any(need && !shared)) { // NaN or extreme exponents: plain divisions for those lanes
         q.x = shared ? q.x : v.x / t;
         q.y = shared ? q.y : v.y / t;
         q.z = shared ? q.z : v.z / t;
@@ -198,12 +199,12 @@ __device__ inline Vec div3(Vec v, double t)
 }
 
 // magnitude_fn (:175-186): NORMALISES, by three divisions
-template <class T> __device__ inline VecT<T> vnormalise(VecT<T> a)
+template <class T> __device__ inline VecT<T> vnormalise(VecT<T> a, bool need = true)
 {
     T tmp = ORT_SQRT(a.x * a.x + a.y * a.y + a.z * a.z);
-    return div3(a, tmp);
+    return div3(a, tmp, need);
 }
-template <> __device__ inline VecT<fastd> vnormalise<fastd>(VecT<fastd> a)
+template <> __device__ inline VecT<fastd> vnormalise<fastd>(VecT<fastd> a, bool)
 {
     const double y = rsq_nr2((a.x * a.x + a.y * a.y + a.z * a.z).v);      // multiply by 1/|a| directly
     return {fastd(a.x.v * y), fastd(a.y.v * y), fastd(a.z.v * y)};
@@ -295,7 +296,7 @@ __device__ inline void solve_and_pick(T a, T b, T c, bool live, T &t, bool &hit)
     const T discrim = b * b - T(4.0) * a * c;
     const bool neg = discrim < T(0.0);                // :243 — no real root
     const T sq = ORT_SQRT(discrim);                   // NaN when neg: those lanes are misses
-    const T q = (b > T(0.0)) ? T(-0.5) * (b + sq) : T(-0.5) * (b - sq);
+    const T q = T(-0.5) * (b + ((b > T(0.0)) ? sq : -sq));   // :249-253; b - sq == b + (-sq) exactly
     bool ok = false;
     t = T(0.0);
     hit = false;
@@ -378,7 +379,7 @@ __device__ inline T fresnel(T costt, T n1, T n2, T eta)
 // reciprocals and with refract's own c2 standing in for fresnel's cost2 (the same
 // quantity, rounded along another path; they differ by < 1e-13 once k > 1e-6).
 // |R' - R| < 1e-12, the margin is 1e-10.
-template <bool FILT, class T>
+template <bool FILT, bool KEEP, class T>
 __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta, T u, bool live)
 {
     const T c1s = vdot(N, I);                            // == vdot(I, N): the products commute
@@ -399,10 +400,15 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
         bool rl = u <= fresnel(c1, n1, n2, eta);         // :275
         reflected = decided ? reflected : rl;
     }
-    const VecT<T> refl = vsub(I, vscale(N, T(2.) * c1s));      // :297
-    const VecT<T> Nt = (c1s < T(0.)) ? N : vscale(N, T(-1.));  // :320-325
-    const VecT<T> refr = vadd(vscale(I, eta), vscale(Nt, eta * c1 - c2));   // :329
-    I = vselect(live, vselect(reflected, refl, refr), I);
+    // Both outcomes are I*alpha + N*beta, bit for bit:
+    //   reflect (:297)      I - (2 c1s) N         = I*1   + N*(-(2 c1s))     (x*1 and a + (-b) are exact)
+    //   refract (:320-329)  eta I + (eta c1 - c2) Nt,  Nt = N or -N  = I*eta + N*(+-(eta c1 - c2))
+    // so the two scalars are selected, not the six components.
+    const T m = eta * c1 - c2;
+    const T alpha = reflected ? T(1.) : eta;
+    const T beta = reflected ? -(T(2.) * c1s) : ((c1s < T(0.)) ? m : -m);
+    const VecT<T> out = vadd(vscale(I, alpha), vscale(N, beta));
+    I = KEEP ? vselect(live, out, I) : out;
     return reflected;
 }
 
@@ -747,7 +753,9 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
 // ----------------------------------------------------------------------------
 // EXT = false compiles the step without the in-bottle scattering walk (the lean instantiation
 // of the bulk kernels; the host picks it when no surface carries ORT_F_SCATTER).
-template <bool FILT, class T, bool EXT, class Sys, class Surf, class D>
+// KEEP = false lets lanes whose ray has ended carry garbage in r (the bulk kernels read only
+// st/xp/yp/nis of such lanes); KEEP = true freezes r where the ray ended (debug / tracker output).
+template <bool FILT, class T, bool EXT, bool KEEP = true, class Sys, class Surf, class D>
 __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &draws,
                                     int &nis, int &st, int &xp, int &yp)
 {
@@ -772,11 +780,11 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
             hit = hit && walk_end < 0;
         }
         const VecT<T> moved = vadd(r.pos, vscale(r.dir, t));
-        r.pos = vselect(live && hit, moved, r.pos);
+        r.pos = KEEP ? vselect(live && hit, moved, r.pos) : moved;
         bool out = false;
         if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, live && hit);
         // normal = centre - pos, with orig%x = centre%x for the bottle (lens.f90:288-290)
-        N = vnormalise(VecT<T>{cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z});
+        N = vnormalise(VecT<T>{cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z}, live && hit);
         ended = !hit ? ((flags & ORT_F_MISS_IS_HELP3) ? ORT_ST_HELP3 : lost) : (out ? lost : -1);
         ended = walk_end >= 0 ? walk_end : ended;
         proceed = live && hit && !out;
@@ -785,7 +793,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
         const T d = ORT_DIV(s.cz - r.pos.z, r.dir.z);
         const VecT<T> moved = vadd(r.pos, vscale(r.dir, d));
         if (kind == ORT_SURF_IMAGE) {
-            r.pos = vselect(live, moved, r.pos);
+            r.pos = KEEP ? vselect(live, moved, r.pos) : moved;
             const int ist = make_image<FILT, T>(S, r, live, xp, yp);
             st = live ? ist : st;
             return;
@@ -793,18 +801,18 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
         bool out = false;
         if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, live);
         if (kind == ORT_SURF_IRIS) {
-            r.pos = vselect(live && out, moved, r.pos);     // pos = origpos unless lost (lens.f90:564, :643)
+            if (KEEP) r.pos = vselect(live && out, moved, r.pos);   // pos = origpos unless lost (lens.f90:564, :643)
             st = (live && out) ? lost : st;
             return;
         }
-        r.pos = vselect(live, moved, r.pos);
+        r.pos = KEEP ? vselect(live, moved, r.pos) : moved;
         N = {T(0.), T(0.), T(-1.)};                         // flatNormal, lens.f90:165
         ended = out ? lost : -1;
         proceed = live && !out;
     }
     const T u = draws.template peek_as<T>();
     draws.advance(proceed);
-    const bool reflected = reflect_refract<FILT, T>(r.dir, N, s.n1, s.n2, s.eta, u, proceed);
+    const bool reflected = reflect_refract<FILT, KEEP, T>(r.dir, N, s.n1, s.n2, s.eta, u, proceed);
     const bool dies = reflected && (flags & ORT_F_SKIP_ON_REFLECT);
     st = live ? (proceed ? (dies ? lost : -1) : ended) : st;
 }

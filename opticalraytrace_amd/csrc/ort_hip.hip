@@ -136,13 +136,14 @@ __global__ __launch_bounds__(256) void fold_kernel(int32_t *image, int32_t *repl
 
 // One lockstep pass of a wave over surfaces [k0, k1): every lane steps with its `st`
 // predicate; the loop leaves as soon as no lane of the wave is alive (uniform branch).
-template <bool FILT, class T, bool EXT, class Sys, class Surf, class D>
+// KEEP: see surface_step — false where only st/xp/yp/nis of an ended ray are read afterwards.
+template <bool FILT, class T, bool EXT, bool KEEP, class Sys, class Surf, class D>
 __device__ inline void walk(const Sys &S, const Surf *surf, int k0, int k1, RayT<T> &r, D &draws,
                             int &nis, int &st, int &xp, int &yp)
 {
     for (int k = k0; k < k1; ++k) {
         if (!wave_any(st < 0)) break;
-        surface_step<FILT, T, EXT>(S, surf[k], r, draws, nis, st, xp, yp);
+        surface_step<FILT, T, EXT, KEEP>(S, surf[k], r, draws, nis, st, xp, yp);
     }
 }
 
@@ -204,14 +205,14 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
                 }
                 if (act) a.npath[ic] = np;
             } else {
-                walk<FILT, T, ANYSRC>(S, surf, 0, ns, r, d, nis, st, xp, yp);
+                walk<FILT, T, ANYSRC, true>(S, surf, 0, ns, r, d, nis, st, xp, yp);
             }
             kdraws = d.k;
         } else {
             KeyedDraws d;
             d.init_keyed(a.rng_base, a.first_ray + ic, have_in ? a.draw_base : 0);
             if (!have_in && !emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
-            walk<FILT, T, ANYSRC>(S, surf, 0, ns, r, d, nis, st, xp, yp);
+            walk<FILT, T, ANYSRC, false>(S, surf, 0, ns, r, d, nis, st, xp, yp);
         }
         if (!act) continue;
         if (MODE == MODE_DEBUG) {
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 d.z = (uint64_t)__double_as_longlong(q[6][slot]);
             }
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
-            walk<FILT, T, ANYSRC>(S, surf, split, ns, r, d, nis, st, xp, yp);
+            walk<FILT, T, ANYSRC, false>(S, surf, split, ns, r, d, nis, st, xp, yp);
             if (act) finish(st, nis, xp, yp);
             __builtin_amdgcn_wave_barrier();
         } else if (have_new) {
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
                 if (!emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             }
-            walk<FILT, T, ANYSRC>(S, surf, 0, split, r, d, nis, st, xp, yp);
+            walk<FILT, T, ANYSRC, false>(S, surf, 0, split, r, d, nis, st, xp, yp);
             const bool survive = act && st < 0;
             const unsigned long long mask = __ballot(survive);
             if (survive) {
