@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/ort.h"
 #include "ort_fastd.h"
 
@@ -90,6 +91,7 @@ struct Draws {
         z += c ? kGolden : 0ull;
     }
     __device__ inline double next() { double u = peek(); advance(true); return u; }
+    __device__ inline void take(bool c, const Draws &o) { k = c ? o.k : k; z = c ? o.z : z; }   // same stream
     template <class T> __device__ inline T peek_as() const { return (T)peek(); }
     template <class T> __device__ inline T next_as() { return (T)next(); }
 };
@@ -110,6 +112,7 @@ struct KeyedDraws {
     __device__ inline double peek() const { return bits_to_unit(mix64(z + kGolden)); }
 #endif
     __device__ inline void advance(bool c) { z += c ? kGolden : 0ull; }
+    __device__ inline void take(bool c, const KeyedDraws &o) { z = c ? o.z : z; }
     __device__ inline double next() { z += kGolden; return bits_to_unit(mix64(z)); }
     template <class T> __device__ inline T peek_as() const
     {
@@ -137,6 +140,53 @@ struct KeyedDraws {
 #define ORT_DIV(a, b) ((a) / (b))
 #endif
 
+// the i1 ballot builtin: an s_and of the compare mask with exec.  (HIP's __ballot(int) first
+// materialises the predicate as 0/1 in a VGPR and compares it again: two VALU instructions.)
+__device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// ORT_RARE(site, cond): a lane raises its `rare` flag.  -DORT_DBG_RARE (development) also counts
+// the raises per site in ort_dbg_rare[].
+#ifdef ORT_DBG_RARE
+__device__ unsigned long long ort_dbg_rare[16];
+#define ORT_RARE(site, cond) do { const bool c_ = (cond); rare = rare || c_; if (c_) atomicAdd(&ort_dbg_rare[site], 1ull); } while (0)
+#else
+#define ORT_RARE(site, cond) do { rare = rare || (cond); } while (0)
+#endif
+// "does any lane need the literal formula": the guard of every rare path
+#ifdef ORT_ABL_NOFALLBACK
+__device__ inline bool wave_rare(bool) { return false; }
+#else
+__device__ inline bool wave_rare(bool p) { return wave_any(p); }
+#endif
+
+// sqrt(x) at the hot sites.  FILT (fp64): the compiler's own fp64 square-root expansion —
+// v_rsq_f64 seed, one coupled Goldschmidt step, two residual corrections — WITHOUT its input
+// scaling (only active below 2^-767) and its class fix-up (x = 0, inf): the same instructions
+// on the same operands, hence bit-identical to sqrt(x), whenever 2^-700 < |x| < 2^700 (x < 0
+// gives NaN either way).  A lane outside that range that needs the value raises `rare`
+// (tests/csrc/check_exact_ops.hip compares the two over 2^28 operands of every exponent).
+template <bool FILT, class T>
+__device__ inline T sqrt_f(T x, bool need, bool &rare)
+{
+#if !defined(ORT_ABL_FASTSQRT)
+    if constexpr (FILT && std::is_same<T, double>::value) {
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y;
+        double h = y * 0.5;
+        const double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        double d = __builtin_fma(-g, g, x);
+        g = __builtin_fma(d, h, g);
+        d = __builtin_fma(-g, g, x);
+        g = __builtin_fma(d, h, g);
+        const bool plain = fabs(x) > 0x1p-700 && fabs(x) < 0x1p700;      // false for NaN too
+        ORT_RARE(0, need && !plain);
+        return g;
+    }
+#endif
+    return ORT_SQRT(x);
+}
+
 // ----------------------------------------------------------------------------
 // 3-vector algebra, src/vector_class.f90:48-186
 // ----------------------------------------------------------------------------
@@ -150,46 +200,56 @@ template <class T> __device__ inline VecT<T> vadd(VecT<T> a, VecT<T> b) { return
 template <class T> __device__ inline VecT<T> vscale(VecT<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
 template <class T> __device__ inline T vdot(VecT<T> a, VecT<T> b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
 template <class T> __device__ inline VecT<T> vselect(bool c, VecT<T> a, VecT<T> b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
-__device__ inline bool wave_any(bool p) { return __ballot(p) != 0ull; }
 
 // x/t, y/t, z/t — three IEEE-754 divisions by the same denominator — with the
 // reciprocal refinement done once.  This is the compiler's own fp64 division
 // sequence (v_div_scale / v_rcp / 2 Newton steps / v_div_fmas / v_div_fixup)
-// with the denominator-only half shared; it is taken only when v_div_scale
-// returns the same scaled denominator for all three numerators (always, outside
-// the subnormal/overflow corners), so each quotient is bit-for-bit `x / t`.
-// `need` marks the lanes whose quotient is used: only those can force the fallback.
-__device__ inline VecT<float> div3(VecT<float> v, float t, bool = true) { return {v.x / t, v.y / t, v.z / t}; }
-__device__ inline VecT<fastd> div3(VecT<fastd> v, fastd t, bool = true)
+// with the denominator-only half shared.  It applies when v_div_scale leaves the
+// denominator unscaled for every numerator (d_i == t: always, outside the
+// subnormal / overflow corners); then each quotient is bit-for-bit `x / t`.
+// v_div_scale returns NaN when an operand is zero or NaN: exactly the cases in which
+// v_div_fixup discards the iteration and forms the result from the operands' classes, so a
+// NaN d_i (an exactly-zero numerator: the x component of every cylinder normal) does not
+// break sharing — the test is the ORDERED `d_i <> t`.
+__device__ inline Vec div3_shared(Vec v, double t, bool &shared)
 {
-    const double r = rcp_nr2(t.v);
-    return {fastd(v.x.v * r), fastd(v.y.v * r), fastd(v.z.v * r)};
-}
-
-__device__ inline Vec div3(Vec v, double t, bool need = true)
-{
-#if defined(ORT_ABL_FASTDIV)
-    return {ORT_DIV(v.x, t), ORT_DIV(v.y, t), ORT_DIV(v.z, t)};
-#else
     bool f0, f1, f2, fd;
     const double d0 = __builtin_amdgcn_div_scale(v.x, t, false, &fd);
     const double d1 = __builtin_amdgcn_div_scale(v.y, t, false, &fd);
     const double d2 = __builtin_amdgcn_div_scale(v.z, t, false, &fd);
-    const bool shared = (d0 == d1) && (d0 == d2);
-    double r = __builtin_amdgcn_rcp(d0);
-    double e = __builtin_fma(-d0, r, 1.0);
+    shared = !(d0 < t || d0 > t) && !(d1 < t || d1 > t) && !(d2 < t || d2 > t);
+    double r = __builtin_amdgcn_rcp(t);
+    double e = __builtin_fma(-t, r, 1.0);
     r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d0, r, 1.0);
+    e = __builtin_fma(-t, r, 1.0);
     r = __builtin_fma(r, e, r);
     const double n0 = __builtin_amdgcn_div_scale(v.x, t, true, &f0);
     const double n1 = __builtin_amdgcn_div_scale(v.y, t, true, &f1);
     const double n2 = __builtin_amdgcn_div_scale(v.z, t, true, &f2);
     const double m0 = n0 * r, m1 = n1 * r, m2 = n2 * r;
     Vec q;
-    q.x = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-d0, m0, n0), r, m0, f0), t, v.x);
-    q.y = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-d0, m1, n1), r, m1, f1), t, v.y);
-    q.z = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-d0, m2, n2), r, m2, f2), t, v.z);
-    if (wave_any(need && !shared)) { // NaN or extreme exponents: plain divisions for those lanes
+    q.x = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-t, m0, n0), r, m0, f0), t, v.x);
+    q.y = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-t, m1, n1), r, m1, f1), t, v.y);
+    q.z = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(-t, m2, n2), r, m2, f2), t, v.z);
+    return q;
+}
+
+// the three quotients, self-contained (emitters): lanes where the shared form does not apply
+// divide plainly, behind a wave-uniform branch
+__device__ inline VecT<float> div3(VecT<float> v, float t) { return {v.x / t, v.y / t, v.z / t}; }
+__device__ inline VecT<fastd> div3(VecT<fastd> v, fastd t)
+{
+    const double r = rcp_nr2(t.v);
+    return {fastd(v.x.v * r), fastd(v.y.v * r), fastd(v.z.v * r)};
+}
+__device__ inline Vec div3(Vec v, double t)
+{
+#if defined(ORT_ABL_FASTDIV)
+    return {ORT_DIV(v.x, t), ORT_DIV(v.y, t), ORT_DIV(v.z, t)};
+#else
+    bool shared;
+    Vec q = div3_shared(v, t, shared);
+    if (wave_any(!shared)) {
         q.x = shared ? q.x : v.x / t;
         q.y = shared ? q.y : v.y / t;
         q.z = shared ? q.z : v.z / t;
@@ -199,15 +259,32 @@ __device__ inline Vec div3(Vec v, double t, bool need = true)
 }
 
 // magnitude_fn (:175-186): NORMALISES, by three divisions
-template <class T> __device__ inline VecT<T> vnormalise(VecT<T> a, bool need = true)
+template <class T> __device__ inline VecT<T> vnormalise(VecT<T> a)
 {
     T tmp = ORT_SQRT(a.x * a.x + a.y * a.y + a.z * a.z);
-    return div3(a, tmp, need);
+    return div3(a, tmp);
 }
-template <> __device__ inline VecT<fastd> vnormalise<fastd>(VecT<fastd> a, bool)
+template <> __device__ inline VecT<fastd> vnormalise<fastd>(VecT<fastd> a)
 {
     const double y = rsq_nr2((a.x * a.x + a.y * a.y + a.z * a.z).v);      // multiply by 1/|a| directly
     return {fastd(a.x.v * y), fastd(a.y.v * y), fastd(a.z.v * y)};
+}
+
+// the same at the hot sites: FILT (fp64) takes sqrt_f and the shared division and raises `rare`
+// for a lane that needs the result where either does not apply
+template <bool FILT, class T>
+__device__ inline VecT<T> vnormalise_f(VecT<T> a, bool need, bool &rare)
+{
+#if !defined(ORT_ABL_FASTDIV)
+    if constexpr (FILT && std::is_same<T, double>::value) {
+        const double tmp = sqrt_f<true, double>(a.x * a.x + a.y * a.y + a.z * a.z, need, rare);
+        bool shared;
+        const Vec q = div3_shared(a, tmp, shared);
+        ORT_RARE(1, need && !shared);
+        return q;
+    }
+#endif
+    return vnormalise(a);
 }
 
 template <class T> struct RayT { VecT<T> pos, dir; };
@@ -217,16 +294,19 @@ using Ray = RayT<double>;
 // Filtered predicates (FILT = true, the production setting).
 //
 // What only feeds a DECISION — reflect or refract (u <= R), inside the aperture,
-// which root of the quadratic, NA acceptance, which image bin — is first evaluated
-// with a cheap approximation whose error bound is orders of magnitude smaller than
-// the margin it is tested against; only when some lane of the wave lands inside
-// the margin (probability ~1e-10 per test, and always for the special cases: total
-// internal reflection, costt >= 1 at normal incidence, tangent rays, NaN) is the
-// reference's literal formula evaluated (wave-uniform branch) and used for those
-// lanes.  The decision taken is therefore always the reference's, and outcomes stay
-// bit-identical, while ~4 of the ~13 fp64 divide / square-root expansions per
-// surface leave the common path.  FILT = false evaluates every predicate literally
-// (kept for A/B and for tests).
+// which root of the quadratic, NA acceptance, which image bin — is evaluated with a
+// cheap approximation whose error bound is orders of magnitude smaller than the
+// margin it is tested against.  A lane that lands inside the margin (probability
+// ~1e-10 per test), and every special case (total internal reflection, costt >= 1 at
+// normal incidence, tangent rays, zero or non-finite operands), raises the per-lane
+// flag `rare` and carries on with an unspecified value.  The CALLER re-runs the whole
+// segment with FILT = false (the reference's literal formulas) for a wave in which any
+// lane raised the flag, and takes those lanes' results from that run.  The decision
+// taken is therefore always the reference's and outcomes stay bit-identical, while
+// the hot path holds no rare branch at all (having one behind every predicate cost
+// 14 % of the kernel time: each is a scheduling barrier plus scalar work) and ~4 of the
+// ~13 fp64 divide / square-root expansions per surface leave it.  FILT = false
+// evaluates every predicate literally (the redo path, A/B, tests).
 // ----------------------------------------------------------------------------
 // 1/y with relative error < 2^-40 for finite normal y: v_rcp_f64 seed + one Newton step
 __device__ inline double rcp_approx(double y)
@@ -290,38 +370,33 @@ template <> __device__ inline bool aperture_present<float>(float a)
 //   q < 0 : q/a < 0 ; hit <=> c/q >= 0 <=> c <= 0 -> t = c/q
 // ----------------------------------------------------------------------------
 template <bool FILT, class T>
-__device__ inline void solve_and_pick(T a, T b, T c, bool live, T &t, bool &hit)
+__device__ inline void solve_and_pick(T a, T b, T c, bool live, T &t, bool &hit, bool &rare)
 {
     static_assert(!FILT || sizeof(T) == 8, "filtered predicates are derived for fp64 only");
     const T discrim = b * b - T(4.0) * a * c;
     const bool neg = discrim < T(0.0);                // :243 — no real root
-    const T sq = ORT_SQRT(discrim);                   // NaN when neg: those lanes are misses
+    const T sq = sqrt_f<FILT, T>(discrim, live, rare); // NaN when neg: those lanes are misses
     const T q = T(-0.5) * (b + ((b > T(0.0)) ? sq : -sq));   // :249-253; b - sq == b + (-sq) exactly
-    bool ok = false;
-    t = T(0.0);
-    hit = false;
-    if (FILT) {
+    if constexpr (FILT) {
         const T bb = b * b;
-        ok = discrim > T(1e-10) * bb && a > T(1e-10) && a < T(1e10) && bb < T(1e200) &&
-             fabs(q) > T(1e-100) && (c == T(0.0) || fabs(c) > T(1e-200));
+        const bool ok = discrim > T(1e-10) * bb && a > T(1e-10) && a < T(1e10) && bb < T(1e200) &&
+                        fabs(q) > T(1e-100) && (c == T(0.0) || fabs(c) > T(1e-200));
         const bool qpos = q > T(0.0);
         const bool use_qa = qpos && (c < T(0.0));
         t = ORT_DIV(use_qa ? q : c, use_qa ? a : q);
-        hit = qpos || !(c > T(0.0));
-    }
-    const bool slow = !neg && !ok;                    // tangent, degenerate or NaN: literal formula
-    if (wave_any(live && slow)) {
+        hit = (qpos || !(c > T(0.0))) && !neg;
+        ORT_RARE(2, live && !neg && !ok);             // tangent, degenerate or NaN
+    } else {
         const bool dz = discrim == T(0.0);            // :245-247
         const T xd = T(-0.5) * b / a;
-        T t0 = dz ? xd : q / a;
-        T t1 = dz ? xd : c / q;
+        const T t0 = dz ? xd : q / a;
+        const T t1 = dz ? xd : c / q;
         const bool sw = t0 > t1;                      // :75-79
         const T lo = sw ? t1 : t0, hi = sw ? t0 : t1;
         const bool lneg = lo < T(0.0);                // :80-83
-        t = slow ? (lneg ? hi : lo) : t;
-        hit = slow ? !(lneg && hi < T(0.0)) : hit;
+        t = lneg ? hi : lo;
+        hit = !(lneg && hi < T(0.0)) && !neg;
     }
-    hit = hit && !neg;
 }
 
 // intersect_sphere (src/surfaces.f90:52-89) and intersect_cylinder (:91-130) in
@@ -329,7 +404,7 @@ __device__ inline void solve_and_pick(T a, T b, T c, bool live, T &t, bool &hit)
 // (a = dz^2+dy^2 etc. — fp addition commutes, so the sums are bit-identical).
 template <bool FILT, class T>
 __device__ inline void intersect_quadric(const RayT<T> &r, T cx, T cy, T cz, T radius,
-                                         bool cylinder, bool live, T &t, bool &hit)
+                                         bool cylinder, bool live, T &t, bool &hit, bool &rare)
 {
     T Lx = cylinder ? T(0.0) : r.pos.x - cx;
     T Ly = r.pos.y - cy;
@@ -338,13 +413,13 @@ __device__ inline void intersect_quadric(const RayT<T> &r, T cx, T cy, T cz, T r
     T a = (dx * dx) + (r.dir.y * r.dir.y) + (r.dir.z * r.dir.z);
     T b = T(2.0) * ((dx * Lx) + (r.dir.y * Ly) + (r.dir.z * Lz));
     T c = ((Lx * Lx) + (Ly * Ly) + (Lz * Lz)) - radius * radius;
-    solve_and_pick<FILT>(a, b, c, live, t, hit);
+    solve_and_pick<FILT>(a, b, c, live, t, hit, rare);
 }
 
 // intersect_ellipse, src/surfaces.f90:133-176
 template <bool FILT, class T>
 __device__ inline void intersect_ellipse(const RayT<T> &r, T cy, T cz, T semia, T semib,
-                                         bool live, T &t, bool &hit)
+                                         bool live, T &t, bool &hit, bool &rare)
 {
     T sa = T(1.) / (semia * semia);
     T sb = T(1.) / (semib * semib);
@@ -353,7 +428,7 @@ __device__ inline void intersect_ellipse(const RayT<T> &r, T cy, T cz, T semia, 
     T a = sa * (r.dir.z * r.dir.z) + sb * (r.dir.y * r.dir.y);
     T b = T(2) * (sa * r.dir.z * Lz + sb * r.dir.y * Ly);
     T c = sa * (Lz * Lz) + sb * (Ly * Ly) - T(1);
-    solve_and_pick<FILT>(a, b, c, live, t, hit);
+    solve_and_pick<FILT>(a, b, c, live, t, hit, rare);
 }
 
 // fresnel, src/surfaces.f90:336-372, as one expression (eta = n1/n2 rounded once on
@@ -375,30 +450,34 @@ __device__ inline T fresnel(T costt, T n1, T n2, T eta)
 // reflect_refract (src/surfaces.f90:262-282) with reflect (:285-300) and refract
 // (:303-333), predicated: the direction is committed where `live`.  The caller
 // supplies the uniform u and consumes the draw.  Returns true where the ray reflected.
-// FILT: R is only ever compared with u, so it is first formed with two approximate
+// FILT: R is only ever compared with u, so it is formed with two approximate
 // reciprocals and with refract's own c2 standing in for fresnel's cost2 (the same
 // quantity, rounded along another path; they differ by < 1e-13 once k > 1e-6).
 // |R' - R| < 1e-12, the margin is 1e-10.
 template <bool FILT, bool KEEP, class T>
-__device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta, T u, bool live)
+__device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta, T u, bool live, bool &rare)
 {
     const T c1s = vdot(N, I);                            // == vdot(I, N): the products commute
     const T c1 = fabs(c1s);                              // costt (fresnel) and |c1| (refract)
     const T k = T(1.0) - eta * eta * (T(1.0) - c1 * c1); // refract's radicand, refract's order (:327)
-    const T c2 = ORT_SQRT(k);                            // NaN beyond total reflection: unused there
-    bool reflected = false, decided = false;
+    const T c2 = sqrt_f<FILT, T>(k, false, rare);        // NaN beyond total reflection: unused there
+    bool reflected;
     if constexpr (FILT) {
         T a1 = n1 * c1, b1 = n2 * c2, a2 = n1 * c2, b2 = n2 * c1;
         T f1 = (a1 - b1) * rcp_approx(a1 + b1);
         T f2 = (a2 - b2) * rcp_approx(a2 + b2);
         T R = T(0.5) * (f1 * f1 + f2 * f2);
-        // NaN anywhere -> undecided; c1 >= 1, k ~ 0 or < 0 (total reflection) -> literal path
-        decided = (k > T(1e-6)) && (c1 < T(1.0)) && (fabs(u - R) > T(1e-10));
-        reflected = u < R;
-    }
-    if (wave_any(live && !decided)) {
-        bool rl = u <= fresnel(c1, n1, n2, eta);         // :275
-        reflected = decided ? reflected : rl;
+        // Total internal reflection is an everyday outcome at the rim of the plano-convex lens
+        // (6 % of the ring rays): k < -1e-6 means eta^2 (1 - c1^2) > 1 + 1e-6, so fresnel's
+        // `sint2 > 1` (:353) holds whatever its rounding and it returns 1: u <= 1 reflects.
+        // (R is NaN there and is not consulted.)  NaN anywhere else -> undecided; c1 >= 1 and
+        // k within 1e-6 of zero -> literal path.
+        const bool tir = k < T(-1e-6);
+        const bool decided = (c1 < T(1.0)) && (tir || ((k > T(1e-6)) && (fabs(u - R) > T(1e-10))));
+        reflected = tir || (u < R);
+        ORT_RARE(3, live && !decided);
+    } else {
+        reflected = u <= fresnel(c1, n1, n2, eta);       // :275
     }
     // Both outcomes are I*alpha + N*beta, bit for bit:
     //   reflect (:297)      I - (2 c1s) N         = I*1   + N*(-(2 c1s))     (x*1 and a + (-b) are exact)
@@ -415,27 +494,30 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
 // aperture test `sqrt(x^2+y^2) > A` (lens.f90:450-454, :576-580, :559-563): decided on
 // the squares unless they agree to 1e-12 (then the reference's square root is taken)
 template <bool FILT, class T>
-__device__ inline bool outside_aperture(T x, T y, T A, bool live)
+__device__ inline bool outside_aperture(T x, T y, T A, bool live, bool &rare)
 {
     const T s2 = x * x + y * y;
-    const T A2 = A * A;
-    bool out = s2 > A2;
-    const bool near = FILT ? !(fabs(s2 - A2) > T(1e-12) * A2) : true;
-    if (wave_any(live && near)) out = near ? (ORT_SQRT(s2) > A) : out;
-    return out;
+    if constexpr (FILT) {
+        const T A2 = A * A;
+        ORT_RARE(4, live && !(fabs(s2 - A2) > T(1e-12) * A2));
+        return s2 > A2;
+    } else {
+        return ORT_SQRT(s2) > A;
+    }
 }
 
 // ----------------------------------------------------------------------------
 // In-bottle scattering: tauint (src/surfaces.f90:13-50), the
 // Henyey-Greenstein direction update `stokes` (src/stokes.f90:7-166, hgg /= 0 at both call
 // sites) and the random walk of src/lens.f90:262-282 / :312-333 — all predicated: `on` marks
-// the lanes still walking; every draw is consumed only by those lanes.
+// the lanes still walking; every draw is consumed only by those lanes.  Always literal
+// (no filtered predicates inside the walk).
 // ----------------------------------------------------------------------------
 template <class T> __device__ inline void sincos_t(T x, T *s, T *c);
 
 // one leg: optical depth tau = -log(u) against the distance to the cylinder wall.
 // ok = false is the reference's `error stop "no intersection"`.
-template <bool FILT, class T, class D>
+template <class T, class D>
 __device__ inline void tauint(const RayT<T> &r, T mua, T mus, T cy, T cz, T radius, bool on, D &draws,
                               T &dist, bool &at_wall, bool &ok, int &nis)
 {
@@ -445,7 +527,8 @@ __device__ inline void tauint(const RayT<T> &r, T mua, T mus, T cy, T cz, T radi
     const T tau = -log(u);
     T d;
     bool hit;
-    intersect_quadric<FILT, T>(r, T(0.), cy, cz, radius, true, on, d, hit);
+    bool unused = false;
+    intersect_quadric<false, T>(r, T(0.), cy, cz, radius, true, on, d, hit, unused);
     nis += on ? 1 : 0;
     const T tauradius = d * mu_tot;
     const bool inside = tau < tauradius;
@@ -501,13 +584,13 @@ __device__ inline void stokes_hg(VecT<T> &dir, T hgg, T twopi, bool on, D &draws
 // walk of lens.f90:262-282 / :312-333.  `t` enters as the distance to the wall (from the
 // surface's own intersection) and leaves as the length of the last leg; lanes that end here get
 // `ended` = ORT_ST_LOST_BOTTLE (absorbed / heading back) or ORT_ST_NO_INTERSECTION.
-template <bool FILT, class T, class Surf, class D>
+template <class T, class Surf, class D>
 __device__ inline void scatter_walk(const Surf &s, T twopi, RayT<T> &r, T &t, bool on, D &draws, int &nis,
                                     int &ended)
 {
     T dist;
     bool at_wall, ok;
-    tauint<FILT, T>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, on, draws, dist, at_wall, ok, nis);
+    tauint<T>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, on, draws, dist, at_wall, ok, nis);
     ended = (on && !ok) ? ORT_ST_NO_INTERSECTION : ended;
     t = on ? dist : t;
     bool alive = on && ok;                               // not yet ended inside the walk
@@ -522,7 +605,7 @@ __device__ inline void scatter_walk(const Surf &s, T twopi, RayT<T> &r, T &t, bo
         alive = alive && !absorbed;
         walking = walking && !absorbed;
         stokes_hg<T>(r.dir, s.hgg, twopi, walking, draws);
-        tauint<FILT, T>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, walking, draws, dist, at_wall, ok, nis);
+        tauint<T>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, walking, draws, dist, at_wall, ok, nis);
         const bool lostw = walking && !ok;
         ended = lostw ? ORT_ST_NO_INTERSECTION : ended;
         alive = alive && !lostw;
@@ -628,7 +711,8 @@ __device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws)
     RayT<T> drop = {{tmp1, tmp2, T(1.0)}, {T(0.), T(0.), T(-1.)}};
     T t;
     bool hit;
-    intersect_quadric<false, T>(drop, T(0.), S.crs_cy, S.crs_cz, S.crs_radius, true, true, t, hit);
+    bool unused = false;
+    intersect_quadric<false, T>(drop, T(0.), S.crs_cy, S.crs_cz, S.crs_radius, true, true, t, hit, unused);
     t = hit ? t : T(0.);                                   // the reference leaves t undefined on a miss
     r.pos = vadd(drop.pos, vscale(drop.dir, t));
     r.dir = {sint * cosp, sint * sinp, cost};
@@ -701,38 +785,32 @@ __device__ inline bool emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint6
 // `if(angle > na) return` does with a NaN angle.  Returns the ORT_ST_* status.
 // ----------------------------------------------------------------------------
 template <bool FILT, class T, class Sys>
-__device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int &xp, int &yp)
+__device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int &xp, int &yp, bool &rare)
 {
-    bool na_decided = false, reject = false;
+    bool reject;
+    T fx, fy;
     if constexpr (FILT) {
         // x = dir_z / |dir| up to 1e-13; the literal form below rounds it five more times
-        T xa = r.dir.z * rsq_approx(vdot(r.dir, r.dir));
-        na_decided = fabs(xa - T(S.na_cos_min)) > T(1e-10);
+        const T xa = r.dir.z * rsq_approx(vdot(r.dir, r.dir));
         reject = xa < T(S.na_cos_min);
-    }
-    if (wave_any(live && !na_decided)) {
-        VecT<T> d = vnormalise(r.dir);
-        d = vscale(d, T(-1.));
-        T top = (T(0.) * d.x) + (T(0.) * d.y) + (T(-1.) * d.z);
-        T bottom = ORT_SQRT(vdot(d, d)) * T(1.0);
-        bool rl = (top / bottom) < T(S.na_cos_min);
-        reject = na_decided ? reject : rl;
-    }
-    T fx = T(0.), fy = T(0.);
-    bool bin_decided = false;
-    if constexpr (FILT) {
         // floor(x / binwid) from one multiply unless the quotient is within 1e-6 of an integer
         // (|q * 2.3e-16| < 1e-9 for |q| < 4e6)
-        T qx = r.pos.x * T(S.inv_bin_width), qy = r.pos.y * T(S.inv_bin_width);
+        const T qx = r.pos.x * T(S.inv_bin_width), qy = r.pos.y * T(S.inv_bin_width);
         fx = floor(qx); fy = floor(qy);
-        T gx = qx - fx, gy = qy - fy;
-        bin_decided = gx > T(1e-6) && gx < T(1. - 1e-6) && gy > T(1e-6) && gy < T(1. - 1e-6) &&
-                      fabs(qx) < T(1e6) && fabs(qy) < T(1e6);
-    }
-    if (wave_any(live && !reject && !bin_decided)) {
-        T lx = floor(r.pos.x / T(S.bin_width)), ly = floor(r.pos.y / T(S.bin_width));
-        fx = bin_decided ? fx : lx;
-        fy = bin_decided ? fy : ly;
+        const T gx = qx - fx, gy = qy - fy;
+        const bool na_decided = fabs(xa - T(S.na_cos_min)) > T(1e-10);
+        const bool bin_decided = gx > T(1e-6) && gx < T(1. - 1e-6) && gy > T(1e-6) && gy < T(1. - 1e-6) &&
+                                 fabs(qx) < T(1e6) && fabs(qy) < T(1e6);
+        ORT_RARE(5, live && !na_decided);
+        ORT_RARE(6, live && !reject && !bin_decided);
+    } else {
+        VecT<T> d = vnormalise(r.dir);
+        d = vscale(d, T(-1.));
+        const T top = (T(0.) * d.x) + (T(0.) * d.y) + (T(-1.) * d.z);
+        const T bottom = ORT_SQRT(vdot(d, d)) * T(1.0);
+        reject = (top / bottom) < T(S.na_cos_min);
+        fx = floor(r.pos.x / T(S.bin_width));
+        fy = floor(r.pos.y / T(S.bin_width));
     }
     const bool off = (r.pos.x > T(1000) || r.pos.y > T(1000)) ||            // :48
                      !(fabs(fx) <= T(200.)) || !(fabs(fy) <= T(200.));       // :52
@@ -757,7 +835,7 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
 // st/xp/yp/nis of such lanes); KEEP = true freezes r where the ray ended (debug / tracker output).
 template <bool FILT, class T, bool EXT, bool KEEP = true, class Sys, class Surf, class D>
 __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &draws,
-                                    int &nis, int &st, int &xp, int &yp)
+                                    int &nis, int &st, int &xp, int &yp, bool &rare)
 {
     const bool live = st < 0;
     const int kind = __builtin_amdgcn_readfirstlane(s.kind);
@@ -772,19 +850,19 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
         T t;
         bool hit;
         const bool cyl = kind != ORT_SURF_SPHERE;
-        if (kind == ORT_SURF_ELLIPSE) intersect_ellipse<FILT, T>(r, s.cy, s.cz, s.radius, s.radius_b, live, t, hit);
-        else intersect_quadric<FILT, T>(r, s.cx, s.cy, s.cz, s.radius, cyl, live, t, hit);
+        if (kind == ORT_SURF_ELLIPSE) intersect_ellipse<FILT, T>(r, s.cy, s.cz, s.radius, s.radius_b, live, t, hit, rare);
+        else intersect_quadric<FILT, T>(r, s.cx, s.cy, s.cz, s.radius, cyl, live, t, hit, rare);
         int walk_end = -1;
         if (EXT && (flags & ORT_F_SCATTER)) {               // wave-uniform
-            scatter_walk<FILT, T>(s, S.twopi, r, t, live && hit, draws, nis, walk_end);
+            scatter_walk<T>(s, S.twopi, r, t, live && hit && !rare, draws, nis, walk_end);
             hit = hit && walk_end < 0;
         }
         const VecT<T> moved = vadd(r.pos, vscale(r.dir, t));
         r.pos = KEEP ? vselect(live && hit, moved, r.pos) : moved;
         bool out = false;
-        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, live && hit);
+        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, live && hit, rare);
         // normal = centre - pos, with orig%x = centre%x for the bottle (lens.f90:288-290)
-        N = vnormalise(VecT<T>{cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z}, live && hit);
+        N = vnormalise_f<FILT, T>(VecT<T>{cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z}, live && hit, rare);
         ended = !hit ? ((flags & ORT_F_MISS_IS_HELP3) ? ORT_ST_HELP3 : lost) : (out ? lost : -1);
         ended = walk_end >= 0 ? walk_end : ended;
         proceed = live && hit && !out;
@@ -794,12 +872,12 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
         const VecT<T> moved = vadd(r.pos, vscale(r.dir, d));
         if (kind == ORT_SURF_IMAGE) {
             r.pos = KEEP ? vselect(live, moved, r.pos) : moved;
-            const int ist = make_image<FILT, T>(S, r, live, xp, yp);
+            const int ist = make_image<FILT, T>(S, r, live, xp, yp, rare);
             st = live ? ist : st;
             return;
         }
         bool out = false;
-        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, live);
+        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, live, rare);
         if (kind == ORT_SURF_IRIS) {
             if (KEEP) r.pos = vselect(live && out, moved, r.pos);   // pos = origpos unless lost (lens.f90:564, :643)
             st = (live && out) ? lost : st;
@@ -812,7 +890,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
     }
     const T u = draws.template peek_as<T>();
     draws.advance(proceed);
-    const bool reflected = reflect_refract<FILT, KEEP, T>(r.dir, N, s.n1, s.n2, s.eta, u, proceed);
+    const bool reflected = reflect_refract<FILT, KEEP, T>(r.dir, N, s.n1, s.n2, s.eta, u, proceed, rare);
     const bool dies = reflected && (flags & ORT_F_SKIP_ON_REFLECT);
     st = live ? (proceed ? (dies ? lost : -1) : ended) : st;
 }

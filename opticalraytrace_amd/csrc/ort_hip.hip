@@ -138,12 +138,49 @@ __global__ __launch_bounds__(256) void fold_kernel(int32_t *image, int32_t *repl
 // predicate; the loop leaves as soon as no lane of the wave is alive (uniform branch).
 // KEEP: see surface_step — false where only st/xp/yp/nis of an ended ray are read afterwards.
 template <bool FILT, class T, bool EXT, bool KEEP, class Sys, class Surf, class D>
-__device__ inline void walk(const Sys &S, const Surf *surf, int k0, int k1, RayT<T> &r, D &draws,
-                            int &nis, int &st, int &xp, int &yp)
+__device__ inline void walk_pass(const Sys &S, const Surf *surf, int k0, int k1, RayT<T> &r, D &draws,
+                                 int &nis, int &st, int &xp, int &yp, bool &rare)
 {
     for (int k = k0; k < k1; ++k) {
         if (!wave_any(st < 0)) break;
-        surface_step<FILT, T, EXT, KEEP>(S, surf[k], r, draws, nis, st, xp, yp);
+#ifdef ORT_DBG_RARE
+        const bool before = rare;
+#endif
+        surface_step<FILT, T, EXT, KEEP>(S, surf[k], r, draws, nis, st, xp, yp, rare);
+#ifdef ORT_DBG_RARE
+        if (rare && !before && k < 8) atomicAdd(&ort::ort_dbg_rare[8 + k], 1ull);   // first raise, by surface
+#endif
+    }
+}
+
+// The segment [k0, k1) with the reference's outcome for every lane.  FILT: one pass with the
+// filtered predicates; if any lane raised `rare` (ort_device.h) the wave runs the segment again
+// from its initial state — `restore(r, draws, st)` re-creates it: reloaded or re-emitted, so no
+// register is held for it through the hot pass — with the literal formulas, and the flagged
+// lanes take that run's results.  One rare branch per segment instead of one per predicate.
+template <bool FILT, class T, bool EXT, bool KEEP, class Sys, class Surf, class D, class Restore>
+__device__ inline void walk(const Sys &S, const Surf *surf, int k0, int k1, RayT<T> &r, D &draws,
+                            int &nis, int &st, int &xp, int &yp, Restore restore)
+{
+    bool rare = false;
+    if constexpr (!FILT) {
+        walk_pass<false, T, EXT, KEEP>(S, surf, k0, k1, r, draws, nis, st, xp, yp, rare);
+    } else {
+        const int nis0 = nis, xp0 = xp, yp0 = yp;
+        walk_pass<true, T, EXT, KEEP>(S, surf, k0, k1, r, draws, nis, st, xp, yp, rare);
+        if (wave_rare(rare)) {
+            RayT<T> r2;
+            D d2 = draws;
+            int st2, nis2 = nis0, xp2 = xp0, yp2 = yp0;
+            bool unused = false;
+            restore(r2, d2, st2);
+            walk_pass<false, T, EXT, KEEP>(S, surf, k0, k1, r2, d2, nis2, st2, xp2, yp2, unused);
+            r.pos = vselect(rare, r2.pos, r.pos);
+            r.dir = vselect(rare, r2.dir, r.dir);
+            draws.take(rare, d2);
+            nis = rare ? nis2 : nis; st = rare ? st2 : st;
+            xp = rare ? xp2 : xp; yp = rare ? yp2 : yp;
+        }
     }
 }
 
@@ -199,20 +236,28 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
                 for (int k = 0; k < ns; ++k) {
                     if (!wave_any(st < 0)) break;
                     const bool was_live = st < 0;
-                    surface_step<FILT, T, true>(S, surf[k], r, d, nis, st, xp, yp);
+                    bool unused = false;                 // the tracker walks with the literal predicates
+                    surface_step<false, T, true>(S, surf[k], r, d, nis, st, xp, yp, unused);
                     const bool track = (__builtin_amdgcn_readfirstlane((int)surf[k].flags) & ORT_F_TRACK) != 0;
                     push(was_live && (st >= 0 || track));   // where it ended, or a tracked surface passed alive
                 }
                 if (act) a.npath[ic] = np;
             } else {
-                walk<FILT, T, ANYSRC, true>(S, surf, 0, ns, r, d, nis, st, xp, yp);
+                const Draws d0 = d;
+                const int st0 = st;
+                walk<FILT, T, ANYSRC, true>(S, surf, 0, ns, r, d, nis, st, xp, yp,
+                                            [&](RayT<T> &rr, Draws &dd, int &ss) { rr = em; dd = d0; ss = st0; });
             }
             kdraws = d.k;
         } else {
             KeyedDraws d;
             d.init_keyed(a.rng_base, a.first_ray + ic, have_in ? a.draw_base : 0);
             if (!have_in && !emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
-            walk<FILT, T, ANYSRC, false>(S, surf, 0, ns, r, d, nis, st, xp, yp);
+            const RayT<T> r0 = r;
+            const KeyedDraws d0 = d;
+            const int st0 = st;
+            walk<FILT, T, ANYSRC, false>(S, surf, 0, ns, r, d, nis, st, xp, yp,
+                                         [&](RayT<T> &rr, KeyedDraws &dd, int &ss) { rr = r0; dd = d0; ss = st0; });
         }
         if (!act) continue;
         if (MODE == MODE_DEBUG) {
@@ -325,16 +370,23 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
             const int slot = (qhead + lane) & (kQueueCap - 1);
             qhead = (qhead + m) & (kQueueCap - 1);
             qcount -= m;
-            RayT<T> r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}};
+            // a queued ray: also how the literal re-run gets its initial state back (the slot is
+            // not overwritten before the next push)
+            auto load = [&](RayT<T> &rr, KeyedDraws &dd, int &ss) {
+                rr = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}};
+                dd.z = 0;
+                if (act) {
+                    rr.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
+                    rr.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
+                    dd.z = (uint64_t)__double_as_longlong(q[6][slot]);
+                }
+                ss = act ? -1 : ORT_ST_NA_REJECT;
+            };
+            RayT<T> r;
             KeyedDraws d;
-            d.z = 0;
-            if (act) {
-                r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
-                r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
-                d.z = (uint64_t)__double_as_longlong(q[6][slot]);
-            }
-            int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
-            walk<FILT, T, ANYSRC, false>(S, surf, split, ns, r, d, nis, st, xp, yp);
+            int nis = 0, xp = 0, yp = 0, st;
+            load(r, d, st);
+            walk<FILT, T, ANYSRC, false>(S, surf, split, ns, r, d, nis, st, xp, yp, load);
             if (act) finish(st, nis, xp, yp);
             __builtin_amdgcn_wave_barrier();
         } else if (have_new) {
@@ -343,20 +395,26 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
             const bool act = i < hi;
             next += 64;
             const uint64_t ic = act ? i : hi - 1;        // clamped: idle lanes recompute the last ray, unused
+            // a fresh ray: read from the resident bundle or emitted from its key; the literal
+            // re-run starts from the same call
+            auto fresh = [&](RayT<T> &rr, KeyedDraws &dd, int &ss) {
+                ss = act ? -1 : ORT_ST_NA_REJECT;
+                if (MODE == MODE_RESIDENT) {
+                    dd.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
+                    rr.pos = {T(a.pos_dir_in[0 * n + ic]), T(a.pos_dir_in[1 * n + ic]), T(a.pos_dir_in[2 * n + ic])};
+                    rr.dir = {T(a.pos_dir_in[3 * n + ic]), T(a.pos_dir_in[4 * n + ic]), T(a.pos_dir_in[5 * n + ic])};
+                } else {
+                    dd.init_keyed(a.rng_base, a.first_ray + ic, 0);
+                    if (!emit<T, ANYSRC>(S, a.phase, rr, dd, a.first_ray + ic, a.img_cdf)) ss = ORT_ST_LOST_TELESCOPE;
+                }
+            };
             RayT<T> r;
             KeyedDraws d;
-            int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
-            if (MODE == MODE_RESIDENT) {
-                d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
-                r.pos = {T(a.pos_dir_in[0 * n + ic]), T(a.pos_dir_in[1 * n + ic]), T(a.pos_dir_in[2 * n + ic])};
-                r.dir = {T(a.pos_dir_in[3 * n + ic]), T(a.pos_dir_in[4 * n + ic]), T(a.pos_dir_in[5 * n + ic])};
-            } else {
-                d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                if (!emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
-            }
-            walk<FILT, T, ANYSRC, false>(S, surf, 0, split, r, d, nis, st, xp, yp);
+            int nis = 0, xp = 0, yp = 0, st;
+            fresh(r, d, st);
+            walk<FILT, T, ANYSRC, false>(S, surf, 0, split, r, d, nis, st, xp, yp, fresh);
             const bool survive = act && st < 0;
-            const unsigned long long mask = __ballot(survive);
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(survive);
             if (survive) {
                 const int slot = (qhead + qcount + lane_prefix(mask)) & (kQueueCap - 1);
                 q[0][slot] = (double)r.pos.x; q[1][slot] = (double)r.pos.y; q[2][slot] = (double)r.pos.z;
@@ -874,3 +932,11 @@ int ort_last_kernel_ms(ort_ctx *c, int kind, float *ms)
 }
 
 }  // extern "C"
+
+#ifdef ORT_DBG_RARE
+// development build only: per-site counts of raised `rare` flags since the library was loaded
+extern "C" int ort_debug_rare(unsigned long long out[16])
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ort::ort_dbg_rare), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

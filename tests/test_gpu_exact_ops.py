@@ -1,0 +1,23 @@
+"""The hand-expanded fp64 operations of csrc/ort_device.h (square root without range scaling, three
+divisions sharing one reciprocal) against the compiler's IEEE operations, bit for bit, on the GPU.
+The checker is tests/csrc/check_exact_ops.hip, built by __graft_entry__.build() / the csrc Makefile
+into build/check_exact_ops."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "build", "check_exact_ops")
+
+
+@pytest.mark.gpu
+def test_expanded_sqrt_and_division_are_bit_identical():
+    if not os.path.exists(EXE):
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "opticalraytrace_amd", "csrc"), "check"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("mode")]
+    assert len(lines) == 2 and all("mismatches sqrt 0 div3 0 normalise 0" in ln for ln in lines), out.stdout

@@ -384,3 +384,40 @@ def test_scattering_bottle_vs_oracle(ctxs, name):
     orc.trace(2, 0, n, SEED, wimg, wc)
     assert np.abs(img.astype(np.int64) - wimg).sum() <= 8
     assert np.abs(cnt.astype(np.int64) - wc.astype(np.int64)).max() <= 8
+
+@pytest.mark.parametrize("name", ["large", "small_iris_after", "ellipse"])
+def test_bulk_kernels_rerun_flagged_rays_literally(ctxs, name):
+    """The bulk kernels re-run a segment with the literal formulas for a wave in which a lane sat
+    on a decision boundary.  A resident bundle that mixes the boundary rays (every one raises
+    the flag somewhere) into ordinary rays must give the same image and counters in every
+    kernel variant — queued/lockstep x filtered/literal — and the oracle's image."""
+    import torch
+    osys, ctx = ctxs(name)
+    orc = _oracle(osys)
+    a, _ = _special_rays(osys)
+    n = 20000
+    rng = np.random.default_rng(5)
+    for phase in (2, 1):
+        ctx.set_kernel_variant(1)
+        em = ctx.trace_rays(phase, n, first_ray=0, seed=SEED)["emitted"]        # ordinary rays of this phase
+        pos = rng.integers(0, n, a.shape[1])
+        bundle_h = em.copy()
+        bundle_h[:, pos] = a                                                   # boundary rays scattered over the waves
+        bundle = torch.from_numpy(bundle_h).to("cuda:0")
+        want = orc.trace_rays(phase, n, pos_dir_in=bundle_h, seed=SEED, first_ray=0, draw_base=3)
+        img_want = np.zeros((401, 401), dtype=np.int64)
+        b = want["status"] == 0
+        np.add.at(img_want, (want["bin_xy"][1][b] + 200, want["bin_xy"][0][b] + 200), 1)
+        results = []
+        for variant in (1, 0, 3, 2):
+            ctx.set_kernel_variant(variant)
+            ctx.reset()
+            ctx.trace_resident(phase, 0, n, SEED, 3, bundle.data_ptr())
+            ctx.synchronize()
+            results.append(ctx.read())
+        ctx.set_kernel_variant(1)
+        img0, cnt0 = results[0]
+        for img, cnt in results[1:]:
+            assert np.array_equal(img, img0) and np.array_equal(cnt, cnt0)
+        assert np.array_equal(img0[phase - 1].astype(np.int64), img_want)
+        assert int(cnt0[2 + (phase - 1)]) == int(want["n_isect"].sum())
