@@ -48,6 +48,12 @@ __host__ __device__ inline uint64_t stream_base(uint64_t seed, int phase)
     return mix64(seed ^ (kGolden * (uint64_t)phase));
 }
 
+// the global ray index back from a draw counter z = base + GOLDEN*((ray<<24) + k), k < 2^24:
+// GOLDEN is odd, so it has an inverse modulo 2^64
+constexpr uint64_t kGoldenInv = 0xF1DE83E19937733Dull;
+static_assert(kGolden * kGoldenInv == 1ull, "kGoldenInv must invert kGolden modulo 2^64");
+__host__ __device__ inline uint64_t ray_of_counter(uint64_t z, uint64_t base) { return ((z - base) * kGoldenInv) >> 24; }
+
 // top 53 bits of x as a double in [0,1) = (double)(x >> 11) * 2^-53, exactly, without the
 // quarter-rate int->fp64 conversions: 2^84 + hi*2^32 and 2^52 + lo are built from bits
 // (0x453.. / 0x433.. exponent words), their difference from (2^84 + 2^52) is the exact
@@ -793,14 +799,15 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
         // x = dir_z / |dir| up to 1e-13; the literal form below rounds it five more times
         const T xa = r.dir.z * rsq_approx(vdot(r.dir, r.dir));
         reject = xa < T(S.na_cos_min);
-        // floor(x / binwid) from one multiply unless the quotient is within 1e-6 of an integer
-        // (|q * 2.3e-16| < 1e-9 for |q| < 4e6)
+        // floor(x / binwid) from one multiply.  |q| > 1e3: off the +-200 grid whatever the rounding.
+        // Otherwise the product and the quotient differ by < 1e3 * 4.4e-16, so floor agrees unless q
+        // is within 1e-9 of an integer.
         const T qx = r.pos.x * T(S.inv_bin_width), qy = r.pos.y * T(S.inv_bin_width);
         fx = floor(qx); fy = floor(qy);
         const T gx = qx - fx, gy = qy - fy;
         const bool na_decided = fabs(xa - T(S.na_cos_min)) > T(1e-10);
-        const bool bin_decided = gx > T(1e-6) && gx < T(1. - 1e-6) && gy > T(1e-6) && gy < T(1. - 1e-6) &&
-                                 fabs(qx) < T(1e6) && fabs(qy) < T(1e6);
+        const bool far = fabs(qx) > T(1e3) || fabs(qy) > T(1e3);
+        const bool bin_decided = far || (gx > T(1e-9) && gx < T(1. - 1e-9) && gy > T(1e-9) && gy < T(1. - 1e-9));   // NaN: undecided
         ORT_RARE(5, live && !na_decided);
         ORT_RARE(6, live && !reject && !bin_decided);
     } else {

@@ -41,6 +41,8 @@ constexpr int kBlock = 256;
 constexpr int kTimingRing = 64;         // launches kept by ort_kernel_times
 constexpr int kReplicas = 8;            // image replicas, one per XCD-sized group of workgroups
 constexpr int kMaxBlocks = 256 * 8;     // 256 CUs x 8 workgroups: >> 256 workgroups fills all 8 XCDs
+constexpr uint64_t kChunkRays = 1ull << 25;   // rays per launch of the queued kernel (bounds the re-run list: 4 B per ray)
+constexpr int kRedoBlocks = 128;        // grid of the literal re-run kernel (it normally finds an empty list and returns)
 
 enum { MODE_FUSED = 0, MODE_RESIDENT = 1, MODE_DEBUG = 2 };
 
@@ -51,8 +53,14 @@ struct TraceArgs {
     unsigned long long *counters;
     uint64_t first_ray, n_rays, rng_base;
     int phase, draw_base;
+    // the re-run list of the queued filtered kernel (see trace_queue_kernel): ray indices relative
+    // to first_ray; ctl[0] = entries, ctl[1] = workgroups of the re-run kernel that are done
+    uint32_t *redo_list;
+    unsigned int *redo_ctl;
+    int listed;                  // trace_kernel: iterate redo_list instead of [0, n_rays)
     // resident / debug inputs
-    const double *pos_dir_in;    // SoA [6][n] or null
+    uint64_t in_stride;          // component stride of pos_dir_in (the bundle's ray count)
+    const double *pos_dir_in;    // SoA [6][in_stride] or null
     const double *u;             // [nu][n] or null
     int nu;
     // debug outputs (any may be null)
@@ -134,6 +142,9 @@ __global__ __launch_bounds__(256) void fold_kernel(int32_t *image, int32_t *repl
     }
 }
 
+#ifdef ORT_ABL_NOREDO
+namespace ort { __device__ unsigned long long abl_sink; }
+#endif
 // One lockstep pass of a wave over surfaces [k0, k1): every lane steps with its `st`
 // predicate; the loop leaves as soon as no lane of the wave is alive (uniform branch).
 // KEEP: see surface_step — false where only st/xp/yp/nis of an ended ray are read afterwards.
@@ -168,7 +179,12 @@ __device__ inline void walk(const Sys &S, const Surf *surf, int k0, int k1, RayT
     } else {
         const int nis0 = nis, xp0 = xp, yp0 = yp;
         walk_pass<true, T, EXT, KEEP>(S, surf, k0, k1, r, draws, nis, st, xp, yp, rare);
+#ifdef ORT_ABL_NOREDO
+        if (wave_rare(rare)) { if (rare) atomicAdd(&ort::abl_sink, 1ull); }
+        if (false) {
+#else
         if (wave_rare(rare)) {
+#endif
             RayT<T> r2;
             D d2 = draws;
             int st2, nis2 = nis0, xp2 = xp0, yp2 = yp0;
@@ -190,6 +206,9 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
 {
     __shared__ typename SysTypes<T>::Sys S;
     __shared__ unsigned int blk[4];       // lost, isect, binned, help3
+    // the re-run launch normally finds its list empty (no workgroup appends while it runs, so
+    // every workgroup reads the same count)
+    if (MODE != MODE_DEBUG && a.listed && a.redo_ctl[0] == 0) return;
     stage_system(S, a.sys);
     if (MODE != MODE_DEBUG) {
         if (threadIdx.x < 4) blk[threadIdx.x] = 0;
@@ -198,22 +217,28 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
     unsigned int lost = 0, isect = 0, binned = 0, help3 = 0;
     int32_t *layer = hist_layer(a);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t n = a.n_rays;
+    // listed: the rays to trace are the entries of the re-run list (the queued filtered kernel
+    // appended the rays that sat on a decision boundary); otherwise all of [0, n_rays)
+    const bool listed = MODE != MODE_DEBUG && a.listed;
+    const uint64_t n = listed ? (uint64_t)a.redo_ctl[0] : a.n_rays;
+    const uint64_t ns_in = a.in_stride;                  // component stride of the input bundle
 
     const int ns = S.n_surfaces[a.phase - 1];
     const typename SysTypes<T>::Surf *surf = S.surfaces[a.phase - 1];
     // whole waves iterate together (the tail wave keeps its out-of-range lanes dead)
     const uint64_t base0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ull;
     for (uint64_t wbase = base0; wbase < n; wbase += stride) {
-        const uint64_t i = wbase + (threadIdx.x & 63);
-        const bool act = i < n;
-        const uint64_t ic = act ? i : n - 1;             // clamped index for loads of idle lanes
+        const uint64_t j = wbase + (threadIdx.x & 63);
+        const bool act = j < n;
+        const uint64_t jc = act ? j : n - 1;             // clamped index for loads of idle lanes
+        const uint64_t ic = listed ? (uint64_t)a.redo_list[jc] : jc;
+        const uint64_t i = ic;                           // output index (debug entry: never listed)
         RayT<T> r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}}, em;
         int nis = 0, xp = -9999, yp = -9999, st = act ? -1 : ORT_ST_NA_REJECT;
         const bool have_in = MODE != MODE_FUSED && a.pos_dir_in;
         if (have_in) {
-            r.pos = {(T)a.pos_dir_in[0 * n + ic], (T)a.pos_dir_in[1 * n + ic], (T)a.pos_dir_in[2 * n + ic]};
-            r.dir = {(T)a.pos_dir_in[3 * n + ic], (T)a.pos_dir_in[4 * n + ic], (T)a.pos_dir_in[5 * n + ic]};
+            r.pos = {(T)a.pos_dir_in[0 * ns_in + ic], (T)a.pos_dir_in[1 * ns_in + ic], (T)a.pos_dir_in[2 * ns_in + ic]};
+            r.dir = {(T)a.pos_dir_in[3 * ns_in + ic], (T)a.pos_dir_in[4 * ns_in + ic], (T)a.pos_dir_in[5 * ns_in + ic]};
         }
         int kdraws = 0;
         if (MODE == MODE_DEBUG) {
@@ -292,6 +317,12 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
         __syncthreads();
         if (threadIdx.x < 4 && blk[threadIdx.x])
             atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
+        // the last workgroup to finish leaves the list empty for the next launch (every workgroup
+        // has read ctl[0] before it counts itself done)
+        if (listed && threadIdx.x == 0 && atomicAdd(&a.redo_ctl[1], 1u) == gridDim.x - 1) {
+            a.redo_ctl[0] = 0;
+            a.redo_ctl[1] = 0;
+        }
     }
 }
 
@@ -306,6 +337,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
 // although rays die at different surfaces.  No workgroup barrier is involved: a
 // queue is only ever touched by the wave that owns it.  Per-ray arithmetic and draw
 // order are exactly those of the lockstep kernel, so results are bit-identical.
+// With filtered predicates the kernel holds no literal formula at all: see `defer` below.
 // ---------------------------------------------------------------------------
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kQueueCap = 128;      // >= 63 leftover + 64 new survivors
@@ -321,6 +353,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
 {
     __shared__ ort_system S;
     __shared__ double Q[kWavesPerBlock][kQueueFields][kQueueCap];
+    __shared__ int QN[kWavesPerBlock][kQueueCap];        // intersections evaluated before the queue point
     __shared__ unsigned int blk[4];
     stage_system(S, a.sys);
     if (threadIdx.x < 4) blk[threadIdx.x] = 0;
@@ -329,6 +362,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double (*q)[kQueueCap] = Q[wave];
+    int *qn = QN[wave];
     const int ph = a.phase - 1;
     const ort_surface *surf = S.surfaces[ph];
     const int ns = S.n_surfaces[ph];
@@ -336,6 +370,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
     if (split <= 0 || split >= ns) split = ns;          // no queue point: one segment
     int32_t *layer = hist_layer(a);
     const uint64_t n = a.n_rays;
+    const uint64_t ns_in = a.in_stride;
 
     // contiguous, 64-aligned range of ray indices for this wave
     const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
@@ -358,6 +393,10 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
             if (st == ORT_ST_HELP3) help3++;
         }
     };
+    // A ray that raised `rare` (ort_device.h: it sat on a decision boundary of a filtered
+    // predicate) leaves this kernel without any side effect: its index goes to the re-run list
+    // and trace_kernel<literal> traces it from the start afterwards.  ~4e-6 of the rays.
+    auto defer = [&](uint64_t i) { a.redo_list[atomicAdd(&a.redo_ctl[0], 1u)] = (uint32_t)i; };
 
     uint64_t next = lo;
     int qcount = 0, qhead = 0;
@@ -370,24 +409,22 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
             const int slot = (qhead + lane) & (kQueueCap - 1);
             qhead = (qhead + m) & (kQueueCap - 1);
             qcount -= m;
-            // a queued ray: also how the literal re-run gets its initial state back (the slot is
-            // not overwritten before the next push)
-            auto load = [&](RayT<T> &rr, KeyedDraws &dd, int &ss) {
-                rr = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}};
-                dd.z = 0;
-                if (act) {
-                    rr.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
-                    rr.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
-                    dd.z = (uint64_t)__double_as_longlong(q[6][slot]);
-                }
-                ss = act ? -1 : ORT_ST_NA_REJECT;
-            };
-            RayT<T> r;
+            RayT<T> r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}};
             KeyedDraws d;
-            int nis = 0, xp = 0, yp = 0, st;
-            load(r, d, st);
-            walk<FILT, T, ANYSRC, false>(S, surf, split, ns, r, d, nis, st, xp, yp, load);
-            if (act) finish(st, nis, xp, yp);
+            d.z = 0;
+            int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
+            if (act) {
+                r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
+                r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
+                d.z = (uint64_t)__double_as_longlong(q[6][slot]);
+                nis = qn[slot];
+            }
+            bool rare = false;
+            walk_pass<FILT, T, ANYSRC, false>(S, surf, split, ns, r, d, nis, st, xp, yp, rare);
+            if (act) {
+                if (FILT && rare) defer(ray_of_counter(d.z, a.rng_base) - a.first_ray);
+                else finish(st, nis, xp, yp);
+            }
             __builtin_amdgcn_wave_barrier();
         } else if (have_new) {
             // ---- segment 1 on 64 fresh rays
@@ -395,32 +432,30 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
             const bool act = i < hi;
             next += 64;
             const uint64_t ic = act ? i : hi - 1;        // clamped: idle lanes recompute the last ray, unused
-            // a fresh ray: read from the resident bundle or emitted from its key; the literal
-            // re-run starts from the same call
-            auto fresh = [&](RayT<T> &rr, KeyedDraws &dd, int &ss) {
-                ss = act ? -1 : ORT_ST_NA_REJECT;
-                if (MODE == MODE_RESIDENT) {
-                    dd.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
-                    rr.pos = {T(a.pos_dir_in[0 * n + ic]), T(a.pos_dir_in[1 * n + ic]), T(a.pos_dir_in[2 * n + ic])};
-                    rr.dir = {T(a.pos_dir_in[3 * n + ic]), T(a.pos_dir_in[4 * n + ic]), T(a.pos_dir_in[5 * n + ic])};
-                } else {
-                    dd.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                    if (!emit<T, ANYSRC>(S, a.phase, rr, dd, a.first_ray + ic, a.img_cdf)) ss = ORT_ST_LOST_TELESCOPE;
-                }
-            };
             RayT<T> r;
             KeyedDraws d;
-            int nis = 0, xp = 0, yp = 0, st;
-            fresh(r, d, st);
-            walk<FILT, T, ANYSRC, false>(S, surf, 0, split, r, d, nis, st, xp, yp, fresh);
-            const bool survive = act && st < 0;
+            int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
+            if (MODE == MODE_RESIDENT) {
+                d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
+                r.pos = {T(a.pos_dir_in[0 * ns_in + ic]), T(a.pos_dir_in[1 * ns_in + ic]), T(a.pos_dir_in[2 * ns_in + ic])};
+                r.dir = {T(a.pos_dir_in[3 * ns_in + ic]), T(a.pos_dir_in[4 * ns_in + ic]), T(a.pos_dir_in[5 * ns_in + ic])};
+            } else {
+                d.init_keyed(a.rng_base, a.first_ray + ic, 0);
+                if (!emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
+            }
+            bool rare = false;
+            walk_pass<FILT, T, ANYSRC, false>(S, surf, 0, split, r, d, nis, st, xp, yp, rare);
+            const bool deferred = FILT && rare && act;
+            const bool survive = act && st < 0 && !deferred;
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(survive);
             if (survive) {
                 const int slot = (qhead + qcount + lane_prefix(mask)) & (kQueueCap - 1);
                 q[0][slot] = (double)r.pos.x; q[1][slot] = (double)r.pos.y; q[2][slot] = (double)r.pos.z;
                 q[3][slot] = (double)r.dir.x; q[4][slot] = (double)r.dir.y; q[5][slot] = (double)r.dir.z;
                 q[6][slot] = __longlong_as_double((long long)d.z);
-                isect += (unsigned)nis;                    // counted so far; segment 2 adds the rest
+                qn[slot] = nis;
+            } else if (deferred) {
+                defer(i);
             } else if (act) {
                 finish(st, nis, xp, yp);
             }
@@ -510,6 +545,9 @@ struct ort_ctx {
     ort_system *d_sys;
     int32_t *d_image, *own_image;
     int32_t *d_replicas;         // kReplicas zeroed images (scratch between trace and fold)
+    uint32_t *d_redo_list;       // re-run list of the queued filtered kernel, redo_cap entries
+    size_t redo_cap;
+    unsigned int *d_redo_ctl;    // [2]: entries, re-run workgroups done; zero between launches
     long long *d_img_cdf;        // image-source table (ORT_IMAGE_SOURCE_CELLS + 1) or null
     unsigned long long *d_counters, *own_counters;
     bool timing;
@@ -573,6 +611,8 @@ int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out)
     HIP_TRY(hipMalloc(&c->own_counters, ORT_NUM_COUNTERS * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&c->d_replicas, (size_t)kReplicas * ORT_IMAGE_BINS * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->d_replicas, 0, (size_t)kReplicas * ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMalloc(&c->d_redo_ctl, 2 * sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(c->d_redo_ctl, 0, 2 * sizeof(unsigned int), c->stream));
     c->d_image = c->own_image;
     c->d_counters = c->own_counters;
     for (int k = 0; k < 3; ++k) {
@@ -600,6 +640,7 @@ int ort_destroy(ort_ctx *c)
     for (int k = 0; k < 3; ++k) { (void)hipEventDestroy(c->ev[k][0]); (void)hipEventDestroy(c->ev[k][1]); }
     for (int k = 0; k < kTimingRing; ++k) { (void)hipEventDestroy(c->ring[k][0]); (void)hipEventDestroy(c->ring[k][1]); }
     (void)hipFree(c->d_sys); (void)hipFree(c->own_image); (void)hipFree(c->own_counters); (void)hipFree(c->d_replicas); (void)hipFree(c->d_img_cdf);
+    (void)hipFree(c->d_redo_list); (void)hipFree(c->d_redo_ctl);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ORT_OK;
@@ -641,32 +682,17 @@ int ort_reset(ort_ctx *c)
     return ORT_OK;
 }
 
-static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
+// One kernel of the trace family on `grid` workgroups.
+static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool queued, bool filt, bool anysrc)
 {
-    a.sys = c->d_sys; a.image = c->d_image; a.counters = c->d_counters;
-    const bool use_rep = (c->variant & 4) == 0 && mode != MODE_DEBUG;
-    a.replicas = use_rep ? c->d_replicas : nullptr;
-    a.img_cdf = c->d_img_cdf;
-    if (a.n_rays == 0) return ORT_OK;
-    int grid = grid_for(a.n_rays);
-    const int slot = (int)(c->ring_count % kTimingRing);
-    if (c->timing && evk >= 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
-    if (c->timing && evk == 0) HIP_TRY(hipEventRecord(c->ring[slot][0], c->stream));
-    const bool queued = (c->variant & 1) && mode != MODE_DEBUG && c->precision != 1;
-    const bool filt = (c->variant & 2) == 0;
-    if (queued) {
-        // every wave walks a 64-aligned contiguous range: no more waves than 64-ray batches
-        uint64_t batches = (a.n_rays + 63) / 64;
-        uint64_t blocks = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
-        if (blocks < (uint64_t)grid) grid = (int)blocks;
-    }
 #define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
-    // the default emitters (ring / point) have their own, leaner instantiation
-    const bool anysrc = c->emitter[a.phase - 1] != (a.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT) || c->scatter;
     if (c->precision == 2) {
         // fast fp64 (ort_fastd.h): FMA contraction, Newton divide / Goldschmidt sqrt; ~1e-13 from exact
         if (mode == MODE_DEBUG) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, fastd, true>));
-        else if (anysrc) {
+        else if (!queued) {                                   // the literal re-run of deferred rays
+            if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, false, fastd, true>));
+            else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, fastd, true>));
+        } else if (anysrc) {
             if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true, fastd>));
             else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true, fastd>));
         } else {
@@ -691,11 +717,64 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a, int evk)
             else { if (filt) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true, double, true>)); else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, double, true>)); }
         }
     } else {
+        // the default emitters (ring / point) without scattering have their own, leaner instantiation
         if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, double>));
         else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, double>));
     }
 #undef ORT_LAUNCH
-    if (use_rep) hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, a.phase);
+}
+
+static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
+{
+    a0.sys = c->d_sys; a0.image = c->d_image; a0.counters = c->d_counters;
+    const bool use_rep = (c->variant & 4) == 0 && mode != MODE_DEBUG;
+    a0.replicas = use_rep ? c->d_replicas : nullptr;
+    a0.img_cdf = c->d_img_cdf;
+    a0.in_stride = a0.n_rays;
+    if (a0.n_rays == 0) return ORT_OK;
+    const bool queued = (c->variant & 1) && mode != MODE_DEBUG && c->precision != 1;
+    const bool filt = (c->variant & 2) == 0;
+    const bool anysrc = c->emitter[a0.phase - 1] != (a0.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT) || c->scatter;
+    // The queued filtered kernel defers the rays that sit on a decision boundary to a list, which
+    // the literal lockstep kernel traces right after it.  Every ray of a launch could be on it
+    // (an axial beam meets every flat face at costt == 1), so a launch covers at most kChunkRays.
+    const bool deferring = queued && filt;
+    const uint64_t total = a0.n_rays;
+    const uint64_t step = deferring ? kChunkRays : total;
+    if (deferring) {
+        const size_t need = (size_t)(total < step ? total : step);
+        if (need > c->redo_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_redo_list);
+            c->d_redo_list = nullptr; c->redo_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_redo_list, need * sizeof(uint32_t)));
+            c->redo_cap = need;
+        }
+        a0.redo_list = c->d_redo_list;
+        a0.redo_ctl = c->d_redo_ctl;
+    }
+    const int slot = (int)(c->ring_count % kTimingRing);
+    if (c->timing && evk >= 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
+    if (c->timing && evk == 0) HIP_TRY(hipEventRecord(c->ring[slot][0], c->stream));
+    for (uint64_t off = 0; off < total; off += step) {
+        TraceArgs a = a0;
+        a.n_rays = total - off < step ? total - off : step;
+        a.first_ray = a0.first_ray + off;
+        if (a.pos_dir_in) a.pos_dir_in += off;              // same component stride (in_stride)
+        int grid = grid_for(a.n_rays);
+        if (queued) {
+            // every wave walks a 64-aligned contiguous range: no more waves than 64-ray batches
+            uint64_t batches = (a.n_rays + 63) / 64;
+            uint64_t blocks = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
+            if (blocks < (uint64_t)grid) grid = (int)blocks;
+        }
+        launch_one(c, mode, a, grid, queued, filt, anysrc);
+        if (deferring) {
+            a.listed = 1;
+            launch_one(c, mode, a, kRedoBlocks, false, false, true);
+        }
+    }
+    if (use_rep) hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, a0.phase);
     HIP_TRY(hipGetLastError());
     if (c->timing && evk >= 0) { HIP_TRY(hipEventRecord(c->ev[evk][1], c->stream)); c->ev_valid[evk] = true; }
     if (c->timing && evk == 0) { HIP_TRY(hipEventRecord(c->ring[slot][1], c->stream)); c->ring_count++; }
