@@ -40,7 +40,8 @@ constexpr int kBlock = 256;
 #endif
 constexpr int kTimingRing = 64;         // launches kept by ort_kernel_times
 constexpr int kReplicas = 8;            // image replicas, one per XCD-sized group of workgroups
-constexpr int kMaxBlocks = 256 * 8;     // 256 CUs x 8 workgroups: >> 256 workgroups fills all 8 XCDs
+constexpr int kMaxBlocks = 256 * 12;    // 256 CUs x 12 workgroups = 3 rounds at 4 resident per CU: the static ranges'
+                                        // cost spread (~10 %) then idles the chip for 1/3 less than with 2 rounds
 constexpr uint64_t kChunkRays = 1ull << 25;   // rays per launch of the queued kernel (bounds the re-run list: 4 B per ray)
 constexpr int kRedoBlocks = 128;        // grid of the literal re-run kernel (it normally finds an empty list and returns)
 
@@ -353,7 +354,9 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
 {
     __shared__ ort_system S;
     __shared__ double Q[kWavesPerBlock][kQueueFields][kQueueCap];
-    __shared__ int QN[kWavesPerBlock][kQueueCap];        // intersections evaluated before the queue point
+    // intersections evaluated before the queue point: `split` for every survivor unless a surface
+    // scatters (extended instantiation), so only that one carries the count through the queue
+    __shared__ int QN[kWavesPerBlock][ANYSRC ? kQueueCap : 1];
     __shared__ unsigned int blk[4];
     stage_system(S, a.sys);
     if (threadIdx.x < 4) blk[threadIdx.x] = 0;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
                 r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
                 d.z = (uint64_t)__double_as_longlong(q[6][slot]);
-                nis = qn[slot];
+                nis = ANYSRC ? qn[slot] : split;
             }
             bool rare = false;
             walk_pass<FILT, T, ANYSRC, false>(S, surf, split, ns, r, d, nis, st, xp, yp, rare);
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 q[0][slot] = (double)r.pos.x; q[1][slot] = (double)r.pos.y; q[2][slot] = (double)r.pos.z;
                 q[3][slot] = (double)r.dir.x; q[4][slot] = (double)r.dir.y; q[5][slot] = (double)r.dir.z;
                 q[6][slot] = __longlong_as_double((long long)d.z);
-                qn[slot] = nis;
+                if (ANYSRC) qn[slot] = nis;
             } else if (deferred) {
                 defer(i);
             } else if (act) {
