@@ -216,7 +216,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "trace_queue_kernel<MODE_FUSED, filtered> (+ fold_kernel, same event bracket)", "kernel_ms": k_s * 1e3,
+            "kernel": "trace_queue_kernel<MODE_FUSED, filtered> (+ the literal re-run launch and fold_kernel, same event bracket)", "kernel_ms": k_s * 1e3,
             "algorithmic_bytes_per_launch": alg_bytes,
             "note": "SURVEY §8(d) contract figure 48 B/ray + 8 B/binned ray; the path is fp64-VALU "
                     "bound, see roofline_fp64 (DESIGN.md §5)",

@@ -14,8 +14,9 @@
 // scalar unit, not the VALUs, set the pace (round-1 PMC: SQ_ACTIVE_INST_SCA 73 % of
 // elapsed vs VALU 60 %).  So: every lane executes every surface step with a `live`
 // predicate and commits state through selects; the only branches are WAVE-UNIFORM
-// (surface kind via readfirstlane, "does any lane need the literal formula" via
-// ballot), plus the exec-masked side effects (image atomic, LDS queue traffic).
+// (surface kind via readfirstlane), plus the exec-masked side effects (image atomic,
+// LDS queue traffic).  The filtered predicates below do not branch to their literal
+// formulas either: they raise a per-lane flag and the caller deals with it per segment.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -303,16 +304,19 @@ using Ray = RayT<double>;
 // which root of the quadratic, NA acceptance, which image bin — is evaluated with a
 // cheap approximation whose error bound is orders of magnitude smaller than the
 // margin it is tested against.  A lane that lands inside the margin (probability
-// ~1e-10 per test), and every special case (total internal reflection, costt >= 1 at
-// normal incidence, tangent rays, zero or non-finite operands), raises the per-lane
-// flag `rare` and carries on with an unspecified value.  The CALLER re-runs the whole
-// segment with FILT = false (the reference's literal formulas) for a wave in which any
-// lane raised the flag, and takes those lanes' results from that run.  The decision
-// taken is therefore always the reference's and outcomes stay bit-identical, while
-// the hot path holds no rare branch at all (having one behind every predicate cost
-// 14 % of the kernel time: each is a scheduling barrier plus scalar work) and ~4 of the
-// ~13 fp64 divide / square-root expansions per surface leave it.  FILT = false
-// evaluates every predicate literally (the redo path, A/B, tests).
+// ~1e-10 per test), and every special case (costt >= 1 at normal incidence, k within
+// 1e-6 of total reflection, tangent rays, zero or non-finite operands), raises the
+// per-lane flag `rare` and carries on with an unspecified value.  The CALLER sees to it
+// that such a ray is traced with FILT = false (the reference's literal formulas) instead:
+// the queued kernel appends its index to a list that the literal lockstep kernel traces
+// afterwards (ort_hip.hip, `defer`); the lockstep kernel re-runs the segment in place
+// (`walk`).  The decision taken is therefore always the reference's and outcomes stay
+// bit-identical, while the hot path holds no rare branch at all (one behind every
+// predicate cost 14 % of the kernel time: each is a scheduling barrier plus scalar
+// work, and two of them — total internal reflection at the rim of the plano-convex lens,
+// the exactly-zero x component of every cylinder normal — were not rare) and ~4 of the
+// ~13 fp64 divide / square-root expansions per surface leave it.  FILT = false evaluates
+// every predicate literally (re-run path, A/B, tests).
 // ----------------------------------------------------------------------------
 // 1/y with relative error < 2^-40 for finite normal y: v_rcp_f64 seed + one Newton step
 __device__ inline double rcp_approx(double y)

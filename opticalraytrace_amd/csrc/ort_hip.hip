@@ -11,12 +11,15 @@
 //       (fold_kernel adds them into the image afterwards); counters are reduced per workgroup.
 //         MODE_FUSED     emit in-kernel (src/main.f90:90-109 / :127-162 whole loop body)
 //         MODE_RESIDENT  ray bundle read from HBM, SoA fp64 [6][n], coalesced
-//         FILT           filtered predicates (decisions from bounded approximations)
+//         FILT           filtered predicates (decisions from bounded approximations); a ray that
+//                        lands inside a margin is not decided here: its index goes to the
+//                        re-run list and it leaves the kernel without side effect
 //         EXT            also compiles the rarely used emitters (spot, crs, image) and the
 //                        in-bottle scattering walk; the default instantiation leaves them out
-//   trace_kernel<MODE, FILT, T, EXT>         plain lockstep thread-per-ray walk: the parity /
-//       debug entry (MODE_DEBUG: per-ray outputs, tracker paths, no side effect), the fp32
-//       path and the A/B baseline of the queued kernel
+//   trace_kernel<MODE, FILT, T, EXT>         plain lockstep thread-per-ray walk: the literal
+//       re-run of the listed rays right after the queued kernel (normally an empty list), the
+//       parity / debug entry (MODE_DEBUG: per-ray outputs, tracker paths, no side effect), the
+//       fp32 path and the A/B baseline of the queued kernel
 //   fold_kernel, emit_kernel
 //
 // No MFMA: there is no contraction anywhere on this path; the kernel is bound by

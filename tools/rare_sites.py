@@ -12,7 +12,7 @@ from opticalraytrace_amd.params import Settings  # noqa: E402
 from opticalraytrace_amd.system import OpticalSystem  # noqa: E402
 
 SITES = ["sqrt range", "div3 shared", "quadratic", "fresnel", "aperture", "NA", "bin"]
-n = 1_000_000
+n = 10_000_000
 ctx = capi.Context(OpticalSystem.from_settings(Settings(nphotons=n, bottle_file="clearBottle-large.params")))
 lib = capi.load_library()
 buf = (ctypes.c_ulonglong * 16)()
