@@ -421,3 +421,28 @@ def test_bulk_kernels_rerun_flagged_rays_literally(ctxs, name):
             assert np.array_equal(img, img0) and np.array_equal(cnt, cnt0)
         assert np.array_equal(img0[phase - 1].astype(np.int64), img_want)
         assert int(cnt0[2 + (phase - 1)]) == int(want["n_isect"].sum())
+
+
+def test_launches_are_cut_at_the_rerun_list_capacity(ctxs):
+    """The queued kernel covers at most 2^25 rays per launch (the re-run list holds 4 bytes per
+    ray of a launch).  A call that spans two launches — fused and from a resident bundle, whose
+    component stride stays the bundle's — equals the same rays traced in two calls."""
+    import torch
+    osys, ctx = ctxs("large")
+    n = (1 << 25) + 12345
+    ctx.reset()
+    ctx.trace(2, 0, n, SEED)
+    img_a, cnt_a = ctx.read()
+    ctx.reset()
+    ctx.trace(2, 0, 1 << 24, SEED)
+    ctx.trace(2, 1 << 24, n - (1 << 24), SEED)
+    img_b, cnt_b = ctx.read()
+    assert np.array_equal(img_a, img_b) and np.array_equal(cnt_a, cnt_b)
+    bundle = torch.empty((6, n), dtype=torch.float64, device="cuda:0")       # 1.6 GB
+    ctx.reset()
+    ctx.emit(2, 0, n, SEED, bundle.data_ptr())
+    ctx.trace_resident(2, 0, n, SEED, 2, bundle.data_ptr())
+    ctx.synchronize()
+    img_c, cnt_c = ctx.read()
+    del bundle
+    assert np.array_equal(img_a, img_c) and np.array_equal(cnt_a, cnt_c)
