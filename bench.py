@@ -182,13 +182,15 @@ def main():
     alg_flop = FLOP_PER_INTERSECTION * isect_launch
     ach_gbs = alg_bytes / k_s / 1e9
     ach_tf = alg_flop / k_s / 1e12
-    traffic = None
+    traffic = valu_busy = None
     tf = os.path.join(ROOT, "profiles", "traffic_bytes_per_launch.json")
     if os.path.exists(tf):                         # written from the rocprofv3 --pmc passes
         try:
-            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            prof = json.load(open(tf))
+            traffic = prof.get("hbm_bytes_per_launch")
+            valu_busy = prof.get("valu_busy_frac")
         except Exception:
-            traffic = None
+            traffic = valu_busy = None
 
     out = {
         "metric": "ray-surface intersections/sec",
@@ -224,6 +226,7 @@ def main():
         "roofline_fp64": {
             "bound": "valu_fp64", "achieved": ach_tf, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach_tf / FP64_VEC_PEAK_TFLOPS, "flop_per_intersection": FLOP_PER_INTERSECTION,
+            "valu_busy_frac_profiled": valu_busy,     # rocprofv3 PMC of this kernel, profiles/ (not live)
         },
     }
     if fast is not None:
