@@ -55,18 +55,19 @@ constexpr uint64_t kGoldenInv = 0xF1DE83E19937733Dull;
 static_assert(kGolden * kGoldenInv == 1ull, "kGoldenInv must invert kGolden modulo 2^64");
 __host__ __device__ inline uint64_t ray_of_counter(uint64_t z, uint64_t base) { return ((z - base) * kGoldenInv) >> 24; }
 
-// top 53 bits of x as a double in [0,1) = (double)(x >> 11) * 2^-53, exactly, without the
-// quarter-rate int->fp64 conversions: 2^84 + hi*2^32 and 2^52 + lo are built from bits
-// (0x453.. / 0x433.. exponent words), their difference from (2^84 + 2^52) is the exact
-// 53-bit integer hi*2^32 + lo, and the final scaling is a power of two.
+// top 53 bits of x as a double in [0,1) = (double)(x >> 11) * 2^-53, exactly, without int->fp64
+// conversions or a multiply: with hi = top 21 bits and lo = next 32 bits,
+//   A = 2^31 + hi * 2^-21   (exponent word 0x41E.., hi in the low mantissa word: ulp(A) = 2^-21)
+//   B = 2^-1 + lo * 2^-53   (exponent word 0x3FE.., ulp(B) = 2^-53)
+// and (A - (2^31 + 2^-1)) + B = hi * 2^-21 + lo * 2^-53: both steps are exact (each result is
+// representable), and that is the 53-bit fraction.
 __device__ inline double bits_to_unit(uint64_t x)
 {
     const uint32_t hi = (uint32_t)(x >> 43);               // top 21 bits
     const uint32_t lo = (uint32_t)(x >> 11);               // next 32 bits
-    const double dh = __hiloint2double(0x45300000, (int)hi);   // 2^84 + hi * 2^32
-    const double dl = __hiloint2double(0x43300000, (int)lo);   // 2^52 + lo
-    const double v = (dh - 0x1.00000001p84) + dl;              // (hi*2^32 - 2^52) + (2^52 + lo), both steps exact
-    return v * 0x1.0p-53;
+    const double A = __hiloint2double(0x41E00000, (int)hi);
+    const double B = __hiloint2double(0x3FE00000, (int)lo);
+    return (A - 0x1.00000001p31) + B;
 }
 
 // Per-ray draw source.  peek() is the next uniform, advance(c) consumes it where c.
@@ -356,6 +357,25 @@ template <class T> struct SysTypes { using Sys = SystemT<T>; using Surf = Surfac
 template <> struct SysTypes<double> { using Sys = ort_system; using Surf = ort_surface; };
 template <> struct SysTypes<fastd> { using Sys = ort_system; using Surf = ort_surface; };   // doubles convert implicitly
 
+// Per-surface values every ray of a workgroup would otherwise recompute (wave-uniform operands,
+// but fp64 arithmetic lives in the vector unit): formed once per workgroup next to the staged
+// system, by the very operations the per-ray code would use, so nothing changes bit-wise.  Only
+// the filtered path reads them; the literal path recomputes from the surface record.
+template <class T> struct SurfAuxT { T r2, ap2, ap_tol, eta2, ell_sa, ell_sb; };
+template <class T, class Surf>
+__device__ inline SurfAuxT<T> make_aux(const Surf &s)
+{
+    SurfAuxT<T> a;
+    const T r = s.radius, rb = s.radius_b, A = s.aperture, e = s.eta;
+    a.r2 = r * r;                          // intersect_sphere / _cylinder: radius**2
+    a.ap2 = A * A;                         // aperture test on the squares
+    a.ap_tol = T(1e-12) * a.ap2;
+    a.eta2 = e * e;                        // refract: eta**2
+    a.ell_sa = T(1.) / (r * r);            // intersect_ellipse: 1/semia**2, 1/semib**2 (inf for other kinds: unused)
+    a.ell_sb = T(1.) / (rb * rb);
+    return a;
+}
+
 template <class T> __device__ inline bool aperture_present(T a);
 template <> __device__ inline bool aperture_present<double>(double a)
 {
@@ -371,32 +391,45 @@ template <> __device__ inline bool aperture_present<float>(float a)
 }
 
 // ----------------------------------------------------------------------------
-// solveQuadratic (src/surfaces.f90:227-260) + root choice (:75-86), predicated.
-// Away from tangency the order of the two roots follows from signs alone
-// (q^2 - a*c = (|b| sqrt(D) + D)/2 >= 1e-5 q^2 under the filter, a > 0, and
-// rounding is monotone), so only the quotient the reference ends up returning is
-// divided out, with its operands chosen by selects:
+// solveQuadratic (src/surfaces.f90:227-260) + root choice (:75-86), predicated.  The callers
+// pass hb = b/2 (the reference forms b = 2.*(...)).
+// FILT works on the quantities scaled by exact powers of two — D = hb^2 - a c = discrim/4,
+// sqrt(D) = sqrt(discrim)/2, q = -(hb +- sqrt(D)) — which round exactly like the reference's
+// (scaling by 2 or 4 commutes with rounding away from the subnormal range, and D is kept inside
+// (1e-200, 1e200)), so q, and the quotient returned, are the reference's bit for bit with three
+// multiplications fewer.  Away from tangency the order of the two roots follows from signs alone
+// (q^2 - a c = |hb| sqrt(D) + D >= 2.5e-11 q^2 under the filter, a > 0, and rounding is
+// monotone), so only the quotient the reference ends up returning is divided out, with its
+// operands chosen by selects:
 //   q > 0 : roots c/q <= q/a ; c/q < 0 <=> c < 0  -> t = c < 0 ? q/a : c/q   (always a hit)
 //   q < 0 : q/a < 0 ; hit <=> c/q >= 0 <=> c <= 0 -> t = c/q
+// Range guards: D in (1e-200, 1e200) (hence |hb| < 1e105, 1e-100 < |q| < 2e105: no quotient
+// leaves the normal range for a < 1e10 and c = 0 or |c| > 1e-200; a = 0 or NaN makes D fail).
 // ----------------------------------------------------------------------------
 template <bool FILT, class T>
-__device__ inline void solve_and_pick(T a, T b, T c, bool live, T &t, bool &hit, bool &rare)
+__device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit, bool &rare)
 {
     static_assert(!FILT || sizeof(T) == 8, "filtered predicates are derived for fp64 only");
-    const T discrim = b * b - T(4.0) * a * c;
-    const bool neg = discrim < T(0.0);                // :243 — no real root
-    const T sq = sqrt_f<FILT, T>(discrim, live, rare); // NaN when neg: those lanes are misses
-    const T q = T(-0.5) * (b + ((b > T(0.0)) ? sq : -sq));   // :249-253; b - sq == b + (-sq) exactly
     if constexpr (FILT) {
-        const T bb = b * b;
-        const bool ok = discrim > T(1e-10) * bb && a > T(1e-10) && a < T(1e10) && bb < T(1e200) &&
-                        fabs(q) > T(1e-100) && (c == T(0.0) || fabs(c) > T(1e-200));
+        const T hh = hb * hb;
+        const T D = hh - a * c;
+        const bool neg = D < T(0.0);                  // :243 — no real root
+        bool unused = false;
+        const T sq = sqrt_f<true, T>(D, false, unused);   // range: see `ok`; NaN when neg (misses)
+        const T q = -(hb + ((hb > T(0.0)) ? sq : -sq));   // :249-253
+        const bool ok = D > T(1e-10) * hh && D > T(1e-200) && D < T(1e200) && a < T(1e10) &&
+                        (c == T(0.0) || fabs(c) > T(1e-200));
         const bool qpos = q > T(0.0);
         const bool use_qa = qpos && (c < T(0.0));
         t = ORT_DIV(use_qa ? q : c, use_qa ? a : q);
         hit = (qpos || !(c > T(0.0))) && !neg;
         ORT_RARE(2, live && !neg && !ok);             // tangent, degenerate or NaN
     } else {
+        const T b = T(2.0) * hb;
+        const T discrim = b * b - T(4.0) * a * c;
+        const bool neg = discrim < T(0.0);            // :243
+        const T sq = ORT_SQRT(discrim);
+        const T q = (b > T(0.0)) ? T(-0.5) * (b + sq) : T(-0.5) * (b - sq);
         const bool dz = discrim == T(0.0);            // :245-247
         const T xd = T(-0.5) * b / a;
         const T t0 = dz ? xd : q / a;
@@ -412,8 +445,9 @@ __device__ inline void solve_and_pick(T a, T b, T c, bool live, T &t, bool &hit,
 // intersect_sphere (src/surfaces.f90:52-89) and intersect_cylinder (:91-130) in
 // one body: the x-axis cylinder is the sphere with the x terms removed
 // (a = dz^2+dy^2 etc. — fp addition commutes, so the sums are bit-identical).
+// r2 = radius**2 (SurfAuxT); the literal path forms it itself.
 template <bool FILT, class T>
-__device__ inline void intersect_quadric(const RayT<T> &r, T cx, T cy, T cz, T radius,
+__device__ inline void intersect_quadric(const RayT<T> &r, T cx, T cy, T cz, T radius, T r2,
                                          bool cylinder, bool live, T &t, bool &hit, bool &rare)
 {
     T Lx = cylinder ? T(0.0) : r.pos.x - cx;
@@ -421,24 +455,24 @@ __device__ inline void intersect_quadric(const RayT<T> &r, T cx, T cy, T cz, T r
     T Lz = r.pos.z - cz;
     T dx = cylinder ? T(0.0) : r.dir.x;
     T a = (dx * dx) + (r.dir.y * r.dir.y) + (r.dir.z * r.dir.z);
-    T b = T(2.0) * ((dx * Lx) + (r.dir.y * Ly) + (r.dir.z * Lz));
-    T c = ((Lx * Lx) + (Ly * Ly) + (Lz * Lz)) - radius * radius;
-    solve_and_pick<FILT>(a, b, c, live, t, hit, rare);
+    T hb = (dx * Lx) + (r.dir.y * Ly) + (r.dir.z * Lz);
+    T c = ((Lx * Lx) + (Ly * Ly) + (Lz * Lz)) - (FILT ? r2 : radius * radius);
+    solve_and_pick<FILT>(a, hb, c, live, t, hit, rare);
 }
 
-// intersect_ellipse, src/surfaces.f90:133-176
+// intersect_ellipse, src/surfaces.f90:133-176 (sa, sb = 1/semia**2, 1/semib**2: SurfAuxT)
 template <bool FILT, class T>
-__device__ inline void intersect_ellipse(const RayT<T> &r, T cy, T cz, T semia, T semib,
+__device__ inline void intersect_ellipse(const RayT<T> &r, T cy, T cz, T semia, T semib, T aux_sa, T aux_sb,
                                          bool live, T &t, bool &hit, bool &rare)
 {
-    T sa = T(1.) / (semia * semia);
-    T sb = T(1.) / (semib * semib);
+    T sa = FILT ? aux_sa : T(1.) / (semia * semia);
+    T sb = FILT ? aux_sb : T(1.) / (semib * semib);
     T Ly = r.pos.y - cy;
     T Lz = r.pos.z - cz;
     T a = sa * (r.dir.z * r.dir.z) + sb * (r.dir.y * r.dir.y);
-    T b = T(2) * (sa * r.dir.z * Lz + sb * r.dir.y * Ly);
+    T hb = sa * r.dir.z * Lz + sb * r.dir.y * Ly;
     T c = sa * (Lz * Lz) + sb * (Ly * Ly) - T(1);
-    solve_and_pick<FILT>(a, b, c, live, t, hit, rare);
+    solve_and_pick<FILT>(a, hb, c, live, t, hit, rare);
 }
 
 // fresnel, src/surfaces.f90:336-372, as one expression (eta = n1/n2 rounded once on
@@ -461,22 +495,28 @@ __device__ inline T fresnel(T costt, T n1, T n2, T eta)
 // (:303-333), predicated: the direction is committed where `live`.  The caller
 // supplies the uniform u and consumes the draw.  Returns true where the ray reflected.
 // FILT: R is only ever compared with u, so it is formed with two approximate
-// reciprocals and with refract's own c2 standing in for fresnel's cost2 (the same
-// quantity, rounded along another path; they differ by < 1e-13 once k > 1e-6).
-// |R' - R| < 1e-12, the margin is 1e-10.
+// reciprocals, with refract's own c2 standing in for fresnel's cost2 (the same
+// quantity, rounded along another path; they differ by < 1e-13 once k > 1e-6) and with
+// refract's eta c1 - c2 as the first numerator.  |R' - R| < 1e-12, the margin is 1e-10.
 template <bool FILT, bool KEEP, class T>
-__device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta, T u, bool live, bool &rare)
+__device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta, T eta2, T u, bool live, bool &rare)
 {
     const T c1s = vdot(N, I);                            // == vdot(I, N): the products commute
     const T c1 = fabs(c1s);                              // costt (fresnel) and |c1| (refract)
-    const T k = T(1.0) - eta * eta * (T(1.0) - c1 * c1); // refract's radicand, refract's order (:327)
-    const T c2 = sqrt_f<FILT, T>(k, false, rare);        // NaN beyond total reflection: unused there
+    // refract's radicand, refract's order (:327); eta2 = eta**2 (SurfAuxT)
+    const T k = T(1.0) - (FILT ? eta2 : eta * eta) * (T(1.0) - c1 * c1);
+    bool unused = false;
+    const T c2 = sqrt_f<FILT, T>(k, false, unused);      // NaN beyond total reflection: unused there
+    const T ec1 = eta * c1;
+    const T m = ec1 - c2;                                // refract's coefficient of the normal (:329)
     bool reflected;
     if constexpr (FILT) {
-        T a1 = n1 * c1, b1 = n2 * c2, a2 = n1 * c2, b2 = n2 * c1;
-        T f1 = (a1 - b1) * rcp_approx(a1 + b1);
-        T f2 = (a2 - b2) * rcp_approx(a2 + b2);
-        T R = T(0.5) * (f1 * f1 + f2 * f2);
+        // fresnel's two amplitude ratios with numerator and denominator divided by n2:
+        // (n1 c1 - n2 c2)/(n1 c1 + n2 c2) = (eta c1 - c2)/(eta c1 + c2), likewise the other
+        const T ec2 = eta * c2;
+        const T f1 = m * rcp_approx(ec1 + c2);
+        const T f2 = (ec2 - c1) * rcp_approx(ec2 + c1);
+        const T R = T(0.5) * (f1 * f1 + f2 * f2);
         // Total internal reflection is an everyday outcome at the rim of the plano-convex lens
         // (6 % of the ring rays): k < -1e-6 means eta^2 (1 - c1^2) > 1 + 1e-6, so fresnel's
         // `sint2 > 1` (:353) holds whatever its rounding and it returns 1: u <= 1 reflects.
@@ -493,7 +533,6 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
     //   reflect (:297)      I - (2 c1s) N         = I*1   + N*(-(2 c1s))     (x*1 and a + (-b) are exact)
     //   refract (:320-329)  eta I + (eta c1 - c2) Nt,  Nt = N or -N  = I*eta + N*(+-(eta c1 - c2))
     // so the two scalars are selected, not the six components.
-    const T m = eta * c1 - c2;
     const T alpha = reflected ? T(1.) : eta;
     const T beta = reflected ? -(T(2.) * c1s) : ((c1s < T(0.)) ? m : -m);
     const VecT<T> out = vadd(vscale(I, alpha), vscale(N, beta));
@@ -504,12 +543,11 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
 // aperture test `sqrt(x^2+y^2) > A` (lens.f90:450-454, :576-580, :559-563): decided on
 // the squares unless they agree to 1e-12 (then the reference's square root is taken)
 template <bool FILT, class T>
-__device__ inline bool outside_aperture(T x, T y, T A, bool live, bool &rare)
+__device__ inline bool outside_aperture(T x, T y, T A, T A2, T A2tol, bool live, bool &rare)
 {
     const T s2 = x * x + y * y;
-    if constexpr (FILT) {
-        const T A2 = A * A;
-        ORT_RARE(4, live && !(fabs(s2 - A2) > T(1e-12) * A2));
+    if constexpr (FILT) {                               // A2 = A*A, A2tol = 1e-12 A2 (SurfAuxT)
+        ORT_RARE(4, live && !(fabs(s2 - A2) > A2tol));
         return s2 > A2;
     } else {
         return ORT_SQRT(s2) > A;
@@ -538,7 +576,7 @@ __device__ inline void tauint(const RayT<T> &r, T mua, T mus, T cy, T cz, T radi
     T d;
     bool hit;
     bool unused = false;
-    intersect_quadric<false, T>(r, T(0.), cy, cz, radius, true, on, d, hit, unused);
+    intersect_quadric<false, T>(r, T(0.), cy, cz, radius, T(0.), true, on, d, hit, unused);
     nis += on ? 1 : 0;
     const T tauradius = d * mu_tot;
     const bool inside = tau < tauradius;
@@ -722,7 +760,7 @@ __device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws)
     T t;
     bool hit;
     bool unused = false;
-    intersect_quadric<false, T>(drop, T(0.), S.crs_cy, S.crs_cz, S.crs_radius, true, true, t, hit, unused);
+    intersect_quadric<false, T>(drop, T(0.), S.crs_cy, S.crs_cz, S.crs_radius, T(0.), true, true, t, hit, unused);
     t = hit ? t : T(0.);                                   // the reference leaves t undefined on a miss
     r.pos = vadd(drop.pos, vscale(drop.dir, t));
     r.dir = {sint * cosp, sint * sinp, cost};
@@ -845,7 +883,7 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
 // KEEP = false lets lanes whose ray has ended carry garbage in r (the bulk kernels read only
 // st/xp/yp/nis of such lanes); KEEP = true freezes r where the ray ended (debug / tracker output).
 template <bool FILT, class T, bool EXT, bool KEEP = true, class Sys, class Surf, class D>
-__device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &draws,
+__device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<T> &ax, RayT<T> &r, D &draws,
                                     int &nis, int &st, int &xp, int &yp, bool &rare)
 {
     const bool live = st < 0;
@@ -861,8 +899,8 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
         T t;
         bool hit;
         const bool cyl = kind != ORT_SURF_SPHERE;
-        if (kind == ORT_SURF_ELLIPSE) intersect_ellipse<FILT, T>(r, s.cy, s.cz, s.radius, s.radius_b, live, t, hit, rare);
-        else intersect_quadric<FILT, T>(r, s.cx, s.cy, s.cz, s.radius, cyl, live, t, hit, rare);
+        if (kind == ORT_SURF_ELLIPSE) intersect_ellipse<FILT, T>(r, s.cy, s.cz, s.radius, s.radius_b, ax.ell_sa, ax.ell_sb, live, t, hit, rare);
+        else intersect_quadric<FILT, T>(r, s.cx, s.cy, s.cz, s.radius, ax.r2, cyl, live, t, hit, rare);
         int walk_end = -1;
         if (EXT && (flags & ORT_F_SCATTER)) {               // wave-uniform
             scatter_walk<T>(s, S.twopi, r, t, live && hit && !rare, draws, nis, walk_end);
@@ -871,7 +909,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
         const VecT<T> moved = vadd(r.pos, vscale(r.dir, t));
         r.pos = KEEP ? vselect(live && hit, moved, r.pos) : moved;
         bool out = false;
-        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, live && hit, rare);
+        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, ax.ap2, ax.ap_tol, live && hit, rare);
         // normal = centre - pos, with orig%x = centre%x for the bottle (lens.f90:288-290)
         N = vnormalise_f<FILT, T>(VecT<T>{cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z}, live && hit, rare);
         ended = !hit ? ((flags & ORT_F_MISS_IS_HELP3) ? ORT_ST_HELP3 : lost) : (out ? lost : -1);
@@ -888,7 +926,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
             return;
         }
         bool out = false;
-        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, live, rare);
+        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, ax.ap2, ax.ap_tol, live, rare);
         if (kind == ORT_SURF_IRIS) {
             if (KEEP) r.pos = vselect(live && out, moved, r.pos);   // pos = origpos unless lost (lens.f90:564, :643)
             st = (live && out) ? lost : st;
@@ -901,7 +939,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, RayT<T> &r, D &
     }
     const T u = draws.template peek_as<T>();
     draws.advance(proceed);
-    const bool reflected = reflect_refract<FILT, KEEP, T>(r.dir, N, s.n1, s.n2, s.eta, u, proceed, rare);
+    const bool reflected = reflect_refract<FILT, KEEP, T>(r.dir, N, s.n1, s.n2, s.eta, ax.eta2, u, proceed, rare);
     const bool dies = reflected && (flags & ORT_F_SKIP_ON_REFLECT);
     st = live ? (proceed ? (dies ? lost : -1) : ended) : st;
 }

@@ -117,6 +117,14 @@ __device__ inline void stage_system(SystemT<float> &dst, const ort_system *src)
     __syncthreads();
 }
 
+// the phase's per-surface derived constants (ort_device.h: SurfAuxT), one thread per surface
+template <class T, class Surf>
+__device__ inline void stage_aux(SurfAuxT<T> *aux, const Surf *surf, int ns)
+{
+    if ((int)threadIdx.x < ns) aux[threadIdx.x] = make_aux<T>(surf[threadIdx.x]);
+    __syncthreads();
+}
+
 // Where this workgroup bins its hits.  The point-source image is a blob of a few thousand
 // 64-byte lines; with one image every wave of the chip queues its atomics on those same
 // lines (measured: +0.19 ms on a 0.75 ms launch at 4 waves/SIMD).  So the hits go to one of
@@ -153,15 +161,15 @@ namespace ort { __device__ unsigned long long abl_sink; }
 // predicate; the loop leaves as soon as no lane of the wave is alive (uniform branch).
 // KEEP: see surface_step — false where only st/xp/yp/nis of an ended ray are read afterwards.
 template <bool FILT, class T, bool EXT, bool KEEP, class Sys, class Surf, class D>
-__device__ inline void walk_pass(const Sys &S, const Surf *surf, int k0, int k1, RayT<T> &r, D &draws,
-                                 int &nis, int &st, int &xp, int &yp, bool &rare)
+__device__ inline void walk_pass(const Sys &S, const Surf *surf, const SurfAuxT<T> *aux, int k0, int k1,
+                                 RayT<T> &r, D &draws, int &nis, int &st, int &xp, int &yp, bool &rare)
 {
     for (int k = k0; k < k1; ++k) {
         if (!wave_any(st < 0)) break;
 #ifdef ORT_DBG_RARE
         const bool before = rare;
 #endif
-        surface_step<FILT, T, EXT, KEEP>(S, surf[k], r, draws, nis, st, xp, yp, rare);
+        surface_step<FILT, T, EXT, KEEP>(S, surf[k], aux[k], r, draws, nis, st, xp, yp, rare);
 #ifdef ORT_DBG_RARE
         if (rare && !before && k < 8) atomicAdd(&ort::ort_dbg_rare[8 + k], 1ull);   // first raise, by surface
 #endif
@@ -174,15 +182,15 @@ __device__ inline void walk_pass(const Sys &S, const Surf *surf, int k0, int k1,
 // register is held for it through the hot pass — with the literal formulas, and the flagged
 // lanes take that run's results.  One rare branch per segment instead of one per predicate.
 template <bool FILT, class T, bool EXT, bool KEEP, class Sys, class Surf, class D, class Restore>
-__device__ inline void walk(const Sys &S, const Surf *surf, int k0, int k1, RayT<T> &r, D &draws,
-                            int &nis, int &st, int &xp, int &yp, Restore restore)
+__device__ inline void walk(const Sys &S, const Surf *surf, const SurfAuxT<T> *aux, int k0, int k1,
+                            RayT<T> &r, D &draws, int &nis, int &st, int &xp, int &yp, Restore restore)
 {
     bool rare = false;
     if constexpr (!FILT) {
-        walk_pass<false, T, EXT, KEEP>(S, surf, k0, k1, r, draws, nis, st, xp, yp, rare);
+        walk_pass<false, T, EXT, KEEP>(S, surf, aux, k0, k1, r, draws, nis, st, xp, yp, rare);
     } else {
         const int nis0 = nis, xp0 = xp, yp0 = yp;
-        walk_pass<true, T, EXT, KEEP>(S, surf, k0, k1, r, draws, nis, st, xp, yp, rare);
+        walk_pass<true, T, EXT, KEEP>(S, surf, aux, k0, k1, r, draws, nis, st, xp, yp, rare);
 #ifdef ORT_ABL_NOREDO
         if (wave_rare(rare)) { if (rare) atomicAdd(&ort::abl_sink, 1ull); }
         if (false) {
@@ -194,7 +202,7 @@ __device__ inline void walk(const Sys &S, const Surf *surf, int k0, int k1, RayT
             int st2, nis2 = nis0, xp2 = xp0, yp2 = yp0;
             bool unused = false;
             restore(r2, d2, st2);
-            walk_pass<false, T, EXT, KEEP>(S, surf, k0, k1, r2, d2, nis2, st2, xp2, yp2, unused);
+            walk_pass<false, T, EXT, KEEP>(S, surf, aux, k0, k1, r2, d2, nis2, st2, xp2, yp2, unused);
             r.pos = vselect(rare, r2.pos, r.pos);
             r.dir = vselect(rare, r2.dir, r.dir);
             draws.take(rare, d2);
@@ -213,7 +221,9 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
     // the re-run launch normally finds its list empty (no workgroup appends while it runs, so
     // every workgroup reads the same count)
     if (MODE != MODE_DEBUG && a.listed && a.redo_ctl[0] == 0) return;
+    __shared__ SurfAuxT<T> AUX[ORT_MAX_SURFACES];
     stage_system(S, a.sys);
+    stage_aux(AUX, S.surfaces[a.phase - 1], S.n_surfaces[a.phase - 1]);
     if (MODE != MODE_DEBUG) {
         if (threadIdx.x < 4) blk[threadIdx.x] = 0;
         __syncthreads();
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
                     if (!wave_any(st < 0)) break;
                     const bool was_live = st < 0;
                     bool unused = false;                 // the tracker walks with the literal predicates
-                    surface_step<false, T, true>(S, surf[k], r, d, nis, st, xp, yp, unused);
+                    surface_step<false, T, true>(S, surf[k], AUX[k], r, d, nis, st, xp, yp, unused);
                     const bool track = (__builtin_amdgcn_readfirstlane((int)surf[k].flags) & ORT_F_TRACK) != 0;
                     push(was_live && (st >= 0 || track));   // where it ended, or a tracked surface passed alive
                 }
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             } else {
                 const Draws d0 = d;
                 const int st0 = st;
-                walk<FILT, T, ANYSRC, true>(S, surf, 0, ns, r, d, nis, st, xp, yp,
+                walk<FILT, T, ANYSRC, true>(S, surf, AUX, 0, ns, r, d, nis, st, xp, yp,
                                             [&](RayT<T> &rr, Draws &dd, int &ss) { rr = em; dd = d0; ss = st0; });
             }
             kdraws = d.k;
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             const RayT<T> r0 = r;
             const KeyedDraws d0 = d;
             const int st0 = st;
-            walk<FILT, T, ANYSRC, false>(S, surf, 0, ns, r, d, nis, st, xp, yp,
+            walk<FILT, T, ANYSRC, false>(S, surf, AUX, 0, ns, r, d, nis, st, xp, yp,
                                          [&](RayT<T> &rr, KeyedDraws &dd, int &ss) { rr = r0; dd = d0; ss = st0; });
         }
         if (!act) continue;
@@ -361,7 +371,9 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
     // scatters (extended instantiation), so only that one carries the count through the queue
     __shared__ int QN[kWavesPerBlock][ANYSRC ? kQueueCap : 1];
     __shared__ unsigned int blk[4];
+    __shared__ SurfAuxT<T> AUX[ORT_MAX_SURFACES];
     stage_system(S, a.sys);
+    stage_aux(AUX, S.surfaces[a.phase - 1], S.n_surfaces[a.phase - 1]);
     if (threadIdx.x < 4) blk[threadIdx.x] = 0;
     __syncthreads();
 
@@ -426,7 +438,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 nis = ANYSRC ? qn[slot] : split;
             }
             bool rare = false;
-            walk_pass<FILT, T, ANYSRC, false>(S, surf, split, ns, r, d, nis, st, xp, yp, rare);
+            walk_pass<FILT, T, ANYSRC, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
                 if (FILT && rare) defer(ray_of_counter(d.z, a.rng_base) - a.first_ray);
                 else finish(st, nis, xp, yp);
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 if (!emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             }
             bool rare = false;
-            walk_pass<FILT, T, ANYSRC, false>(S, surf, 0, split, r, d, nis, st, xp, yp, rare);
+            walk_pass<FILT, T, ANYSRC, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
             const bool deferred = FILT && rare && act;
             const bool survive = act && st < 0 && !deferred;
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(survive);
