@@ -278,17 +278,34 @@ template <> __device__ inline VecT<fastd> vnormalise<fastd>(VecT<fastd> a)
     return {fastd(a.x.v * y), fastd(a.y.v * y), fastd(a.z.v * y)};
 }
 
-// the same at the hot sites: FILT (fp64) takes sqrt_f and the shared division and raises `rare`
-// for a lane that needs the result where either does not apply
+// Normalisation at the hot sites.  FILT (fp64): sqrt_f, then the three quotients v_i / t from
+// the compiler's own division sequence with everything that only serves operands needing
+// v_div_scale's rescaling, or v_div_fixup's special cases, left out: one refined reciprocal of
+// t, then per component  m = v r,  e = fma(-t, m, v),  q = fma(e, r, m)  — exactly what
+// v_div_scale / v_div_fmas / v_div_fixup reduce to when nothing is scaled and nothing is special.
+// That holds when t = |v| lies in (2^-350, 2^350) (sqrt_f's range test) and every component is
+// either exactly zero (the x of each cylinder normal; gives +0 like 0/t) or above 2^-300 in
+// magnitude; |v_i| <= t bounds the quotients by 1.  A lane outside that raises `rare`.
+// tests/csrc/check_exact_ops.hip compares with the IEEE divisions over 2^28 operand sets.
 template <bool FILT, class T>
 __device__ inline VecT<T> vnormalise_f(VecT<T> a, bool need, bool &rare)
 {
 #if !defined(ORT_ABL_FASTDIV)
     if constexpr (FILT && std::is_same<T, double>::value) {
-        const double tmp = sqrt_f<true, double>(a.x * a.x + a.y * a.y + a.z * a.z, need, rare);
-        bool shared;
-        const Vec q = div3_shared(a, tmp, shared);
-        ORT_RARE(1, need && !shared);
+        const double t = sqrt_f<true, double>(a.x * a.x + a.y * a.y + a.z * a.z, need, rare);
+        double r = __builtin_amdgcn_rcp(t);
+        double e = __builtin_fma(-t, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-t, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        const double mx = a.x * r, my = a.y * r, mz = a.z * r;
+        Vec q;
+        q.x = __builtin_fma(__builtin_fma(-t, mx, a.x), r, mx);
+        q.y = __builtin_fma(__builtin_fma(-t, my, a.y), r, my);
+        q.z = __builtin_fma(__builtin_fma(-t, mz, a.z), r, mz);
+        const bool odd = (!(fabs(a.x) > 0x1p-300) && a.x != 0.0) || (!(fabs(a.y) > 0x1p-300) && a.y != 0.0) ||
+                         (!(fabs(a.z) > 0x1p-300) && a.z != 0.0);
+        ORT_RARE(1, need && odd);
         return q;
     }
 #endif

@@ -19,11 +19,16 @@ __device__ inline uint64_t mix(uint64_t z)
 }
 
 // mode 0: any bit pattern (all exponents, NaN, inf, subnormal); mode 1: magnitudes the tracer
-// meets (1e-12 .. 1e3, both signs, and exact zeros)
+// meets (1e-12 .. 1e3, both signs, and exact zeros); mode 2: exponents -340 .. 340
 __device__ inline double operand(uint64_t key, int mode)
 {
     const uint64_t b = mix(key);
     if (mode == 0) return __longlong_as_double((long long)b);
+    if (mode == 2) {                                         // 2^-340 .. 2^340: straddles the guards' thresholds
+        const double mm = 1.0 + (double)(b >> 12) * 0x1p-52;
+        const int ee = (int)((b >> 1) & 1023) % 681 - 340;
+        return (b & 1) ? -ldexp(mm, ee) : ldexp(mm, ee);
+    }
     const double m = 1.0 + (double)(b >> 12) * 0x1p-52;
     const int e = (int)((b >> 4) & 63) - 40;                 // 2^-40 .. 2^23
     double v = ldexp(m, e);
@@ -69,7 +74,7 @@ int main()
     unsigned long long *d_bad, h[6];
     if (hipMalloc(&d_bad, sizeof(h)) != hipSuccess) { printf("no device\n"); return 2; }
     int rc = 0;
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 3; ++mode) {
         (void)hipMemset(d_bad, 0, sizeof(h));
         const uint64_t n = 1ull << 28;
         check<<<4096, 256>>>(n, mode, d_bad);

@@ -20,4 +20,4 @@ def test_expanded_sqrt_and_division_are_bit_identical():
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("mode")]
-    assert len(lines) == 2 and all("mismatches sqrt 0 div3 0 normalise 0" in ln for ln in lines), out.stdout
+    assert len(lines) == 3 and all("mismatches sqrt 0 div3 0 normalise 0" in ln for ln in lines), out.stdout
