@@ -51,8 +51,8 @@ def cpu_baseline(rays: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays", type=int, default=10_000_000, help="rays per GPU per step")
     ap.add_argument("--phase", type=int, default=2, help="2 = point loop (configs[1]); 1 = ring loop")
     ap.add_argument("--cpu-rays", type=int, default=20_000_000)
