@@ -772,7 +772,9 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
         a0.redo_ctl = c->d_redo_ctl;
     }
     const int slot = (int)(c->ring_count % kTimingRing);
-    if (c->timing && evk >= 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
+    // fused traces (evk 0) are timed by the ring's event pair alone: every event record is a
+    // packet the command processor handles between two kernels
+    if (c->timing && evk > 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
     if (c->timing && evk == 0) HIP_TRY(hipEventRecord(c->ring[slot][0], c->stream));
     for (uint64_t off = 0; off < total; off += step) {
         TraceArgs a = a0;
@@ -794,8 +796,8 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     }
     if (use_rep) hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, a0.phase);
     HIP_TRY(hipGetLastError());
-    if (c->timing && evk >= 0) { HIP_TRY(hipEventRecord(c->ev[evk][1], c->stream)); c->ev_valid[evk] = true; }
-    if (c->timing && evk == 0) { HIP_TRY(hipEventRecord(c->ring[slot][1], c->stream)); c->ring_count++; }
+    if (c->timing && evk > 0) { HIP_TRY(hipEventRecord(c->ev[evk][1], c->stream)); c->ev_valid[evk] = true; }
+    if (c->timing && evk == 0) { HIP_TRY(hipEventRecord(c->ring[slot][1], c->stream)); c->ring_count++; c->ev_valid[0] = true; }
     return ORT_OK;
 }
 
@@ -1023,8 +1025,13 @@ int ort_last_kernel_ms(ort_ctx *c, int kind, float *ms)
     *ms = -1.f;
     if (!c->ev_valid[kind]) return ORT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventSynchronize(c->ev[kind][1]));
-    HIP_TRY(hipEventElapsedTime(ms, c->ev[kind][0], c->ev[kind][1]));
+    hipEvent_t e0 = c->ev[kind][0], e1 = c->ev[kind][1];
+    if (kind == 0) {                                   // the most recent slot of the ring
+        const int slot = (int)((c->ring_count - 1) % kTimingRing);
+        e0 = c->ring[slot][0]; e1 = c->ring[slot][1];
+    }
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(ms, e0, e1));
     return ORT_OK;
 }
 
