@@ -935,14 +935,14 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
 // of the bulk kernels; the host picks it when no surface carries ORT_F_SCATTER).
 // KEEP = false lets lanes whose ray has ended carry garbage in r (the bulk kernels read only
 // st/xp/yp/nis of such lanes); KEEP = true freezes r where the ray ended (debug / tracker output).
-template <bool FILT, class T, bool EXT, bool KEEP = true, class Sys, class Surf, class D>
+template <bool FILT, class T, bool EXT, bool KEEP = true, int KIND = -1, int FLAGS = -1, int HASAP = -1, class Sys, class Surf, class D>
 __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<T> &ax, RayT<T> &r, D &draws,
                                     int &nis, int &st, int &xp, int &yp, bool &rare)
 {
     const bool live = st < 0;
-    const int kind = __builtin_amdgcn_readfirstlane(s.kind);
-    const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)s.flags);
-    const bool has_ap = aperture_present<T>(s.aperture);                     // aperture >= 0
+    const int kind = KIND >= 0 ? KIND : __builtin_amdgcn_readfirstlane(s.kind);
+    const unsigned flags = FLAGS >= 0 ? (unsigned)FLAGS : (unsigned)__builtin_amdgcn_readfirstlane((int)s.flags);
+    const bool has_ap = HASAP >= 0 ? (HASAP != 0) : aperture_present<T>(s.aperture);   // aperture >= 0
     const int lost = (flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE;
     nis += live ? 1 : 0;
     VecT<T> N;

@@ -176,6 +176,46 @@ __device__ inline void walk_pass(const Sys &S, const Surf *surf, const SurfAuxT<
     }
 }
 
+// Surface programs known at compile time.  The reference's two loops walk a fixed list in
+// their default set-up (bottle present, no iris, circular bottle): with the kinds, flags and
+// aperture presence as template constants the per-step dispatch (readfirstlane + scalar
+// branches + the blocks they cut the schedule into) disappears and the steps are laid out
+// back to back: -8 % kernel time.  The host selects a program only when the staged system
+// matches it field for field (match_program); everything else runs the generic walk.
+enum { PROG_GENERIC = 0, PROG_POINT = 1, PROG_RING = 2 };
+template <int P> struct Prog;
+template <> struct Prog<PROG_POINT> {          // src/main.f90:127-162: bottle, plano-convex, doublet, image
+    static constexpr int phase = 2, n = 8, split = 5;
+    static constexpr int kind[8] = {ORT_SURF_CYLINDER, ORT_SURF_CYLINDER, ORT_SURF_PLANE, ORT_SURF_SPHERE,
+                                    ORT_SURF_SPHERE, ORT_SURF_SPHERE, ORT_SURF_SPHERE, ORT_SURF_IMAGE};
+    static constexpr int flags[8] = {ORT_F_BOTTLE | ORT_F_SKIP_ON_REFLECT, ORT_F_BOTTLE | ORT_F_SKIP_ON_REFLECT, 0,
+                                     ORT_F_SKIP_ON_REFLECT, ORT_F_SKIP_ON_REFLECT, ORT_F_SKIP_ON_REFLECT,
+                                     ORT_F_SKIP_ON_REFLECT | ORT_F_MISS_IS_HELP3, 0};
+    static constexpr int ap[8] = {0, 0, 1, 0, 1, 0, 0, 0};
+};
+template <> struct Prog<PROG_RING> {           // src/main.f90:90-109: plano-convex, doublet, image
+    static constexpr int phase = 1, n = 6, split = 1;
+    static constexpr int kind[6] = {ORT_SURF_PLANE, ORT_SURF_SPHERE, ORT_SURF_SPHERE, ORT_SURF_SPHERE,
+                                    ORT_SURF_SPHERE, ORT_SURF_IMAGE};
+    static constexpr int flags[6] = {0, ORT_F_SKIP_ON_REFLECT, ORT_F_SKIP_ON_REFLECT, ORT_F_SKIP_ON_REFLECT,
+                                     ORT_F_SKIP_ON_REFLECT | ORT_F_MISS_IS_HELP3, 0};
+    static constexpr int ap[6] = {1, 0, 1, 0, 0, 0};
+};
+
+// steps [K, K1) of program P, each entered only while some lane of the wave is alive
+template <bool FILT, class T, bool KEEP, int P, int K, int K1, class Sys, class Surf, class D>
+__device__ inline void walk_fixed(const Sys &S, const Surf *surf, const SurfAuxT<T> *aux, RayT<T> &r, D &draws,
+                                  int &nis, int &st, int &xp, int &yp, bool &rare)
+{
+    if constexpr (K < K1) {
+        if (wave_any(st < 0)) {
+            surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K]>(
+                S, surf[K], aux[K], r, draws, nis, st, xp, yp, rare);
+            walk_fixed<FILT, T, KEEP, P, K + 1, K1>(S, surf, aux, r, draws, nis, st, xp, yp, rare);
+        }
+    }
+}
+
 // The segment [k0, k1) with the reference's outcome for every lane.  FILT: one pass with the
 // filtered predicates; if any lane raised `rare` (ort_device.h) the wave runs the segment again
 // from its initial state — `restore(r, draws, st)` re-creates it: reloaded or re-emitted, so no
@@ -362,9 +402,10 @@ __device__ inline int lane_prefix(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-template <int MODE, bool FILT, bool ANYSRC, class T>
-__global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(TraceArgs a)
+template <int MODE, bool FILT, bool ANYSRC, class T, int PROG = PROG_GENERIC>
+__global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) void trace_queue_kernel(TraceArgs a)
 {
+    static_assert(PROG == PROG_GENERIC || (FILT && !ANYSRC), "programs exist for the lean filtered kernel only");
     __shared__ ort_system S;
     __shared__ double Q[kWavesPerBlock][kQueueFields][kQueueCap];
     // intersections evaluated before the queue point: `split` for every survivor unless a surface
@@ -381,11 +422,17 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
     const int wave = threadIdx.x >> 6;
     double (*q)[kQueueCap] = Q[wave];
     int *qn = QN[wave];
-    const int ph = a.phase - 1;
+    constexpr bool fixed = PROG != PROG_GENERIC;        // surface program known at compile time
+    int phase = a.phase, ns, split;
+    if constexpr (fixed) {
+        phase = Prog<PROG>::phase; ns = Prog<PROG>::n; split = Prog<PROG>::split;   // host: match_program
+    } else {
+        ns = S.n_surfaces[phase - 1];
+        split = S.split[phase - 1];
+        if (split <= 0 || split >= ns) split = ns;      // no queue point: one segment
+    }
+    const int ph = phase - 1;
     const ort_surface *surf = S.surfaces[ph];
-    const int ns = S.n_surfaces[ph];
-    int split = S.split[ph];
-    if (split <= 0 || split >= ns) split = ns;          // no queue point: one segment
     int32_t *layer = hist_layer(a);
     const uint64_t n = a.n_rays;
     const uint64_t ns_in = a.in_stride;
@@ -438,7 +485,8 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 nis = ANYSRC ? qn[slot] : split;
             }
             bool rare = false;
-            walk_pass<FILT, T, ANYSRC, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
+            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n>(S, surf, AUX, r, d, nis, st, xp, yp, rare);
+            else walk_pass<FILT, T, ANYSRC, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
                 if (FILT && rare) defer(ray_of_counter(d.z, a.rng_base) - a.first_ray);
                 else finish(st, nis, xp, yp);
@@ -459,10 +507,11 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_queue_kernel(Trac
                 r.dir = {T(a.pos_dir_in[3 * ns_in + ic]), T(a.pos_dir_in[4 * ns_in + ic]), T(a.pos_dir_in[5 * ns_in + ic])};
             } else {
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                if (!emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
+                if (!emit<T, ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             }
             bool rare = false;
-            walk_pass<FILT, T, ANYSRC, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
+            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split>(S, surf, AUX, r, d, nis, st, xp, yp, rare);
+            else walk_pass<FILT, T, ANYSRC, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
             const bool deferred = FILT && rare && act;
             const bool survive = act && st < 0 && !deferred;
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(survive);
@@ -573,11 +622,29 @@ struct ort_ctx {
     int precision;               // 0 fp64 (reference arithmetic), 1 fp32 (study path)
     int emitter[2];              // host copy of ort_system.emitter
     bool scatter;                // some surface carries ORT_F_SCATTER
+    int prog[2];                 // per phase: PROG_* the staged system matches (match_program)
     hipEvent_t ev[3][2];
     hipEvent_t ring[kTimingRing][2];   // fused-trace launches, most recent kTimingRing
     unsigned long long ring_count;
     bool ev_valid[3];
 };
+
+// does the surface list of `phase` equal program P field for field (kinds, flags other than the
+// tracker's, aperture presence, queue point, default emitter)?
+template <int P>
+static bool matches(const ort_system *sys)
+{
+    const int p = Prog<P>::phase - 1;
+    if (sys->n_surfaces[p] != Prog<P>::n || sys->split[p] != Prog<P>::split) return false;
+    if (sys->emitter[p] != (p == 0 ? ORT_EMIT_RING : ORT_EMIT_POINT)) return false;
+    for (int k = 0; k < Prog<P>::n; ++k) {
+        const ort_surface &s = sys->surfaces[p][k];
+        if (s.kind != Prog<P>::kind[k] || (int)(s.flags & ~ORT_F_TRACK) != Prog<P>::flags[k] ||
+            (s.aperture >= 0.0) != (Prog<P>::ap[k] != 0))
+            return false;
+    }
+    return true;
+}
 
 static void note_system(ort_ctx *c, const ort_system *sys)
 {
@@ -586,6 +653,28 @@ static void note_system(ort_ctx *c, const ort_system *sys)
     for (int p = 0; p < 2; ++p)
         for (int k = 0; k < sys->n_surfaces[p]; ++k)
             if (sys->surfaces[p][k].flags & ORT_F_SCATTER) c->scatter = true;
+    c->prog[0] = matches<PROG_RING>(sys) ? PROG_RING : PROG_GENERIC;
+    c->prog[1] = matches<PROG_POINT>(sys) ? PROG_POINT : PROG_GENERIC;
+    if (getenv("ORT_NO_PROGRAMS")) c->prog[0] = c->prog[1] = PROG_GENERIC;      // development knob (A/B)
+}
+
+// The lean queued kernel (default emitters, no scattering, filtered predicates): specialised for
+// the surface program the staged system matches, generic otherwise.
+template <class T>
+static void launch_lean(ort_ctx *c, int mode, const TraceArgs &a, int grid)
+{
+#define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
+    const int prog = c->prog[a.phase - 1];
+    if (mode == MODE_FUSED) {
+        if (prog == PROG_POINT) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, T, PROG_POINT>));
+        else if (prog == PROG_RING) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, T, PROG_RING>));
+        else ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, T>));
+    } else {
+        if (prog == PROG_POINT) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, T, PROG_POINT>));
+        else if (prog == PROG_RING) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, T, PROG_RING>));
+        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, T>));
+    }
+#undef ORT_LAUNCH
 }
 
 extern "C" {
@@ -714,8 +803,7 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
             if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true, fastd>));
             else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true, fastd>));
         } else {
-            if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, fastd>));
-            else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, fastd>));
+            launch_lean<fastd>(c, mode, a, grid);
         }
     } else if (c->precision == 1) {
         // fp32 study path (BASELINE configs[4]): lockstep kernel, literal predicates
@@ -736,8 +824,7 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
         }
     } else {
         // the default emitters (ring / point) without scattering have their own, leaner instantiation
-        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, double>));
-        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, double>));
+        launch_lean<double>(c, mode, a, grid);
     }
 #undef ORT_LAUNCH
 }
