@@ -8,6 +8,8 @@ Bars (north_star): per-ray results within 1e-10 relative fp64.  What is actually
   * images of keyed runs: identical up to a tiny budget of rays whose emission ulp
     flips a discrete decision (SURVEY §7 "transcendental differences").
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -446,3 +448,33 @@ def test_launches_are_cut_at_the_rerun_list_capacity(ctxs):
     img_c, cnt_c = ctx.read()
     del bundle
     assert np.array_equal(img_a, img_c) and np.array_equal(cnt_a, cnt_c)
+
+
+@pytest.mark.parametrize("name", ["large", "small", "large_iris_before", "ellipse"])
+def test_program_kernels_equal_the_generic_walk(name, hip_library):
+    """The queued kernel is specialised for the two default surface programs (kinds, flags and
+    aperture presence as template constants) when the staged system matches one; ORT_NO_PROGRAMS
+    forces the generic walk.  Same image, same counters — also for systems that match no program
+    (iris, elliptical bottle), where both contexts run the generic kernel."""
+    from opticalraytrace_amd.capi import Context
+    _, osys = make_system(name)
+    n = 300000
+    results = []
+    for no_programs in (False, True):
+        if no_programs:
+            os.environ["ORT_NO_PROGRAMS"] = "1"
+        try:
+            ctx = Context(osys)
+        finally:
+            os.environ.pop("ORT_NO_PROGRAMS", None)
+        for variant in (1, 0):
+            ctx.set_kernel_variant(variant)
+            ctx.reset()
+            ctx.trace(2, 0, n, SEED)
+            ctx.trace(1, 5, n, SEED)
+            results.append(ctx.read())
+        ctx.close()
+    img0, cnt0 = results[0]
+    assert int(cnt0[2]) > 0 and int(cnt0[3]) > 0
+    for img, cnt in results[1:]:
+        assert np.array_equal(img, img0) and np.array_equal(cnt, cnt0)
