@@ -380,7 +380,7 @@ template <> struct SysTypes<fastd> { using Sys = ort_system; using Surf = ort_su
 // the filtered path reads them; the literal path recomputes from the surface record.
 template <class T> struct SurfAuxT { T r2, ap2, ap_tol, eta2, ell_sa, ell_sb; };
 template <class T, class Surf>
-__device__ inline SurfAuxT<T> make_aux(const Surf &s)
+__host__ __device__ inline SurfAuxT<T> make_aux(const Surf &s)
 {
     SurfAuxT<T> a;
     const T r = s.radius, rb = s.radius_b, A = s.aperture, e = s.eta;

@@ -51,7 +51,8 @@ constexpr int kRedoBlocks = 128;        // grid of the literal re-run kernel (it
 enum { MODE_FUSED = 0, MODE_RESIDENT = 1, MODE_DEBUG = 2 };
 
 struct TraceArgs {
-    const ort_system *sys;       // device copy
+    const ort_system *sys;       // device copy (DevSystem.sys)
+    const SurfAuxT<double> *aux; // DevSystem.aux[phase - 1]: read by the program kernels through scalar loads
     int32_t *image;              // [2][401][401]
     int32_t *replicas;           // [kReplicas][2][401][401] or null: see fold_kernel
     unsigned long long *counters;
@@ -176,6 +177,40 @@ __device__ inline void walk_pass(const Sys &S, const Surf *surf, const SurfAuxT<
     }
 }
 
+// What a context keeps on the device: the system as the caller staged it, plus the derived
+// per-surface constants (SurfAuxT; formed on the host by the same IEEE operations).
+struct DevSystem {
+    ort_system sys;
+    SurfAuxT<double> aux[2][ORT_MAX_SURFACES];
+};
+
+// The program kernels know each step's surface index at compile time, so they read its record
+// straight from the device copy through the CONSTANT address space: uniform address + constant
+// memory = scalar loads (s_load_dwordx*) into SGPRs.  The values then feed the vector
+// instructions as scalar operands instead of occupying VGPRs (an LDS read lands in VGPRs), which
+// is what lets the unrolled kernel fit 128 VGPRs without spilling.
+typedef const __attribute__((address_space(4))) ort_surface *const_surf_t;
+typedef const __attribute__((address_space(4))) SurfAuxT<double> *const_aux_t;
+
+__device__ inline ort_surface load_surface(const_surf_t p)
+{
+    ort_surface s;
+    s.cx = p->cx; s.cy = p->cy; s.cz = p->cz; s.radius = p->radius; s.radius_b = p->radius_b;
+    s.n1 = p->n1; s.n2 = p->n2; s.eta = p->eta; s.aperture = p->aperture;
+    s.mua = p->mua; s.mus = p->mus; s.hgg = p->hgg; s.scat_radius = p->scat_radius;
+    s.kind = p->kind; s.flags = p->flags;
+    return s;
+}
+
+template <class T>
+__device__ inline SurfAuxT<T> load_aux(const_aux_t p)
+{
+    SurfAuxT<T> a;
+    a.r2 = T(p->r2); a.ap2 = T(p->ap2); a.ap_tol = T(p->ap_tol); a.eta2 = T(p->eta2);
+    a.ell_sa = T(p->ell_sa); a.ell_sb = T(p->ell_sb);
+    return a;
+}
+
 // Surface programs known at compile time.  The reference's two loops walk a fixed list in
 // their default set-up (bottle present, no iris, circular bottle): with the kinds, flags and
 // aperture presence as template constants the per-step dispatch (readfirstlane + scalar
@@ -203,14 +238,16 @@ template <> struct Prog<PROG_RING> {           // src/main.f90:90-109: plano-con
 };
 
 // steps [K, K1) of program P, each entered only while some lane of the wave is alive
-template <bool FILT, class T, bool KEEP, int P, int K, int K1, class Sys, class Surf, class D>
-__device__ inline void walk_fixed(const Sys &S, const Surf *surf, const SurfAuxT<T> *aux, RayT<T> &r, D &draws,
+template <bool FILT, class T, bool KEEP, int P, int K, int K1, class Sys, class D>
+__device__ inline void walk_fixed(const Sys &S, const_surf_t surf, const_aux_t aux, RayT<T> &r, D &draws,
                                   int &nis, int &st, int &xp, int &yp, bool &rare)
 {
     if constexpr (K < K1) {
         if (wave_any(st < 0)) {
+            const ort_surface s = load_surface(surf + K);
+            const SurfAuxT<T> ax = load_aux<T>(aux + K);
             surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K]>(
-                S, surf[K], aux[K], r, draws, nis, st, xp, yp, rare);
+                S, s, ax, r, draws, nis, st, xp, yp, rare);
             walk_fixed<FILT, T, KEEP, P, K + 1, K1>(S, surf, aux, r, draws, nis, st, xp, yp, rare);
         }
     }
@@ -412,9 +449,9 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     // scatters (extended instantiation), so only that one carries the count through the queue
     __shared__ int QN[kWavesPerBlock][ANYSRC ? kQueueCap : 1];
     __shared__ unsigned int blk[4];
-    __shared__ SurfAuxT<T> AUX[ORT_MAX_SURFACES];
+    __shared__ SurfAuxT<T> AUX[PROG == PROG_GENERIC ? ORT_MAX_SURFACES : 1];
     stage_system(S, a.sys);
-    stage_aux(AUX, S.surfaces[a.phase - 1], S.n_surfaces[a.phase - 1]);
+    if (PROG == PROG_GENERIC) stage_aux(AUX, S.surfaces[a.phase - 1], S.n_surfaces[a.phase - 1]);
     if (threadIdx.x < 4) blk[threadIdx.x] = 0;
     __syncthreads();
 
@@ -433,6 +470,8 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     }
     const int ph = phase - 1;
     const ort_surface *surf = S.surfaces[ph];
+    const const_surf_t csurf = (const_surf_t)a.sys->surfaces[ph];     // program kernels: scalar loads
+    const const_aux_t caux = (const_aux_t)a.aux;
     int32_t *layer = hist_layer(a);
     const uint64_t n = a.n_rays;
     const uint64_t ns_in = a.in_stride;
@@ -485,7 +524,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 nis = ANYSRC ? qn[slot] : split;
             }
             bool rare = false;
-            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n>(S, surf, AUX, r, d, nis, st, xp, yp, rare);
+            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
             else walk_pass<FILT, T, ANYSRC, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
                 if (FILT && rare) defer(ray_of_counter(d.z, a.rng_base) - a.first_ray);
@@ -510,7 +549,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 if (!emit<T, ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
             }
             bool rare = false;
-            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split>(S, surf, AUX, r, d, nis, st, xp, yp, rare);
+            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
             else walk_pass<FILT, T, ANYSRC, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
             const bool deferred = FILT && rare && act;
             const bool survive = act && st < 0 && !deferred;
@@ -609,7 +648,7 @@ struct ort_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
-    ort_system *d_sys;
+    DevSystem *d_sys;
     int32_t *d_image, *own_image;
     int32_t *d_replicas;         // kReplicas zeroed images (scratch between trace and fold)
     uint32_t *d_redo_list;       // re-run list of the queued filtered kernel, redo_cap entries
@@ -656,6 +695,18 @@ static void note_system(ort_ctx *c, const ort_system *sys)
     c->prog[0] = matches<PROG_RING>(sys) ? PROG_RING : PROG_GENERIC;
     c->prog[1] = matches<PROG_POINT>(sys) ? PROG_POINT : PROG_GENERIC;
     if (getenv("ORT_NO_PROGRAMS")) c->prog[0] = c->prog[1] = PROG_GENERIC;      // development knob (A/B)
+}
+
+// system + derived per-surface constants -> device (synchronises: the staging copy is a local)
+static int upload_system(ort_ctx *c, const ort_system *sys)
+{
+    DevSystem h;
+    h.sys = *sys;
+    for (int p = 0; p < 2; ++p)
+        for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.aux[p][k] = make_aux<double>(sys->surfaces[p][k]);
+    HIP_TRY(hipMemcpyAsync(c->d_sys, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORT_OK;
 }
 
 // The lean queued kernel (default emitters, no scattering, filtered predicates): specialised for
@@ -713,7 +764,7 @@ int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out)
     // whatever else the caller runs there (torch's default stream, RCCL's stream dependencies)
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
-    HIP_TRY(hipMalloc(&c->d_sys, sizeof(ort_system)));
+    HIP_TRY(hipMalloc(&c->d_sys, sizeof(DevSystem)));
     HIP_TRY(hipMalloc(&c->own_image, ORT_IMAGE_BINS * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->own_counters, ORT_NUM_COUNTERS * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&c->d_replicas, (size_t)kReplicas * ORT_IMAGE_BINS * sizeof(int32_t)));
@@ -731,7 +782,8 @@ int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out)
         HIP_TRY(hipEventCreate(&c->ring[k][1]));
     }
     note_system(c, sys);
-    HIP_TRY(hipMemcpyAsync(c->d_sys, sys, sizeof(ort_system), hipMemcpyHostToDevice, c->stream));
+    rc = upload_system(c, sys);
+    if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->d_image, 0, ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, ORT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -760,10 +812,7 @@ int ort_set_system(ort_ctx *c, const ort_system *sys)
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     note_system(c, sys);
-    // the copy source must stay valid until the copy has run: synchronise
-    HIP_TRY(hipMemcpyAsync(c->d_sys, sys, sizeof(ort_system), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return ORT_OK;
+    return upload_system(c, sys);
 }
 
 int ort_set_image_source(ort_ctx *c, const int64_t *cdf)
@@ -831,7 +880,8 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
 
 static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
 {
-    a0.sys = c->d_sys; a0.image = c->d_image; a0.counters = c->d_counters;
+    a0.sys = &c->d_sys->sys; a0.aux = c->d_sys->aux[a0.phase - 1];
+    a0.image = c->d_image; a0.counters = c->d_counters;
     const bool use_rep = (c->variant & 4) == 0 && mode != MODE_DEBUG;
     a0.replicas = use_rep ? c->d_replicas : nullptr;
     a0.img_cdf = c->d_img_cdf;
@@ -924,7 +974,7 @@ int ort_emit(ort_ctx *c, int phase, uint64_t first_ray, uint64_t n_rays, uint64_
     HIP_TRY(hipSetDevice(c->device));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2][0], c->stream));
     hipLaunchKernelGGL(emit_kernel, dim3(grid_for(n_rays)), dim3(kBlock), 0, c->stream,
-                       c->d_sys, phase, first_ray, n_rays, stream_base(seed, phase), d_pos_dir,
+                       &c->d_sys->sys, phase, first_ray, n_rays, stream_base(seed, phase), d_pos_dir,
                        (const long long *)c->d_img_cdf);
     HIP_TRY(hipGetLastError());
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[2][1], c->stream)); c->ev_valid[2] = true; }
