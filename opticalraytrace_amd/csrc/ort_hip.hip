@@ -217,24 +217,54 @@ __device__ inline SurfAuxT<T> load_aux(const_aux_t p)
 // branches + the blocks they cut the schedule into) disappears and the steps are laid out
 // back to back: -8 % kernel time.  The host selects a program only when the staged system
 // matches it field for field (match_program); everything else runs the generic walk.
-enum { PROG_GENERIC = 0, PROG_POINT = 1, PROG_RING = 2 };
+enum { PROG_GENERIC = 0, PROG_POINT, PROG_RING, PROG_POINT_IRIS_B, PROG_POINT_IRIS_A, PROG_RING_IRIS_B, PROG_RING_IRIS_A };
+// every program but the generic one: X(name)
+#define ORT_PROGRAMS(X) X(PROG_POINT) X(PROG_RING) X(PROG_POINT_IRIS_B) X(PROG_POINT_IRIS_A) X(PROG_RING_IRIS_B) X(PROG_RING_IRIS_A)
+
+namespace prog {
+constexpr int CYL = ORT_SURF_CYLINDER, PLN = ORT_SURF_PLANE, SPH = ORT_SURF_SPHERE, IRS = ORT_SURF_IRIS, IMG = ORT_SURF_IMAGE;
+constexpr int SK = ORT_F_SKIP_ON_REFLECT, BT = ORT_F_BOTTLE | ORT_F_SKIP_ON_REFLECT, H3 = ORT_F_SKIP_ON_REFLECT | ORT_F_MISS_IS_HELP3;
+}
 template <int P> struct Prog;
-template <> struct Prog<PROG_POINT> {          // src/main.f90:127-162: bottle, plano-convex, doublet, image
+// point loop, src/main.f90:127-162: bottle (2 cylinders), plano-convex (flat, curved), doublet (3 faces), image
+template <> struct Prog<PROG_POINT> {
     static constexpr int phase = 2, n = 8, split = 5;
-    static constexpr int kind[8] = {ORT_SURF_CYLINDER, ORT_SURF_CYLINDER, ORT_SURF_PLANE, ORT_SURF_SPHERE,
-                                    ORT_SURF_SPHERE, ORT_SURF_SPHERE, ORT_SURF_SPHERE, ORT_SURF_IMAGE};
-    static constexpr int flags[8] = {ORT_F_BOTTLE | ORT_F_SKIP_ON_REFLECT, ORT_F_BOTTLE | ORT_F_SKIP_ON_REFLECT, 0,
-                                     ORT_F_SKIP_ON_REFLECT, ORT_F_SKIP_ON_REFLECT, ORT_F_SKIP_ON_REFLECT,
-                                     ORT_F_SKIP_ON_REFLECT | ORT_F_MISS_IS_HELP3, 0};
-    static constexpr int ap[8] = {0, 0, 1, 0, 1, 0, 0, 0};
+    static constexpr int kind[n] = {prog::CYL, prog::CYL, prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
+    static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
+    static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 0};
 };
-template <> struct Prog<PROG_RING> {           // src/main.f90:90-109: plano-convex, doublet, image
+// ring loop, src/main.f90:90-109: plano-convex, doublet, image
+template <> struct Prog<PROG_RING> {
     static constexpr int phase = 1, n = 6, split = 1;
-    static constexpr int kind[6] = {ORT_SURF_PLANE, ORT_SURF_SPHERE, ORT_SURF_SPHERE, ORT_SURF_SPHERE,
-                                    ORT_SURF_SPHERE, ORT_SURF_IMAGE};
-    static constexpr int flags[6] = {0, ORT_F_SKIP_ON_REFLECT, ORT_F_SKIP_ON_REFLECT, ORT_F_SKIP_ON_REFLECT,
-                                     ORT_F_SKIP_ON_REFLECT | ORT_F_MISS_IS_HELP3, 0};
-    static constexpr int ap[6] = {1, 0, 1, 0, 0, 0};
+    static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
+    static constexpr int flags[n] = {0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
+    static constexpr int ap[n] = {1, 0, 1, 0, 0, 0};
+};
+// the same with the iris in front of the doublet (src/lens.f90:551-565) ...
+template <> struct Prog<PROG_POINT_IRIS_B> {
+    static constexpr int phase = 2, n = 9, split = 6;
+    static constexpr int kind[n] = {prog::CYL, prog::CYL, prog::PLN, prog::SPH, prog::IRS, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
+    static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, 0, prog::SK, prog::SK, prog::H3, 0};
+    static constexpr int ap[n] = {0, 0, 1, 0, 1, 1, 0, 0, 0};
+};
+template <> struct Prog<PROG_RING_IRIS_B> {
+    static constexpr int phase = 1, n = 7, split = 1;
+    static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::IRS, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
+    static constexpr int flags[n] = {0, prog::SK, 0, prog::SK, prog::SK, prog::H3, 0};
+    static constexpr int ap[n] = {1, 0, 1, 1, 0, 0, 0};
+};
+// ... and behind it (src/lens.f90:632-644)
+template <> struct Prog<PROG_POINT_IRIS_A> {
+    static constexpr int phase = 2, n = 9, split = 5;
+    static constexpr int kind[n] = {prog::CYL, prog::CYL, prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IRS, prog::IMG};
+    static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, prog::SK, prog::SK, prog::H3, 0, 0};
+    static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 1, 0};
+};
+template <> struct Prog<PROG_RING_IRIS_A> {
+    static constexpr int phase = 1, n = 7, split = 1;
+    static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IRS, prog::IMG};
+    static constexpr int flags[n] = {0, prog::SK, prog::SK, prog::SK, prog::H3, 0, 0};
+    static constexpr int ap[n] = {1, 0, 1, 0, 0, 1, 0};
 };
 
 // steps [K, K1) of program P, each entered only while some lane of the wave is alive
@@ -692,8 +722,10 @@ static void note_system(ort_ctx *c, const ort_system *sys)
     for (int p = 0; p < 2; ++p)
         for (int k = 0; k < sys->n_surfaces[p]; ++k)
             if (sys->surfaces[p][k].flags & ORT_F_SCATTER) c->scatter = true;
-    c->prog[0] = matches<PROG_RING>(sys) ? PROG_RING : PROG_GENERIC;
-    c->prog[1] = matches<PROG_POINT>(sys) ? PROG_POINT : PROG_GENERIC;
+    c->prog[0] = c->prog[1] = PROG_GENERIC;
+#define ORT_MATCH(P) if (matches<P>(sys)) c->prog[Prog<P>::phase - 1] = P;
+    ORT_PROGRAMS(ORT_MATCH)
+#undef ORT_MATCH
     if (getenv("ORT_NO_PROGRAMS")) c->prog[0] = c->prog[1] = PROG_GENERIC;      // development knob (A/B)
 }
 
@@ -716,15 +748,18 @@ static void launch_lean(ort_ctx *c, int mode, const TraceArgs &a, int grid)
 {
 #define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
     const int prog = c->prog[a.phase - 1];
-    if (mode == MODE_FUSED) {
-        if (prog == PROG_POINT) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, T, PROG_POINT>));
-        else if (prog == PROG_RING) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, T, PROG_RING>));
-        else ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, T>));
-    } else {
-        if (prog == PROG_POINT) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, T, PROG_POINT>));
-        else if (prog == PROG_RING) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, T, PROG_RING>));
+#define ORT_CASE(P)                                                                                        \
+    case P:                                                                                                \
+        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, T, P>));           \
+        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, T, P>));                           \
+        break;
+    switch (prog) {
+        ORT_PROGRAMS(ORT_CASE)
+    default:
+        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, T>));
         else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, T>));
     }
+#undef ORT_CASE
 #undef ORT_LAUNCH
 }
 
