@@ -2,7 +2,7 @@
 //
 // Kernels (device functions: ort_device.h; the arithmetic type T is double = the reference's
 // arithmetic, bit-exact; float = fp32 study path; fastd = opt-in fast fp64, ort_fastd.h)
-//   trace_queue_kernel<MODE, FILT, EXT, T>   the production kernel.  One wavefront = one ray
+//   trace_queue_kernel<MODE, FILT, EXT, T, PROG>   the production kernel.  One wavefront = one ray
 //       bundle over a contiguous range of global ray indices; the 2.7 KB ort_system (surface
 //       lists + emitter + image constants) is staged into LDS once per workgroup; a ray lives
 //       in VGPRs from emission to binning; survivors of the first surface segment are
@@ -16,6 +16,9 @@
 //                        re-run list and it leaves the kernel without side effect
 //         EXT            also compiles the rarely used emitters (spot, crs, image) and the
 //                        in-bottle scattering walk; the default instantiation leaves them out
+//         PROG           the surface list as template constants (Prog<P>: the default point /
+//                        ring systems and their iris variants), steps unrolled, surface records
+//                        through scalar loads; PROG_GENERIC walks any staged list
 //   trace_kernel<MODE, FILT, T, EXT>         plain lockstep thread-per-ray walk: the literal
 //       re-run of the listed rays right after the queued kernel (normally an empty list), the
 //       parity / debug entry (MODE_DEBUG: per-ray outputs, tracker paths, no side effect), the
