@@ -687,24 +687,39 @@ __device__ inline void scatter_walk(const Surf &s, T twopi, RayT<T> &r, T &t, bo
 // subtraction with FMAs (exact to ~1e-32 for k <= 8), then the classic minimax kernels on
 // [-pi/4, pi/4] (coefficients: Sun fdlibm k_sin.c / k_cos.c), error < 1 ulp — the same class as
 // the device library's sincos (<= 2 ulp from the reference's glibc), at a third of its
-// instructions (it carries a Payne-Hanek path for huge arguments).  Larger arguments: the library.
+// instructions (it carries a Payne-Hanek path for huge arguments).  The reduction stays exact
+// enough (k * 2^-106) far beyond any angle the tracer forms.
+// A 64-bit constant as a SCALAR value: fp64 vector instructions take no 64-bit literal, and left
+// to itself the compiler parks such constants in VGPRs for the whole kernel (26 VGPRs for the
+// polynomial coefficients below).  Two s_mov_b32 give the register allocator a uniform value it
+// keeps in SGPRs (one scalar operand per vector instruction is free).
+__device__ inline double scalar_const(double v)
+{
+    const uint64_t bits = __builtin_bit_cast(uint64_t, v);
+    uint32_t lo, hi;
+    asm("s_mov_b32 %0, %1" : "=s"(lo) : "i"((uint32_t)bits));
+    asm("s_mov_b32 %0, %1" : "=s"(hi) : "i"((uint32_t)(bits >> 32)));
+    return __hiloint2double((int)hi, (int)lo);
+}
+#define ORT_SC(v) scalar_const(v)
+
 __device__ inline void sincos_small(double x, double *s, double *c)
 {
-    const double k = __builtin_rint(x * 6.36619772367581382433e-01);        // x * 2/pi
-    double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
-    r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+    const double k = __builtin_rint(x * ORT_SC(6.36619772367581382433e-01));        // x * 2/pi
+    double r = __builtin_fma(-k, ORT_SC(1.57079632679489655800e+00), x);
+    r = __builtin_fma(-k, ORT_SC(6.12323399573676603587e-17), r);
     const double z = r * r;
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    double ps = __builtin_fma(z, ORT_SC(1.58969099521155010221e-10), ORT_SC(-2.50507602534068634195e-08));
+    ps = __builtin_fma(z, ps, ORT_SC(2.75573137070700676789e-06));
+    ps = __builtin_fma(z, ps, ORT_SC(-1.98412698298579493134e-04));
+    ps = __builtin_fma(z, ps, ORT_SC(8.33333333332248946124e-03));
+    ps = __builtin_fma(z, ps, ORT_SC(-1.66666666666666324348e-01));
     const double sr = __builtin_fma(r * z, ps, r);
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    double pc = __builtin_fma(z, ORT_SC(-1.13596475577881948265e-11), ORT_SC(2.08757232129817482790e-09));
+    pc = __builtin_fma(z, pc, ORT_SC(-2.75573143513906633035e-07));
+    pc = __builtin_fma(z, pc, ORT_SC(2.48015872894767294178e-05));
+    pc = __builtin_fma(z, pc, ORT_SC(-1.38888888888741095749e-03));
+    pc = __builtin_fma(z, pc, ORT_SC(4.16666666666666019037e-02));
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double cr = w + (((1.0 - w) - hz) + z * z * pc);                  // k_cos.c's compensated form
@@ -714,11 +729,9 @@ __device__ inline void sincos_small(double x, double *s, double *c)
     *s = (n & 2) ? -ss : ss;
     *c = ((n + 1) & 2) ? -cc : cc;
 }
-template <> __device__ inline void sincos_t<double>(double x, double *s, double *c)
-{
-    if (wave_any(!(fabs(x) < 12.0))) sincos(x, s, c);   // not reached by the emitters (NaN included)
-    else sincos_small(x, s, c);
-}
+// every call site passes an angle in [0, 2 pi] (twopi * u, a bounded fan angle, a direction's
+// azimuth); no fallback to the device library here: its constants alone would sit in 18 VGPRs
+template <> __device__ inline void sincos_t<double>(double x, double *s, double *c) { sincos_small(x, s, c); }
 template <> __device__ inline void sincos_t<fastd>(fastd x, fastd *s, fastd *c) { sincos_t<double>(x.v, &s->v, &c->v); }
 template <> __device__ inline void sincos_t<float>(float x, float *s, float *c) { sincosf(x, s, c); }
 
