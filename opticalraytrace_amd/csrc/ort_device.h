@@ -287,12 +287,14 @@ template <> __device__ inline VecT<fastd> vnormalise<fastd>(VecT<fastd> a)
 // either exactly zero (the x of each cylinder normal; gives +0 like 0/t) or above 2^-300 in
 // magnitude; |v_i| <= t bounds the quotients by 1.  A lane outside that raises `rare`.
 // tests/csrc/check_exact_ops.hip compares with the IEEE divisions over 2^28 operand sets.
+// the three quotients v_i / t of that scheme alone: requires t in (2^-350, 2^350) (the caller's
+// sqrt_f guarantees it for t = sqrt(s)) and |v_i| <= t up to rounding (components of the vector
+// whose length t is)
 template <bool FILT, class T>
-__device__ inline VecT<T> vnormalise_f(VecT<T> a, bool need, bool &rare)
+__device__ inline VecT<T> div3_f(VecT<T> a, T t, bool need, bool &rare)
 {
 #if !defined(ORT_ABL_FASTDIV)
     if constexpr (FILT && std::is_same<T, double>::value) {
-        const double t = sqrt_f<true, double>(a.x * a.x + a.y * a.y + a.z * a.z, need, rare);
         double r = __builtin_amdgcn_rcp(t);
         double e = __builtin_fma(-t, r, 1.0);
         r = __builtin_fma(r, e, r);
@@ -309,6 +311,16 @@ __device__ inline VecT<T> vnormalise_f(VecT<T> a, bool need, bool &rare)
         return q;
     }
 #endif
+    return div3(a, t);
+}
+
+template <bool FILT, class T>
+__device__ inline VecT<T> vnormalise_f(VecT<T> a, bool need, bool &rare)
+{
+    if constexpr (FILT && std::is_same<T, double>::value) {
+        const double t = sqrt_f<true, double>(a.x * a.x + a.y * a.y + a.z * a.z, need, rare);
+        return div3_f<true, double>(a, t, need, rare);
+    }
     return vnormalise(a);
 }
 
@@ -738,44 +750,46 @@ template <> __device__ inline void sincos_t<float>(float x, float *s, float *c) 
 // ----------------------------------------------------------------------------
 // emitters (straight-line)
 // ----------------------------------------------------------------------------
-// point, src/sourceMod.f90:12-47 (called without offset, src/main.f90:136)
-template <class T, class Sys, class D>
-__device__ inline void emit_point(const Sys &S, RayT<T> &r, D &draws)
+// point, src/sourceMod.f90:12-47 (called without offset, src/main.f90:136).  FILT (the queued
+// kernels): square roots and normalisations in their range-guarded exact forms (sqrt_f, div3_f),
+// a ray outside their ranges raises `rare` and is emitted and traced literally afterwards.
+template <class T, bool FILT = false, class Sys, class D>
+__device__ inline void emit_point(const Sys &S, RayT<T> &r, D &draws, bool &rare)
 {
     T phi = S.twopi * draws.template next_as<T>();
     T sinp, cosp;
     sincos_t<T>(phi, &sinp, &cosp);
     T ran = draws.template next_as<T>();
     T cost = (T(1.0) - ran) + ran * S.cos_theta_max;
-    T sint = ORT_SQRT(T(1.0) - cost * cost);
+    T sint = sqrt_f<FILT, T>(T(1.0) - cost * cost, true, rare);
     r.dir = {sint * cosp, sint * sinp, cost};
     r.pos = {T(0.0), T(0.0), T(0.0)};
 }
 
 // ring, src/sourceMod.f90:250-300
-template <class T, class Sys, class D>
-__device__ inline void emit_ring(const Sys &S, RayT<T> &r, D &draws)
+template <class T, bool FILT = false, class Sys, class D>
+__device__ inline void emit_ring(const Sys &S, RayT<T> &r, D &draws, bool &rare)
 {
     T rr = S.ring_r1 + draws.template next_as<T>() * (S.ring_r2 - S.ring_r1);     // ranu(r1, r2)
     T theta = draws.template next_as<T>() * S.twopi;
     T st, ct;
     sincos_t<T>(theta, &st, &ct);
-    T sq = ORT_SQRT(rr);
+    T sq = sqrt_f<FILT, T>(rr, true, rare);
     T posx = sq * ct;
     T posy = sq * st;
     T Ra = S.ring_bottle_ra;
     T q = S.ring_ellipse ? posy * Ra / S.ring_bottle_rb : posy;            // :277 vs :279
-    T posz = S.ring_bottle_z + ORT_SQRT(Ra * Ra - q * q);
+    T posz = S.ring_bottle_z + sqrt_f<FILT, T>(Ra * Ra - q * q, true, rare);
     r.pos = {posx, posy, posz};
     rr = T(0.) + draws.template next_as<T>() * (S.ring_lens_r2 - T(0.));           // ranu(0., (radius+10e-3)**2)
     theta = draws.template next_as<T>() * S.twopi;
     sincos_t<T>(theta, &st, &ct);
-    sq = ORT_SQRT(rr);
+    sq = sqrt_f<FILT, T>(rr, true, rare);
     T ex = sq * ct - r.pos.x;
     T ey = sq * st - r.pos.y;
     T ez = S.ring_lens_z - r.pos.z;
-    T dist = ORT_SQRT(ex * ex + ey * ey + ez * ez);
-    r.dir = vnormalise(div3(VecT<T>{ex, ey, ez}, dist));
+    T dist = sqrt_f<FILT, T>(ex * ex + ey * ey + ez * ez, true, rare);
+    r.dir = vnormalise_f<FILT, T>(div3_f<FILT, T>(VecT<T>{ex, ey, ez}, dist, true, rare), true, rare);
 }
 
 // create_spot, src/sourceMod.f90:122-159: deterministic fan, no draws; n = 1-based loop index
@@ -873,21 +887,28 @@ __device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r
 // ANYSRC = false instantiates only the two default emitters (ring for phase 1, point for phase
 // 2): the bulk kernels are compiled once for that case so that the rarely used emitters do not
 // cost registers (143 vs 121 VGPRs, i.e. 3 vs 4 waves per SIMD) on the path that is benchmarked.
-template <class T, bool ANYSRC, class Sys, class D>
-__device__ inline bool emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf)
+template <class T, bool ANYSRC, bool FILT = false, class Sys, class D>
+__device__ inline bool emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf, bool &rare)
 {
     const int e = __builtin_amdgcn_readfirstlane(S.emitter[phase - 1]);
     if (!ANYSRC) {
-        if (phase == 1) emit_ring<T>(S, r, draws);
-        else emit_point<T>(S, r, draws);
+        if (phase == 1) emit_ring<T, FILT>(S, r, draws, rare);
+        else emit_point<T, FILT>(S, r, draws, rare);
         return true;
     }
-    if (e == ORT_EMIT_RING) emit_ring<T>(S, r, draws);
-    else if (e == ORT_EMIT_POINT) emit_point<T>(S, r, draws);
+    bool unused = false;                                  // the other emitters are literal throughout
+    if (e == ORT_EMIT_RING) emit_ring<T>(S, r, draws, unused);
+    else if (e == ORT_EMIT_POINT) emit_point<T>(S, r, draws, unused);
     else if (e == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray);
     else if (e == ORT_EMIT_CRS) emit_crs<T>(S, r, draws);
     else return emit_image<T>(S, cdf, r, draws, ray);
     return true;
+}
+template <class T, bool ANYSRC, class Sys, class D>
+__device__ inline bool emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf)
+{
+    bool unused = false;
+    return emit<T, ANYSRC, false>(S, phase, r, draws, ray, cdf, unused);
 }
 
 // ----------------------------------------------------------------------------

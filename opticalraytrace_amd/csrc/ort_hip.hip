@@ -573,15 +573,15 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             RayT<T> r;
             KeyedDraws d;
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
+            bool rare = false;
             if (MODE == MODE_RESIDENT) {
                 d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
                 r.pos = {T(a.pos_dir_in[0 * ns_in + ic]), T(a.pos_dir_in[1 * ns_in + ic]), T(a.pos_dir_in[2 * ns_in + ic])};
                 r.dir = {T(a.pos_dir_in[3 * ns_in + ic]), T(a.pos_dir_in[4 * ns_in + ic]), T(a.pos_dir_in[5 * ns_in + ic])};
             } else {
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                if (!emit<T, ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
+                if (!emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare)) st = ORT_ST_LOST_TELESCOPE;
             }
-            bool rare = false;
             if constexpr (fixed) walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
             else walk_pass<FILT, T, ANYSRC, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
             const bool deferred = FILT && rare && act;
