@@ -138,12 +138,16 @@ struct KeyedDraws {
 // Development-only ablation switches (tools/ablate.sh): they BREAK the numerics contract
 // and exist to price the IEEE divide / square-root expansions.  Never defined in the build.
 #ifdef ORT_ABL_FASTSQRT
-#define ORT_SQRT(x) __builtin_amdgcn_sqrt(x)
+__device__ inline double abl_sqrt(double x) { return __builtin_amdgcn_sqrt(x); }
+template <class T> __device__ inline T abl_sqrt(T x) { return sqrt(x); }
+#define ORT_SQRT(x) abl_sqrt(x)
 #else
 #define ORT_SQRT(x) sqrt(x)
 #endif
 #ifdef ORT_ABL_FASTDIV
-#define ORT_DIV(a, b) ((a) * __builtin_amdgcn_rcp(b))
+__device__ inline double abl_div(double a, double b) { return a * __builtin_amdgcn_rcp(b); }
+template <class T> __device__ inline T abl_div(T a, T b) { return a / b; }
+#define ORT_DIV(a, b) abl_div(a, b)
 #else
 #define ORT_DIV(a, b) ((a) / (b))
 #endif
