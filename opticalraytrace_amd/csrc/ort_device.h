@@ -288,14 +288,17 @@ template <> __device__ inline VecT<fastd> vnormalise<fastd>(VecT<fastd> a)
 // t, then per component  m = v r,  e = fma(-t, m, v),  q = fma(e, r, m)  — exactly what
 // v_div_scale / v_div_fmas / v_div_fixup reduce to when nothing is scaled and nothing is special.
 // That holds when t = |v| lies in (2^-350, 2^350) (sqrt_f's range test) and every component is
-// either exactly zero (the x of each cylinder normal; gives +0 like 0/t) or above 2^-300 in
-// magnitude; |v_i| <= t bounds the quotients by 1.  A lane outside that raises `rare`.
+// above 2^-300 in magnitude or exactly zero (gives +0 like 0/t); |v_i| <= t bounds the quotients
+// by 1.  A lane outside that raises `rare`.
 // tests/csrc/check_exact_ops.hip compares with the IEEE divisions over 2^28 operand sets.
 // the three quotients v_i / t of that scheme alone: requires t in (2^-350, 2^350) (the caller's
 // sqrt_f guarantees it for t = sqrt(s)) and |v_i| <= t up to rounding (components of the vector
 // whose length t is)
+// x_zero: the caller knows a.x is the literal zero (the x of a cylinder normal; wave-uniform).
+// Any other component that is not above 2^-300 — an exact zero included: a ray lying exactly in a
+// coordinate plane through the centre — raises `rare` (three compares instead of six).
 template <bool FILT, class T>
-__device__ inline VecT<T> div3_f(VecT<T> a, T t, bool need, bool &rare)
+__device__ inline VecT<T> div3_f(VecT<T> a, T t, bool need, bool &rare, bool x_zero = false)
 {
 #if !defined(ORT_ABL_FASTDIV)
     if constexpr (FILT && std::is_same<T, double>::value) {
@@ -309,8 +312,7 @@ __device__ inline VecT<T> div3_f(VecT<T> a, T t, bool need, bool &rare)
         q.x = __builtin_fma(__builtin_fma(-t, mx, a.x), r, mx);
         q.y = __builtin_fma(__builtin_fma(-t, my, a.y), r, my);
         q.z = __builtin_fma(__builtin_fma(-t, mz, a.z), r, mz);
-        const bool odd = (!(fabs(a.x) > 0x1p-300) && a.x != 0.0) || (!(fabs(a.y) > 0x1p-300) && a.y != 0.0) ||
-                         (!(fabs(a.z) > 0x1p-300) && a.z != 0.0);
+        const bool odd = (!x_zero && !(fabs(a.x) > 0x1p-300)) || !(fabs(a.y) > 0x1p-300) || !(fabs(a.z) > 0x1p-300);
         ORT_RARE(1, need && odd);
         return q;
     }
@@ -319,11 +321,11 @@ __device__ inline VecT<T> div3_f(VecT<T> a, T t, bool need, bool &rare)
 }
 
 template <bool FILT, class T>
-__device__ inline VecT<T> vnormalise_f(VecT<T> a, bool need, bool &rare)
+__device__ inline VecT<T> vnormalise_f(VecT<T> a, bool need, bool &rare, bool x_zero = false)
 {
     if constexpr (FILT && std::is_same<T, double>::value) {
         const double t = sqrt_f<true, double>(a.x * a.x + a.y * a.y + a.z * a.z, need, rare);
-        return div3_f<true, double>(a, t, need, rare);
+        return div3_f<true, double>(a, t, need, rare, x_zero);
     }
     return vnormalise(a);
 }
@@ -1002,7 +1004,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         bool out = false;
         if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, ax.ap2, ax.ap_tol, live && hit, rare);
         // normal = centre - pos, with orig%x = centre%x for the bottle (lens.f90:288-290)
-        N = vnormalise_f<FILT, T>(VecT<T>{cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z}, live && hit, rare);
+        N = vnormalise_f<FILT, T>(VecT<T>{cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z}, live && hit, rare, cyl);
         ended = !hit ? ((flags & ORT_F_MISS_IS_HELP3) ? ORT_ST_HELP3 : lost) : (out ? lost : -1);
         ended = walk_end >= 0 ? walk_end : ended;
         proceed = live && hit && !out;

@@ -19,7 +19,7 @@ __device__ inline uint64_t mix(uint64_t z)
 }
 
 // mode 0: any bit pattern (all exponents, NaN, inf, subnormal); mode 1: magnitudes the tracer
-// meets (1e-12 .. 1e3, both signs, and exact zeros); mode 2: exponents -340 .. 340
+// meets (1e-12 .. 1e3, both signs, exact zeros in x); mode 2: exponents -340 .. 340
 __device__ inline double operand(uint64_t key, int mode)
 {
     const uint64_t b = mix(key);
@@ -32,7 +32,7 @@ __device__ inline double operand(uint64_t key, int mode)
     const double m = 1.0 + (double)(b >> 12) * 0x1p-52;
     const int e = (int)((b >> 4) & 63) - 40;                 // 2^-40 .. 2^23
     double v = ldexp(m, e);
-    if ((b & 15) == 0) v = 0.0;
+    if ((b & 15) == 0 && (key & 3) == 0) v = 0.0;        // exact zeros: the x operand only
     return (b & 8) ? -v : v;
 }
 
@@ -55,9 +55,10 @@ __global__ void check(uint64_t n, int mode, unsigned long long *bad)
         const ort::Vec q = ort::div3_shared(ort::Vec{x, y, z}, t, shared);
         if (!shared) rd++;
         else if (!same(q.x, x / t) || !same(q.y, y / t) || !same(q.z, z / t)) bd++;
-        // a normalisation as the tracer does it: t = |v|
+        // a normalisation as the tracer does it: t = |v|; an exactly-zero x is announced by the
+        // caller (cylinder normals), any other exact zero must raise the flag
         rare = false;
-        const ort::Vec u = ort::vnormalise_f<true, double>(ort::Vec{x, y, z}, true, rare);
+        const ort::Vec u = ort::vnormalise_f<true, double>(ort::Vec{x, y, z}, true, rare, x == 0.0);
         const double len = sqrt(x * x + y * y + z * z);
         if (rare) rn++;
         else if (!same(u.x, x / len) || !same(u.y, y / len) || !same(u.z, z / len)) bn++;
