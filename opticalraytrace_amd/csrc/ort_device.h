@@ -439,7 +439,7 @@ template <> __device__ inline bool aperture_present<float>(float a)
 //   q > 0 : roots c/q <= q/a ; c/q < 0 <=> c < 0  -> t = c < 0 ? q/a : c/q   (always a hit)
 //   q < 0 : q/a < 0 ; hit <=> c/q >= 0 <=> c <= 0 -> t = c/q
 // Range guards: D in (1e-200, 1e200) (hence |hb| < 1e105, 1e-100 < |q| < 2e105: no quotient
-// leaves the normal range for a < 1e10 and c = 0 or |c| > 1e-200; a = 0 or NaN makes D fail).
+// leaves the normal range for a < 1e10 and |c| > 1e-200; a = 0 or NaN makes D fail).
 // ----------------------------------------------------------------------------
 template <bool FILT, class T>
 __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit, bool &rare)
@@ -451,14 +451,17 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
         const bool neg = D < T(0.0);                  // :243 — no real root
         bool unused = false;
         const T sq = sqrt_f<true, T>(D, false, unused);   // range: see `ok`; NaN when neg (misses)
-        const T q = -(hb + ((hb > T(0.0)) ? sq : -sq));   // :249-253
-        const bool ok = D > T(1e-10) * hh && D > T(1e-200) && D < T(1e200) && a < T(1e10) &&
-                        (c == T(0.0) || fabs(c) > T(1e-200));
-        const bool qpos = q > T(0.0);
-        const bool use_qa = qpos && (c < T(0.0));
+        const bool bpos = hb > T(0.0);
+        const T q = -(hb + (bpos ? sq : -sq));        // :249-253
+        // c = 0 (a ray that starts exactly on the surface) is left to the literal path as well,
+        // so that below c is either < 0 or > 0
+        const bool ok = D > T(1e-10) * hh && D > T(1e-200) && D < T(1e200) && a < T(1e10) && fabs(c) > T(1e-200);
+        const bool qpos = !bpos;                      // q = -(hb + s) < 0 for hb > 0, = s - hb > 0 otherwise (s > 0)
+        const bool cneg = c < T(0.0);
+        const bool use_qa = qpos && cneg;
         t = ORT_DIV(use_qa ? q : c, use_qa ? a : q);
-        hit = (qpos || !(c > T(0.0))) && !neg;
-        ORT_RARE(2, live && !neg && !ok);             // tangent, degenerate or NaN
+        hit = (qpos || cneg) && !neg;
+        ORT_RARE(2, live && !neg && !ok);             // tangent, degenerate, on the surface, or NaN
     } else {
         const T b = T(2.0) * hb;
         const T discrim = b * b - T(4.0) * a * c;
