@@ -324,7 +324,12 @@ template <bool FILT, class T>
 __device__ inline VecT<T> vnormalise_f(VecT<T> a, bool need, bool &rare, bool x_zero = false)
 {
     if constexpr (FILT && std::is_same<T, double>::value) {
-        const double t = sqrt_f<true, double>(a.x * a.x + a.y * a.y + a.z * a.z, need, rare);
+        // sqrt_f's range: div3_f's guard puts |a.y|, |a.z| above 2^-300, so s > 2^-600; the
+        // upper end is tested here
+        const double s = a.x * a.x + a.y * a.y + a.z * a.z;
+        bool unused = false;
+        const double t = sqrt_f<true, double>(s, false, unused);
+        ORT_RARE(0, need && !(s < 0x1p700));
         return div3_f<true, double>(a, t, need, rare, x_zero);
     }
     return vnormalise(a);
