@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <vector>
 #include "../../include/ort.h"
 #include "../../opticalraytrace_amd/csrc/ort_device.h"
 
@@ -70,6 +71,25 @@ __global__ void check(uint64_t n, int mode, unsigned long long *bad)
     atomicAdd(&bad[3], rs); atomicAdd(&bad[4], rd); atomicAdd(&bad[5], rn);
 }
 
+// Accuracy of the decision-only approximations (ort_device.h: rcp_approx, rsq_approx) and of the
+// hardware seeds under them: max relative error over 2^26 operands in [2^-20, 2^20].
+__global__ void approx_err(uint64_t n, double *out)
+{
+    double e_rcp = 0, e_rsq = 0, e_seed_rcp = 0, e_seed_rsq = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = mix(i + 12345);
+        const double x = ldexp(1.0 + (double)(b >> 12) * 0x1p-52, (int)((b >> 4) & 63) % 41 - 20);
+        const double r = 1.0 / x, q = 1.0 / sqrt(x);
+        e_rcp = fmax(e_rcp, fabs(ort::rcp_approx(x) - r) / r);
+        e_rsq = fmax(e_rsq, fabs(ort::rsq_approx(x) - q) / q);
+        e_seed_rcp = fmax(e_seed_rcp, fabs(__builtin_amdgcn_rcp(x) - r) / r);
+        e_seed_rsq = fmax(e_seed_rsq, fabs(__builtin_amdgcn_rsq(x) - q) / q);
+    }
+    // block-free reduction: one slot per thread, maxima taken on the host
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    out[4 * t + 0] = e_rcp; out[4 * t + 1] = e_rsq; out[4 * t + 2] = e_seed_rcp; out[4 * t + 3] = e_seed_rsq;
+}
+
 int main()
 {
     unsigned long long *d_bad, h[6];
@@ -88,5 +108,20 @@ int main()
         if (mode == 1 && (h[4] > n / 1000 || h[5] > n / 1000)) rc = 1;
     }
     (void)hipFree(d_bad);
+    {
+        const int blocks = 1024, threads = 256;
+        double *d_e;
+        std::vector<double> h_e((size_t)4 * blocks * threads);
+        if (hipMalloc(&d_e, h_e.size() * sizeof(double)) != hipSuccess) return 2;
+        approx_err<<<blocks, threads>>>(1ull << 26, d_e);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
+        (void)hipMemcpy(h_e.data(), d_e, h_e.size() * sizeof(double), hipMemcpyDeviceToHost);
+        double m[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < h_e.size(); ++i) m[i & 3] = m[i & 3] > h_e[i] ? m[i & 3] : h_e[i];
+        printf("max relative error: rcp_approx %.3g rsq_approx %.3g (bound 2^-40 = 9.09e-13); seeds v_rcp_f64 %.3g v_rsq_f64 %.3g\n",
+               m[0], m[1], m[2], m[3]);
+        if (!(m[0] < 0x1p-40) || !(m[1] < 0x1p-40)) rc = 1;
+        (void)hipFree(d_e);
+    }
     return rc;
 }
