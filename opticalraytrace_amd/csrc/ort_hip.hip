@@ -14,8 +14,9 @@
 //         FILT           filtered predicates (decisions from bounded approximations); a ray that
 //                        lands inside a margin is not decided here: its index goes to the
 //                        re-run list and it leaves the kernel without side effect
-//         EXT            also compiles the rarely used emitters (spot, crs, image) and the
-//                        in-bottle scattering walk; the default instantiation leaves them out
+//         EXT (ANYSRC)   also compiles the rarely used emitters (spot, crs, image); SCAT the
+//                        in-bottle scattering walk (213+ VGPRs); the default instantiation
+//                        leaves both out, and a phase is given only what its own list needs
 //         PROG           the surface list as template constants (Prog<P>: the default point /
 //                        ring systems and their iris variants), steps unrolled, surface records
 //                        through scalar loads; PROG_GENERIC walks any staged list
@@ -472,15 +473,15 @@ __device__ inline int lane_prefix(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-template <int MODE, bool FILT, bool ANYSRC, class T, int PROG = PROG_GENERIC>
+template <int MODE, bool FILT, bool ANYSRC, class T, int PROG = PROG_GENERIC, bool SCAT = ANYSRC>
 __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) void trace_queue_kernel(TraceArgs a)
 {
-    static_assert(PROG == PROG_GENERIC || (FILT && !ANYSRC), "programs exist for the lean filtered kernel only");
+    static_assert(PROG == PROG_GENERIC || (FILT && !ANYSRC && !SCAT), "programs exist for the lean filtered kernel only");
     __shared__ ort_system S;
     __shared__ double Q[kWavesPerBlock][kQueueFields][kQueueCap];
     // intersections evaluated before the queue point: `split` for every survivor unless a surface
     // scatters (extended instantiation), so only that one carries the count through the queue
-    __shared__ int QN[kWavesPerBlock][ANYSRC ? kQueueCap : 1];
+    __shared__ int QN[kWavesPerBlock][SCAT ? kQueueCap : 1];
     __shared__ unsigned int blk[4];
     __shared__ SurfAuxT<T> AUX[PROG == PROG_GENERIC ? ORT_MAX_SURFACES : 1];
     stage_system(S, a.sys);
@@ -554,11 +555,11 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
                 r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
                 d.z = (uint64_t)__double_as_longlong(q[6][slot]);
-                nis = ANYSRC ? qn[slot] : split;
+                nis = SCAT ? qn[slot] : split;
             }
             bool rare = false;
             if constexpr (fixed) walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
-            else walk_pass<FILT, T, ANYSRC, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
+            else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
                 if (FILT && rare) defer(ray_of_counter(d.z, a.rng_base) - a.first_ray);
                 else finish(st, nis, xp, yp);
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 if (!emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare)) st = ORT_ST_LOST_TELESCOPE;
             }
             if constexpr (fixed) walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
-            else walk_pass<FILT, T, ANYSRC, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
+            else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
             const bool deferred = FILT && rare && act;
             const bool survive = act && st < 0 && !deferred;
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(survive);
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 q[0][slot] = (double)r.pos.x; q[1][slot] = (double)r.pos.y; q[2][slot] = (double)r.pos.z;
                 q[3][slot] = (double)r.dir.x; q[4][slot] = (double)r.dir.y; q[5][slot] = (double)r.dir.z;
                 q[6][slot] = __longlong_as_double((long long)d.z);
-                if (ANYSRC) qn[slot] = nis;
+                if (SCAT) qn[slot] = nis;
             } else if (deferred) {
                 defer(i);
             } else if (act) {
@@ -693,7 +694,7 @@ struct ort_ctx {
     int variant;                 // bit mask, see ort_set_kernel_variant
     int precision;               // 0 fp64 (reference arithmetic), 1 fp32 (study path)
     int emitter[2];              // host copy of ort_system.emitter
-    bool scatter;                // some surface carries ORT_F_SCATTER
+    bool scatter[2];             // per phase: some surface of its list carries ORT_F_SCATTER
     int prog[2];                 // per phase: PROG_* the staged system matches (match_program)
     hipEvent_t ev[3][2];
     hipEvent_t ring[kTimingRing][2];   // fused-trace launches, most recent kTimingRing
@@ -721,10 +722,11 @@ static bool matches(const ort_system *sys)
 static void note_system(ort_ctx *c, const ort_system *sys)
 {
     c->emitter[0] = sys->emitter[0]; c->emitter[1] = sys->emitter[1];
-    c->scatter = false;
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < 2; ++p) {
+        c->scatter[p] = false;
         for (int k = 0; k < sys->n_surfaces[p]; ++k)
-            if (sys->surfaces[p][k].flags & ORT_F_SCATTER) c->scatter = true;
+            if (sys->surfaces[p][k].flags & ORT_F_SCATTER) c->scatter[p] = true;
+    }
     c->prog[0] = c->prog[1] = PROG_GENERIC;
 #define ORT_MATCH(P) if (matches<P>(sys)) c->prog[Prog<P>::phase - 1] = P;
     ORT_PROGRAMS(ORT_MATCH)
@@ -879,6 +881,7 @@ int ort_reset(ort_ctx *c)
 // One kernel of the trace family on `grid` workgroups.
 static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool queued, bool filt, bool anysrc)
 {
+    const bool scat = c->scatter[a.phase - 1];
 #define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
     if (c->precision == 2) {
         // fast fp64 (ort_fastd.h): FMA contraction, Newton divide / Goldschmidt sqrt; ~1e-13 from exact
@@ -903,10 +906,18 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
     } else if (anysrc || !filt || !queued) {
         // alternate emitters and the A/B variants share the generic instantiations
         if (mode == MODE_FUSED) {
-            if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true, double>)); else ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, false, true, double>)); }
+            if (queued) {
+                if (filt && !scat) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true, double, PROG_GENERIC, false>));   // other emitters, clear media
+                else if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true, double>));
+                else ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, false, true, double>));
+            }
             else { if (filt) ORT_LAUNCH((trace_kernel<MODE_FUSED, true, double, true>)); else ORT_LAUNCH((trace_kernel<MODE_FUSED, false, double, true>)); }
         } else {
-            if (queued) { if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true, double>)); else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, false, true, double>)); }
+            if (queued) {
+                if (filt && !scat) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true, double, PROG_GENERIC, false>));
+                else if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true, double>));
+                else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, false, true, double>));
+            }
             else { if (filt) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true, double, true>)); else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, double, true>)); }
         }
     } else {
@@ -927,7 +938,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     if (a0.n_rays == 0) return ORT_OK;
     const bool queued = (c->variant & 1) && mode != MODE_DEBUG && c->precision != 1;
     const bool filt = (c->variant & 2) == 0;
-    const bool anysrc = c->emitter[a0.phase - 1] != (a0.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT) || c->scatter;
+    const bool anysrc = c->emitter[a0.phase - 1] != (a0.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT) || c->scatter[a0.phase - 1];
     // The queued filtered kernel defers the rays that sit on a decision boundary to a list, which
     // the literal lockstep kernel traces right after it.  Every ray of a launch could be on it
     // (an axial beam meets every flat face at costt == 1), so a launch covers at most kChunkRays.
