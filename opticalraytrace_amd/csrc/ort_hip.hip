@@ -221,9 +221,11 @@ __device__ inline SurfAuxT<T> load_aux(const_aux_t p)
 // branches + the blocks they cut the schedule into) disappears and the steps are laid out
 // back to back: -8 % kernel time.  The host selects a program only when the staged system
 // matches it field for field (match_program); everything else runs the generic walk.
-enum { PROG_GENERIC = 0, PROG_POINT, PROG_RING, PROG_POINT_IRIS_B, PROG_POINT_IRIS_A, PROG_RING_IRIS_B, PROG_RING_IRIS_A };
+enum { PROG_GENERIC = 0, PROG_POINT, PROG_RING, PROG_POINT_IRIS_B, PROG_POINT_IRIS_A, PROG_RING_IRIS_B, PROG_RING_IRIS_A,
+       PROG_POINT_BARE };
 // every program but the generic one: X(name)
-#define ORT_PROGRAMS(X) X(PROG_POINT) X(PROG_RING) X(PROG_POINT_IRIS_B) X(PROG_POINT_IRIS_A) X(PROG_RING_IRIS_B) X(PROG_RING_IRIS_A)
+#define ORT_PROGRAMS(X) X(PROG_POINT) X(PROG_RING) X(PROG_POINT_IRIS_B) X(PROG_POINT_IRIS_A) X(PROG_RING_IRIS_B) X(PROG_RING_IRIS_A) \
+    X(PROG_POINT_BARE)
 
 namespace prog {
 constexpr int CYL = ORT_SURF_CYLINDER, PLN = ORT_SURF_PLANE, SPH = ORT_SURF_SPHERE, IRS = ORT_SURF_IRIS, IMG = ORT_SURF_IMAGE;
@@ -269,6 +271,14 @@ template <> struct Prog<PROG_RING_IRIS_A> {
     static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IRS, prog::IMG};
     static constexpr int flags[n] = {0, prog::SK, prog::SK, prog::SK, prog::H3, 0, 0};
     static constexpr int ap[n] = {1, 0, 1, 0, 0, 1, 0};
+};
+
+// the point loop without the bottle (use_bottle = false, src/main.f90:147)
+template <> struct Prog<PROG_POINT_BARE> {
+    static constexpr int phase = 2, n = 6, split = 3;
+    static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
+    static constexpr int flags[n] = {0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
+    static constexpr int ap[n] = {1, 0, 1, 0, 0, 0};
 };
 
 // steps [K, K1) of program P, each entered only while some lane of the wave is alive

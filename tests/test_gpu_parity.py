@@ -450,7 +450,7 @@ def test_launches_are_cut_at_the_rerun_list_capacity(ctxs):
     assert np.array_equal(img_a, img_c) and np.array_equal(cnt_a, cnt_c)
 
 
-@pytest.mark.parametrize("name", ["large", "small", "large_iris_before", "small_iris_after", "ellipse"])
+@pytest.mark.parametrize("name", ["large", "small", "large_iris_before", "small_iris_after", "small_f60_nobottle", "ellipse"])
 def test_program_kernels_equal_the_generic_walk(name, hip_library):
     """The queued kernel is specialised for the default surface programs and their iris variants
     (kinds, flags and aperture presence as template constants) when the staged system matches
