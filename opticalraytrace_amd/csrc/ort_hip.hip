@@ -222,13 +222,13 @@ __device__ inline SurfAuxT<T> load_aux(const_aux_t p)
 // back to back: -8 % kernel time.  The host selects a program only when the staged system
 // matches it field for field (match_program); everything else runs the generic walk.
 enum { PROG_GENERIC = 0, PROG_POINT, PROG_RING, PROG_POINT_IRIS_B, PROG_POINT_IRIS_A, PROG_RING_IRIS_B, PROG_RING_IRIS_A,
-       PROG_POINT_BARE };
+       PROG_POINT_BARE, PROG_POINT_ELLIPSE };
 // every program but the generic one: X(name)
 #define ORT_PROGRAMS(X) X(PROG_POINT) X(PROG_RING) X(PROG_POINT_IRIS_B) X(PROG_POINT_IRIS_A) X(PROG_RING_IRIS_B) X(PROG_RING_IRIS_A) \
-    X(PROG_POINT_BARE)
+    X(PROG_POINT_BARE) X(PROG_POINT_ELLIPSE)
 
 namespace prog {
-constexpr int CYL = ORT_SURF_CYLINDER, PLN = ORT_SURF_PLANE, SPH = ORT_SURF_SPHERE, IRS = ORT_SURF_IRIS, IMG = ORT_SURF_IMAGE;
+constexpr int CYL = ORT_SURF_CYLINDER, ELL = ORT_SURF_ELLIPSE, PLN = ORT_SURF_PLANE, SPH = ORT_SURF_SPHERE, IRS = ORT_SURF_IRIS, IMG = ORT_SURF_IMAGE;
 constexpr int SK = ORT_F_SKIP_ON_REFLECT, BT = ORT_F_BOTTLE | ORT_F_SKIP_ON_REFLECT, H3 = ORT_F_SKIP_ON_REFLECT | ORT_F_MISS_IS_HELP3;
 }
 template <int P> struct Prog;
@@ -279,6 +279,14 @@ template <> struct Prog<PROG_POINT_BARE> {
     static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
     static constexpr int flags[n] = {0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
     static constexpr int ap[n] = {1, 0, 1, 0, 0, 0};
+};
+
+// the point loop through an elliptical bottle (src/lens.f90:221-225)
+template <> struct Prog<PROG_POINT_ELLIPSE> {
+    static constexpr int phase = 2, n = 8, split = 5;
+    static constexpr int kind[n] = {prog::ELL, prog::ELL, prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
+    static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
+    static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 0};
 };
 
 // steps [K, K1) of program P, each entered only while some lane of the wave is alive
