@@ -99,6 +99,10 @@ def main():
     system = OpticalSystem.from_settings(settings)
     tracer = RayTracer(system, device=local_rank, rank=rank, world=world)
     tracer.ctx.set_timing(True)
+    # set-up, not a step: scratch for launches of this size, and the kernels' code objects loaded
+    # by a 64-ray launch (the first launch of a kernel otherwise pays ~2 ms once)
+    tracer.ctx.reserve(args.rays)
+    tracer.ctx.trace(args.phase, 0, 64, DEFAULT_SEED)
     phase, total_rays = args.phase, args.rays * world
     ci, cb = (C_ISECT_POINT, C_BINNED_POINT) if phase == 2 else (C_ISECT_RING, C_BINNED_RING)
 

@@ -213,6 +213,10 @@ int ort_attach_buffers(ort_ctx *ctx, void *d_image, void *d_counters);
 int ort_device_image(ort_ctx *ctx, void **d_image);
 int ort_device_counters(ort_ctx *ctx, void **d_counters);
 int ort_synchronize(ort_ctx *ctx);
+/* Optional: allocate now the per-launch scratch a trace of up to n_rays rays needs (otherwise the
+ * first such ort_trace allocates it, synchronising the stream once).  The reference allocates its
+ * image up front as well (src/main.f90:35). */
+int ort_reserve(ort_ctx *ctx, uint64_t n_rays);
 
 /* Timing of the last launch of each kernel kind on the context's own stream
  * (HIP events recorded around the launch): ms, or <0 if none.  kind: 0 fused

@@ -156,6 +156,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ort_device_image": (C.c_int, [vp, C.POINTER(vp)]),
         "ort_device_counters": (C.c_int, [vp, C.POINTER(vp)]),
         "ort_synchronize": (C.c_int, [vp]),
+        "ort_reserve": (C.c_int, [vp, u64]),
         "ort_last_kernel_ms": (C.c_int, [vp, i32, C.POINTER(C.c_float)]),
         "ort_set_timing": (C.c_int, [vp, i32]),
         "ort_kernel_times": (C.c_int, [vp, C.POINTER(C.c_float), i32, C.POINTER(C.c_int)]),
@@ -176,7 +177,7 @@ EXPORTED_SYMBOLS = ["ort_abi_version", "ort_last_error", "ort_device_count", "or
                     "ort_destroy", "ort_set_system", "ort_set_image_source", "ort_reset", "ort_trace", "ort_emit",
                     "ort_trace_resident", "ort_trace_rays", "ort_trace_paths", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
-                    "ort_device_counters", "ort_synchronize", "ort_last_kernel_ms",
+                    "ort_device_counters", "ort_synchronize", "ort_reserve", "ort_last_kernel_ms",
                     "ort_set_timing", "ort_kernel_times", "ort_set_kernel_variant", "ort_set_precision"]
 
 
@@ -260,6 +261,10 @@ class Context:
 
     def synchronize(self) -> None:
         _check(self.lib, self.lib.ort_synchronize(self._h), "ort_synchronize")
+
+    def reserve(self, n_rays: int) -> None:
+        """Allocate the per-launch scratch of traces of up to n_rays rays now (optional)."""
+        _check(self.lib, self.lib.ort_reserve(self._h, n_rays), "ort_reserve")
 
     def read(self):
         image = np.zeros((2, IMAGE_N, IMAGE_N), dtype=np.int32)

@@ -945,6 +945,20 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
 #undef ORT_LAUNCH
 }
 
+// the re-run list holds one entry per ray of a launch (launches cover at most kChunkRays)
+static int reserve_list(ort_ctx *c, uint64_t n_rays)
+{
+    const size_t need = (size_t)(n_rays < kChunkRays ? n_rays : kChunkRays);
+    if (need > c->redo_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_redo_list);
+        c->d_redo_list = nullptr; c->redo_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_redo_list, need * sizeof(uint32_t)));
+        c->redo_cap = need;
+    }
+    return ORT_OK;
+}
+
 static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
 {
     a0.sys = &c->d_sys->sys; a0.aux = c->d_sys->aux[a0.phase - 1];
@@ -964,14 +978,8 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     const uint64_t total = a0.n_rays;
     const uint64_t step = deferring ? kChunkRays : total;
     if (deferring) {
-        const size_t need = (size_t)(total < step ? total : step);
-        if (need > c->redo_cap) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            (void)hipFree(c->d_redo_list);
-            c->d_redo_list = nullptr; c->redo_cap = 0;
-            HIP_TRY(hipMalloc(&c->d_redo_list, need * sizeof(uint32_t)));
-            c->redo_cap = need;
-        }
+        const int rc = reserve_list(c, total);
+        if (rc) return rc;
         a0.redo_list = c->d_redo_list;
         a0.redo_ctl = c->d_redo_ctl;
     }
@@ -1003,6 +1011,13 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     if (c->timing && evk > 0) { HIP_TRY(hipEventRecord(c->ev[evk][1], c->stream)); c->ev_valid[evk] = true; }
     if (c->timing && evk == 0) { HIP_TRY(hipEventRecord(c->ring[slot][1], c->stream)); c->ring_count++; c->ev_valid[0] = true; }
     return ORT_OK;
+}
+
+int ort_reserve(ort_ctx *c, uint64_t n_rays)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    return reserve_list(c, n_rays);
 }
 
 int ort_trace(ort_ctx *c, int phase, uint64_t first_ray, uint64_t n_rays, uint64_t seed)
