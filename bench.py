@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — ray-surface intersections / second of the MI355X trace path.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is
-launched under torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE
-JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the ranks are
+one process per GPU over RCCL: either the driver starts them (torch.distributed.run sets
+WORLD_SIZE / RANK / LOCAL_RANK) or, when it runs the plain command, this script starts them
+itself as CHILD processes — before it has made any GPU call — and relays rank 0's line and
+their exit code.  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1], the configuration `metric` is quoted on):
+Workload (default = BASELINE.json configs[1], the configuration `metric` is quoted on):
 point source (phase 2 loop, src/main.f90:127-162), clearBottle-large +
 planoConvex-f39.9mm + achromaticDoublet-f50.0mm, 1e7 rays per GPU, fp64.
-A step = one pass of the hot path over one batch: every rank emits, traces and
-bins its own 1e7-ray shard of the global index range (weak scaling), then the
-image + counters are sum-all-reduced over ranks (RCCL; skipped for N = 1).
-Synthetic input = (config, seed 123456789, global ray index): rays are generated
-in-kernel from the key, nothing is read from the host inside the timed region.
+`--workload ring1e8` = configs[2] (ring loop, src/main.f90:90-109, 1e8 rays per GPU per step),
+`--workload full1e9` = configs[3]'s shape (both loops, 1e9 rays per layer per step, the rays of a
+step sharded over the ranks: strong in N, which is what configs[3] asks for).
+A step = one pass of the hot path over one batch: every rank emits, traces and bins its own
+shard of the global index range, then image + counters are sum-all-reduced over ranks ONCE per
+run of K steps, inside the timed region (RCCL; skipped for N = 1) — as the reference keeps one
+shared image for the whole loop (src/main.f90:88-109).
+Synthetic input = (config, seed 123456789, global ray index): rays are generated in-kernel
+from the key, nothing is read from the host inside the timed region.
 value = intersections all ranks evaluated (exact int64 device counter) / wall time.
+
+Order of the legs in one process: CPU baseline (child process, before this process touches
+the GPU), then the informational fp32 and fast-fp64 legs, then the exact fp64 leg that
+`value` reports — last, so that its accumulators are the ones read back and checked.
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -26,10 +37,50 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_VEC_PEAK_TFLOPS = 78.65   # half of the 157.3 TF fp32 vector peak (MI355X_MICROARCH.md)
-FLOP_PER_INTERSECTION = 100.0
-BYTES_PER_RAY = 48.0           # 6 x fp64 ray state
+FP32_VEC_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector (non-MFMA) peak
+FP64_VEC_PEAK_TFLOPS = 78.65   # fp64 vector = half of it
+FLOP_PER_INTERSECTION = 100.0  # + - x / sqrt = 1 each, ~100 per surface solve (an ASSUMED
+                               # algorithmic figure; the executed instruction count is in `roofline`)
+FLOP_PER_RING_EMISSION = 61.0  # ~50 flop + 5 sqrt + 6 divisions (2 sincos not counted)
+BYTES_PER_RAY = 48.0           # SURVEY §8(d) contract layout: 6 x fp64 ray state resident in HBM
 BYTES_PER_BINNED = 8.0         # int32 atomic read-modify-write
+
+WORKLOADS = {
+    # name: (phases per step, rays per GPU per step or None = rays per layer sharded over ranks, text)
+    "point1e7": ((2,), 10_000_000, "point source (phase 2), clearBottle-large + planoConvex-f39.9mm + "
+                                   "achromaticDoublet-f50.0mm, 1e7 rays per GPU (BASELINE configs[1])"),
+    "ring1e8": ((1,), 100_000_000, "ring source (phase 1), clearBottle-large + planoConvex-f39.9mm + "
+                                   "achromaticDoublet-f50.0mm, 1e8 rays per GPU (BASELINE configs[2])"),
+    "full1e9": ((1, 2), None, "ring + point layers, full stack (bottle + plano-convex + doublet), 1e9 rays "
+                              "per layer per step sharded over the ranks (BASELINE configs[3] shape)"),
+}
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (never exec:
+    this process may not be replaced once a GPU runtime is loaded, and it has loaded none yet)."""
+    import torch                                    # device_count() does not initialise the GPU
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); "
+                         "one rank per GPU is the only supported layout\n")
+        return 2
+    with socket.socket() as s:                      # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stdout.write(p.stdout)
+    if p.returncode != 0:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run exited with {p.returncode}\n")
+    return p.returncode
 
 
 def cpu_baseline(rays: int):
@@ -40,7 +91,7 @@ def cpu_baseline(rays: int):
     "reference"), else the C restatement (kind "port")."""
     try:
         out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"),
-                              "--rays", str(rays)], capture_output=True, text=True, timeout=600)
+                              "--rays", str(rays)], capture_output=True, text=True, timeout=900)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:                                  # the baseline is reported, never required
@@ -48,42 +99,74 @@ def cpu_baseline(rays: int):
                 "sample": f"failed: {e!r}"}
 
 
-def main():
+def profiled_counters(workload: str, build_id: str):
+    """Counters of the committed rocprofv3 --pmc passes (profiles/pmc_per_launch.json, written by
+    tools/stamp_profiles.py) — only when they were taken on THIS build of the kernels."""
+    path = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
+    try:
+        prof = json.load(open(path))
+    except Exception:
+        return None, "profiles/pmc_per_launch.json missing"
+    if prof.get("build_id") != build_id:
+        return None, (f"profiles/pmc_per_launch.json was taken on build {prof.get('build_id')}, this "
+                      f"library is {build_id}: counters not quoted")
+    return prof.get("workloads", {}).get(workload), None
+
+
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rays", type=int, default=10_000_000, help="rays per GPU per step")
-    ap.add_argument("--phase", type=int, default=2, help="2 = point loop (configs[1]); 1 = ring loop")
-    ap.add_argument("--cpu-rays", type=int, default=20_000_000)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="point1e7")
+    ap.add_argument("--rays", type=int, default=0, help="override: rays per GPU per step")
+    ap.add_argument("--phase", type=int, default=0, help="override: 1 = ring loop, 2 = point loop")
+    ap.add_argument("--cpu-rays", type=int, default=50_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast", action="store_true", help="skip the informational fast-fp64 leg")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the informational fp32 leg (configs[4])")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and all-reduce even with one rank (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        ap.error("--gpus >= 1, --steps >= 1, --warmup >= 0")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
-                     "(one rank per GPU); see the module docstring")
-        args.gpus = world
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}\n")
+        return 2
+
+    phases, rays_gpu, text = WORKLOADS[args.workload]
+    if args.phase:
+        phases = (args.phase,)
+    if args.rays:
+        rays_gpu = args.rays
+    strong = rays_gpu is None
+    total_rays = 1_000_000_000 if strong else rays_gpu * world        # per layer per step, all ranks
+    custom = bool(args.phase or args.rays)
+    if custom:
+        text = (f"phase(s) {phases}, clearBottle-large + planoConvex-f39.9mm + achromaticDoublet-f50.0mm, "
+                f"{total_rays} rays per layer per step over {world} rank(s)")
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_dist:
         cpu = cpu_baseline(args.cpu_rays)          # before the GPU is touched by this process
 
     import torch
     import torch.distributed as dist
+    from opticalraytrace_amd import capi
     from opticalraytrace_amd.capi import C_BINNED_POINT, C_BINNED_RING, C_ISECT_POINT, C_ISECT_RING
     from opticalraytrace_amd.params import Settings
     from opticalraytrace_amd.system import OpticalSystem
-    from opticalraytrace_amd.tracer import DEFAULT_SEED, RayTracer
+    from opticalraytrace_amd.tracer import DEFAULT_SEED, RayTracer, shard_range
 
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X: the trace path has no CPU fallback")
+        sys.stderr.write("bench.py needs an MI355X: the trace path has no CPU fallback\n")
+        return 2
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -92,27 +175,29 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    settings = Settings(nphotons=args.rays * world, make_images=True,
+    settings = Settings(nphotons=min(total_rays, 2**31 - 1), make_images=True,
                         bottle_file="clearBottle-large.params",
                         L2_file="planoConvex-f39.9mm.params",
                         L3_file="achromaticDoublet-f50.0mm.params")
     system = OpticalSystem.from_settings(settings)
     tracer = RayTracer(system, device=local_rank, rank=rank, world=world)
-    tracer.ctx.set_timing(True)
+    ctx = tracer.ctx
+    ctx.set_timing(True)
+    lo, cnt = shard_range(total_rays, rank, world)
     # set-up, not a step: scratch for launches of this size, and the kernels' code objects loaded
-    # by a 64-ray launch (the first launch of a kernel otherwise pays ~2 ms once)
-    tracer.ctx.reserve(args.rays)
-    tracer.ctx.trace(args.phase, 0, 64, DEFAULT_SEED)
-    phase, total_rays = args.phase, args.rays * world
-    ci, cb = (C_ISECT_POINT, C_BINNED_POINT) if phase == 2 else (C_ISECT_RING, C_BINNED_RING)
+    # by a 64-ray launch in every arithmetic the legs use (a kernel's first launch otherwise pays ~2 ms)
+    ctx.reserve(cnt)
+    for prec in (0, 1, 2):
+        ctx.set_precision(prec)
+        for ph in phases:
+            ctx.trace(ph, 0, 64, DEFAULT_SEED)
+    ctx.set_precision(0)
 
-    # One RUN = warmup + K steps; step k traces the global ray indices [k*T, (k+1)*T) (T = rays
-    # per GPU x ranks), sharded over the ranks, accumulating into the per-GPU image.  As in the
-    # reference (one shared image for the whole loop, src/main.f90:88-109) the image is reduced
-    # ONCE per run — inside the timed region — not once per batch.
+    # step k traces the global ray indices [k*T, (k+1)*T) of each of its phases (T = rays per layer
+    # per step over all ranks), this rank its contiguous shard of them
     def step(k):
-        lo, cnt = (total_rays * rank) // world, (total_rays * (rank + 1)) // world - (total_rays * rank) // world
-        tracer.ctx.trace(phase, k * total_rays + lo, cnt, DEFAULT_SEED)
+        for ph in phases:
+            ctx.trace(ph, k * total_rays + lo, cnt, DEFAULT_SEED)
 
     def fence():
         torch.cuda.synchronize()
@@ -120,81 +205,82 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    tracer.reset()
-    for k in range(args.warmup):
-        step(k)
-    tracer.reduce(force=use_dist)
-    fence()
-    tracer.reset()
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    tracer.reduce(force=use_dist)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    # per-launch kernel durations from the HIP events each launch recorded on the tracer's stream
-    kernel_ms = tracer.ctx.kernel_times(min(args.steps, 64))
-
-    # informational, outside `value`: the same run in the opt-in fast fp64 mode (csrc/ort_fastd.h)
-    fast = None
-    if not args.no_fast:
-        saved_img, saved_cnt = tracer.image.clone(), tracer.counters.clone()
-        tracer.ctx.set_precision(2)
-        for k in range(2):
+    def timed_run(steps, warmup):
+        """W untimed steps, then exactly K steps + the reduce between two fences; max over ranks.
+        The timed steps are steps [W_main, W_main + K) of the global index range in every leg, so the
+        legs trace the same rays and their images can be compared."""
+        tracer.reset()
+        for k in range(warmup):
             step(k)
+        tracer.reduce(force=use_dist)
         fence()
         tracer.reset()
-        t1 = time.perf_counter()
-        for k in range(args.steps):
+        fence()
+        t0 = time.perf_counter()
+        for k in range(steps):
             step(args.warmup + k)
         tracer.reduce(force=use_dist)
         fence()
-        el_fast = time.perf_counter() - t1
+        el = time.perf_counter() - t0
         if use_dist:
-            tm = torch.tensor([el_fast], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            el_fast = float(tm.item())
-        fr = tracer.result(total_rays * args.steps)
-        fast = {"value": int(fr.counters[ci]) / el_fast, "unit": "intersections/s",
-                "ms_per_step": el_fast / args.steps * 1e3,
-                "image_l1_vs_exact": int((fr.image.astype("int64") - saved_img.cpu().numpy()).__abs__().sum()),
-                "note": "ort_set_precision(2): FMA contraction + Newton reciprocal/rsqrt; ~1e-15 relative "
-                        "from the exact path, not bit-identical (profiles/r01/fastd_study.json)"}
-        tracer.ctx.set_precision(0)
-        tracer.image.copy_(saved_img)
-        tracer.counters.copy_(saved_cnt)
+            tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        # per-launch durations from the HIP events each ort_trace recorded on the tracer's stream
+        kms = ctx.kernel_times(min(steps * len(phases), 64))
+        return el, kms
 
+    def isect_binned(res):
+        i = sum(int(res.counters[C_ISECT_RING if ph == 1 else C_ISECT_POINT]) for ph in phases)
+        b = sum(int(res.counters[C_BINNED_RING if ph == 1 else C_BINNED_POINT]) for ph in phases)
+        return i, b
+
+    # ---- informational legs (outside `value`) ---------------------------------------------------
+    legs = {}
+    for name, prec, skip in (("fp32", 1, args.no_fp32), ("fast_fp64", 2, args.no_fast)):
+        if skip:
+            continue
+        ctx.set_precision(prec)
+        el, kms = timed_run(args.steps, min(args.warmup, 2))
+        r = tracer.result(total_rays * args.steps)
+        legs[name] = (el, kms, r)
+    ctx.set_precision(0)
+
+    # ---- the leg `value` reports: exact fp64 -----------------------------------------------------
+    elapsed, kernel_ms = timed_run(args.steps, args.warmup)
     res = tracer.result(total_rays * args.steps)   # counters of the whole timed run, summed over ranks
-    isect_total = int(res.counters[ci])
-    binned_total = int(res.counters[cb])
-    assert int(res.image[phase - 1].sum()) == binned_total, "image and counter disagree"
+    isect_total, binned_total = isect_binned(res)
+    for ph in phases:
+        want = int(res.counters[C_BINNED_RING if ph == 1 else C_BINNED_POINT])
+        assert int(res.image[ph - 1].sum()) == want, "image and counter disagree"
     isect_per_step = isect_total / args.steps
     binned_per_step = binned_total / args.steps
     value = isect_total / elapsed
 
-    # roofline of the dominant kernel (the fused trace kernel), per launch = per rank per step
-    k_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3
-    rays_launch = args.rays
-    isect_launch = isect_per_step / world
-    binned_launch = binned_per_step / world
-    alg_bytes = BYTES_PER_RAY * rays_launch + BYTES_PER_BINNED * binned_launch
-    alg_flop = FLOP_PER_INTERSECTION * isect_launch
-    ach_gbs = alg_bytes / k_s / 1e9
+    # ---- roofline of the dominant kernel (the fused trace kernel), per launch = per rank per phase
+    # of a step.  kernel_ms holds one entry per ort_trace call (queued kernel + its literal re-run
+    # launch + fold_kernel, one event bracket); a step of a two-phase workload is two launches.
+    launches_per_step = len(phases)
+    k_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3                  # mean launch, s
+    rays_launch = cnt
+    isect_launch = isect_per_step / world / launches_per_step
+    binned_launch = binned_per_step / world / launches_per_step
+    ring_share = sum(1 for ph in phases if ph == 1) / launches_per_step
+    alg_flop = FLOP_PER_INTERSECTION * isect_launch + FLOP_PER_RING_EMISSION * rays_launch * ring_share
+    contract_bytes = BYTES_PER_RAY * rays_launch + BYTES_PER_BINNED * binned_launch
     ach_tf = alg_flop / k_s / 1e12
-    traffic = valu_busy = None
-    tf = os.path.join(ROOT, "profiles", "traffic_bytes_per_launch.json")
-    if os.path.exists(tf):                         # written from the rocprofv3 --pmc passes
-        try:
-            prof = json.load(open(tf))
-            traffic = prof.get("hbm_bytes_per_launch")
-            valu_busy = prof.get("valu_busy_frac")
-        except Exception:
-            traffic = valu_busy = None
+    build = capi.build_id()
+    prof, prof_note = profiled_counters(args.workload if not custom else "custom", build)
+    prof = prof or {}
+    traffic = prof.get("hbm_bytes_per_launch")
+
+    def fp_roofline(kms, r, peak, bound):
+        ks = (sum(kms) / len(kms)) * 1e-3
+        i, _ = isect_binned(r)
+        fl = FLOP_PER_INTERSECTION * i / args.steps / world / launches_per_step \
+            + FLOP_PER_RING_EMISSION * rays_launch * ring_share
+        return {"bound": bound, "achieved": fl / ks / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": fl / ks / 1e12 / peak, "kernel_ms": ks * 1e3}
 
     out = {
         "metric": "ray-surface intersections/sec",
@@ -205,46 +291,89 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "point source (phase 2), clearBottle-large + planoConvex-f39.9mm + "
-                               "achromaticDoublet-f50.0mm, 1e7 rays per GPU (BASELINE configs[1])"
-                               if phase == 2 and args.rays == 10_000_000 else
-                               f"phase {phase}, clearBottle-large + planoConvex-f39.9mm + "
-                               f"achromaticDoublet-f50.0mm, {args.rays} rays per GPU",
-                   "rays_per_gpu": args.rays, "phase": phase, "seed": DEFAULT_SEED,
+        "config": {"workload": text, "name": "custom" if custom else args.workload,
+                   "rays_per_layer_per_step": total_rays, "rays_per_gpu_per_launch": cnt,
+                   "phases": list(phases), "seed": DEFAULT_SEED,
                    "sharding": f"contiguous global ray ranges over {world} rank(s); one RCCL sum of "
                                "image+counters per run of K steps, inside the timed region",
                    "intersections_per_step": isect_per_step, "binned_per_step": binned_per_step,
-                   "rays_per_s": total_rays * args.steps / elapsed},
+                   "rays_per_s": total_rays * len(phases) * args.steps / elapsed,
+                   "build_id": build},
+        # the BINDING bound of this path: fp64 vector-ALU issue (no MFMA: there is no contraction)
         "roofline": {
-            "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "trace_queue_kernel<MODE_FUSED, filtered> (+ the literal re-run launch and fold_kernel, same event bracket)", "kernel_ms": k_s * 1e3,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "note": "SURVEY §8(d) contract figure 48 B/ray + 8 B/binned ray; the path is fp64-VALU "
-                    "bound, see roofline_fp64 (DESIGN.md §5)",
-        },
-        "roofline_fp64": {
             "bound": "valu_fp64", "achieved": ach_tf, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach_tf / FP64_VEC_PEAK_TFLOPS, "flop_per_intersection": FLOP_PER_INTERSECTION,
-            "valu_busy_frac_profiled": valu_busy,     # rocprofv3 PMC of this kernel, profiles/ (not live)
+            "frac": ach_tf / FP64_VEC_PEAK_TFLOPS,
+            "traffic": traffic,                                   # HBM bytes per launch, rocprofv3 PMC (or null)
+            "kernel": "trace_queue_kernel<MODE_FUSED, filtered, surface program> (+ the literal re-run "
+                      "launch and fold_kernel, same event bracket)",
+            "kernel_ms": k_s * 1e3,
+            "flop_per_intersection": FLOP_PER_INTERSECTION,
+            "flop_per_ring_emission": FLOP_PER_RING_EMISSION,
+            "algorithmic_flop_per_launch": alg_flop,
+            "note": "algorithmic flop = an assumed 100 per surface solve (SURVEY §8d; + 61 per emitted ring "
+                    "ray in the ring loop) / mean launch duration (HIP events on the context's stream)",
+            # executed work, from the committed PMC passes of this very build (null otherwise)
+            "valu_busy": prof.get("valu_busy_frac"),
+            "valu_lane_utilisation": prof.get("valu_lane_utilisation"),
+            # lane-instructions per surface solve = wave-level VALU instructions x 64 lanes / intersections
+            "valu_instr_per_intersection": (prof["valu_instructions_per_launch"] * 64.0 / prof["intersections_per_launch"]
+                                            if prof.get("valu_instructions_per_launch") and prof.get("intersections_per_launch") else None),
+            "profile_note": prof_note,
         },
+        # SURVEY §8(d)'s contract figure: the bytes the north-star layout (ray state resident in HBM)
+        # WOULD move.  The fused kernel keeps a ray in registers from emission to binning and never
+        # moves the 48 B/ray; shown for the contract only.
+        "roofline_hbm_contract": {
+            "bound": "hbm", "achieved": contract_bytes / k_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": contract_bytes / k_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": contract_bytes,
+            "notional": True,
+        },
+        "roofline_hbm_measured": ({
+            "bound": "hbm", "achieved": traffic / k_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": traffic / k_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_write_bytes": BYTES_PER_BINNED * binned_launch,
+            "write_amplification": (prof.get("write_bytes_per_launch") / (BYTES_PER_BINNED * binned_launch)
+                                    if prof.get("write_bytes_per_launch") and binned_launch else None),
+            "note": "each scattered int32 atomic is one 32-byte memory-side write",
+        } if traffic else None),
     }
-    if fast is not None:
-        out["fast_fp64"] = fast
+    if "fp32" in legs:
+        el, kms, r = legs["fp32"]
+        i32, b32 = isect_binned(r)
+        out["fp32"] = {
+            "value": i32 / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3, "dtype": "f32",
+            "roofline": fp_roofline(kms, r, FP32_VEC_PEAK_TFLOPS, "valu_fp32"),
+            "image_l1_vs_exact": int(abs(r.image.astype("int64") - res.image.astype("int64")).sum()),
+            "image_l1_vs_exact_frac_of_binned": float(abs(r.image.astype("int64") - res.image.astype("int64")).sum()) / max(binned_total, 1),
+            "binned": b32, "binned_exact": binned_total, "intersections": i32, "intersections_exact": isect_total,
+            "note": "ort_set_precision(1), BASELINE configs[4]: the same operations in single precision, literal "
+                    "predicates, uniforms = top 24 bits of the same draws; tests/test_gpu_fp32.py holds the tolerance study",
+        }
+    if "fast_fp64" in legs:
+        el, kms, r = legs["fast_fp64"]
+        i2, _ = isect_binned(r)
+        out["fast_fp64"] = {
+            "value": i2 / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3,
+            "roofline": fp_roofline(kms, r, FP64_VEC_PEAK_TFLOPS, "valu_fp64"),
+            "image_l1_vs_exact": int(abs(r.image.astype("int64") - res.image.astype("int64")).sum()),
+            "note": "ort_set_precision(2): FMA contraction + Newton reciprocal/rsqrt; ~1e-15 relative from the "
+                    "exact path, not bit-identical (tests/test_gpu_fastd.py)",
+        }
     if cpu is not None:
         out["cpu_baseline"] = cpu
         if cpu.get("value"):
             out["gpu_over_cpu"] = value / cpu["value"]
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     tracer.close()
     if use_dist:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

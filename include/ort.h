@@ -39,6 +39,8 @@ extern "C" {
 #define ORT_E_NODEVICE (-2)  /* no HIP device / device index out of range */
 #define ORT_E_HIP (-3)       /* a HIP runtime call failed */
 #define ORT_E_NOMEM (-4)
+#define ORT_E_NOCOMM (-5)    /* RCCL missing or a collective failed (ort_allreduce) */
+#define ORT_MAX_DEVICES 16   /* contexts one ort_allreduce call can span */
 
 /* surface kinds of the staged surface list */
 #define ORT_SURF_PLANE 0     /* move to z = cz, aperture test, Fresnel at N=(0,0,-1)  (src/lens.f90:446-459) */
@@ -139,6 +141,10 @@ typedef struct ort_ctx ort_ctx;
 
 /* Library / device probing. */
 int ort_abi_version(void);
+/* Hash (first 16 hex digits of SHA-256) of the kernel sources the library was built from
+ * (csrc/Makefile: ort_hip.hip, ort_device.h, ort_fastd.h, include/ort.h in that order), so a host
+ * — and the tests — can tell a stale binary from the sources next to it. */
+const char *ort_build_id(void);
 const char *ort_last_error(void);
 int ort_device_count(int *count);
 
@@ -210,6 +216,15 @@ int ort_read(ort_ctx *ctx, int32_t *image, uint64_t *counters);
  * int64[ORT_NUM_COUNTERS]) as the accumulators from now on; they are not zeroed
  * and not freed by the context.  NULL, NULL returns to the context's own. */
 int ort_attach_buffers(ort_ctx *ctx, void *d_image, void *d_counters);
+/* Sum image and counters over the n contexts of ONE process (one context per device) in place,
+ * over RCCL / xGMI: afterwards every context holds the global sums.  The multi-GPU equivalent
+ * of the OpenMP atomic image + `reduction(+:rcount,pcount)` (src/imageMod.f90:55,
+ * src/main.f90:88) for a host that drives all GPUs of a node itself (e.g. a Fortran main
+ * program): trace shard [N g/n, N (g+1)/n) on context g, then one
+ * ort_allreduce.  Asynchronous on each context's stream; ort_read synchronises.  RCCL is loaded
+ * on first use (ORT_E_NOCOMM if absent).  A one-process-per-GPU host reduces the attached
+ * buffers with its own communicator instead (torch.distributed: tracer.py). */
+int ort_allreduce(ort_ctx **ctxs, int n);
 int ort_device_image(ort_ctx *ctx, void **d_image);
 int ort_device_counters(ort_ctx *ctx, void **d_counters);
 int ort_synchronize(ort_ctx *ctx);

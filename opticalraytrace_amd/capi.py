@@ -27,7 +27,7 @@ ST_BINNED, ST_NA_REJECT, ST_OFF_GRID, ST_LOST_BOTTLE, ST_LOST_TELESCOPE, ST_HELP
 
 EMIT_RING, EMIT_POINT, EMIT_SPOT, EMIT_CRS, EMIT_IMAGE = range(5)
 
-_ERRORS = {-1: "ORT_E_INVALID", -2: "ORT_E_NODEVICE", -3: "ORT_E_HIP", -4: "ORT_E_NOMEM"}
+_ERRORS = {-1: "ORT_E_INVALID", -2: "ORT_E_NODEVICE", -3: "ORT_E_HIP", -4: "ORT_E_NOMEM", -5: "ORT_E_NOCOMM"}
 
 
 class OrtError(RuntimeError):
@@ -117,6 +117,21 @@ def library_path() -> str:
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libort_hip.so")
 
 
+KERNEL_SOURCES = ("ort_hip.hip", "ort_device.h", "ort_fastd.h", os.path.join("..", "..", "include", "ort.h"))
+
+
+def source_build_id() -> str:
+    """What ort_build_id() of a library built from the sources in this tree returns
+    (csrc/Makefile BUILD_ID: SHA-256 over the kernel sources, first 16 hex digits)."""
+    import hashlib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def load_library(path: Optional[str] = None) -> C.CDLL:
     """Load libort_hip.so and declare every symbol of include/ort.h.  Raises if absent."""
     global _LIB
@@ -138,6 +153,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     vp, u64, i32, i64 = C.c_void_p, C.c_uint64, C.c_int, C.c_int64
     sig = {
         "ort_abi_version": (C.c_int, []),
+        "ort_build_id": (C.c_char_p, []),
+        "ort_allreduce": (C.c_int, [C.POINTER(vp), i32]),
         "ort_last_error": (C.c_char_p, []),
         "ort_device_count": (C.c_int, [C.POINTER(C.c_int)]),
         "ort_create": (C.c_int, [C.POINTER(OrtSystem), i32, vp, C.POINTER(vp)]),
@@ -173,7 +190,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-EXPORTED_SYMBOLS = ["ort_abi_version", "ort_last_error", "ort_device_count", "ort_create",
+EXPORTED_SYMBOLS = ["ort_abi_version", "ort_build_id", "ort_allreduce", "ort_last_error", "ort_device_count", "ort_create",
                     "ort_destroy", "ort_set_system", "ort_set_image_source", "ort_reset", "ort_trace", "ort_emit",
                     "ort_trace_resident", "ort_trace_rays", "ort_trace_paths", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
@@ -339,6 +356,17 @@ class Context:
             _dptr(out["pos_dir"]), _dptr(out["emitted"]), _iptr(out["status"]),
             _iptr(out["bin_xy"]), _iptr(out["n_isect"]), _iptr(out["n_draws"])), "ort_trace_rays")
         return out
+
+
+def build_id() -> str:
+    return load_library().ort_build_id().decode()
+
+
+def allreduce(contexts) -> None:
+    """ort_allreduce: sum image + counters over the contexts of this process (one per device)."""
+    lib = load_library()
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _check(lib, lib.ort_allreduce(arr, len(contexts)), "ort_allreduce")
 
 
 def device_count() -> int:

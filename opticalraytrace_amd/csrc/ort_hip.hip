@@ -34,6 +34,8 @@
 #include <string.h>
 #include <stdlib.h>
 #include <new>
+#include <dlfcn.h>
+#include <rccl/rccl.h>       // types and enums only: the library is resolved at run time (ort_allreduce)
 #include "../../include/ort.h"
 #include "ort_device.h"
 
@@ -298,8 +300,14 @@ __device__ inline void walk_fixed(const Sys &S, const_surf_t surf, const_aux_t a
         if (wave_any(st < 0)) {
             const ort_surface s = load_surface(surf + K);
             const SurfAuxT<T> ax = load_aux<T>(aux + K);
+#ifdef ORT_ISA_MARKERS      // tools/isa_budget.py: comment lines that delimit the steps in the listing
+            asm volatile("; ORT_STEP_BEGIN %0" ::"n"(K));
+#endif
             surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K]>(
                 S, s, ax, r, draws, nis, st, xp, yp, rare);
+#ifdef ORT_ISA_MARKERS
+            asm volatile("; ORT_STEP_END %0" ::"n"(K));
+#endif
             walk_fixed<FILT, T, KEEP, P, K + 1, K1>(S, surf, aux, r, draws, nis, st, xp, yp, rare);
         }
     }
@@ -790,6 +798,11 @@ extern "C" {
 
 int ort_abi_version(void) { return ORT_ABI_VERSION; }
 
+#ifndef ORT_BUILD_ID
+#define ORT_BUILD_ID "unstamped"
+#endif
+const char *ort_build_id(void) { return ORT_BUILD_ID; }
+
 const char *ort_last_error(void) { return g_err; }
 
 int ort_device_count(int *count)
@@ -799,6 +812,35 @@ int ort_device_count(int *count)
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { *count = 0; return fail(ORT_E_NODEVICE, "hipGetDeviceCount", e); }
     *count = n;
+    return ORT_OK;
+}
+
+// everything of ort_create that can fail after the context exists (the caller destroys it on failure)
+static int create_on_device(ort_ctx *c, const ort_system *sys)
+{
+    HIP_TRY(hipMalloc(&c->d_sys, sizeof(DevSystem)));
+    HIP_TRY(hipMalloc(&c->own_image, ORT_IMAGE_BINS * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->own_counters, ORT_NUM_COUNTERS * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&c->d_replicas, (size_t)kReplicas * ORT_IMAGE_BINS * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(c->d_replicas, 0, (size_t)kReplicas * ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMalloc(&c->d_redo_ctl, 2 * sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(c->d_redo_ctl, 0, 2 * sizeof(unsigned int), c->stream));
+    c->d_image = c->own_image;
+    c->d_counters = c->own_counters;
+    for (int k = 0; k < 3; ++k) {
+        HIP_TRY(hipEventCreate(&c->ev[k][0]));
+        HIP_TRY(hipEventCreate(&c->ev[k][1]));
+    }
+    for (int k = 0; k < kTimingRing; ++k) {
+        HIP_TRY(hipEventCreate(&c->ring[k][0]));
+        HIP_TRY(hipEventCreate(&c->ring[k][1]));
+    }
+    note_system(c, sys);
+    const int rc = upload_system(c, sys);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_image, 0, ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, ORT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return ORT_OK;
 }
 
@@ -822,29 +864,15 @@ int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out)
     // whatever else the caller runs there (torch's default stream, RCCL's stream dependencies)
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
-    HIP_TRY(hipMalloc(&c->d_sys, sizeof(DevSystem)));
-    HIP_TRY(hipMalloc(&c->own_image, ORT_IMAGE_BINS * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&c->own_counters, ORT_NUM_COUNTERS * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(&c->d_replicas, (size_t)kReplicas * ORT_IMAGE_BINS * sizeof(int32_t)));
-    HIP_TRY(hipMemsetAsync(c->d_replicas, 0, (size_t)kReplicas * ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
-    HIP_TRY(hipMalloc(&c->d_redo_ctl, 2 * sizeof(unsigned int)));
-    HIP_TRY(hipMemsetAsync(c->d_redo_ctl, 0, 2 * sizeof(unsigned int), c->stream));
-    c->d_image = c->own_image;
-    c->d_counters = c->own_counters;
-    for (int k = 0; k < 3; ++k) {
-        HIP_TRY(hipEventCreate(&c->ev[k][0]));
-        HIP_TRY(hipEventCreate(&c->ev[k][1]));
+    rc = create_on_device(c, sys);
+    if (rc) {
+        // a half-built context owns device memory and events: release them, keep the message
+        char msg[sizeof g_err];
+        memcpy(msg, g_err, sizeof msg);
+        ort_destroy(c);
+        memcpy(g_err, msg, sizeof msg);
+        return rc;
     }
-    for (int k = 0; k < kTimingRing; ++k) {
-        HIP_TRY(hipEventCreate(&c->ring[k][0]));
-        HIP_TRY(hipEventCreate(&c->ring[k][1]));
-    }
-    note_system(c, sys);
-    rc = upload_system(c, sys);
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_image, 0, ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, ORT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     *out = c;
     return ORT_OK;
 }
@@ -854,8 +882,10 @@ int ort_destroy(ort_ctx *c)
     if (!c) return ORT_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (int k = 0; k < 3; ++k) { (void)hipEventDestroy(c->ev[k][0]); (void)hipEventDestroy(c->ev[k][1]); }
-    for (int k = 0; k < kTimingRing; ++k) { (void)hipEventDestroy(c->ring[k][0]); (void)hipEventDestroy(c->ring[k][1]); }
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 2; ++j) if (c->ev[k][j]) (void)hipEventDestroy(c->ev[k][j]);
+    for (int k = 0; k < kTimingRing; ++k)
+        for (int j = 0; j < 2; ++j) if (c->ring[k][j]) (void)hipEventDestroy(c->ring[k][j]);
     (void)hipFree(c->d_sys); (void)hipFree(c->own_image); (void)hipFree(c->own_counters); (void)hipFree(c->d_replicas); (void)hipFree(c->d_img_cdf);
     (void)hipFree(c->d_redo_list); (void)hipFree(c->d_redo_ctl);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1001,13 +1031,17 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
             if (blocks < (uint64_t)grid) grid = (int)blocks;
         }
         launch_one(c, mode, a, grid, queued, filt, anysrc);
+        HIP_TRY(hipGetLastError());                         // a failed launch is reported where it happened
         if (deferring) {
             a.listed = 1;
             launch_one(c, mode, a, kRedoBlocks, false, false, true);
+            HIP_TRY(hipGetLastError());
         }
     }
-    if (use_rep) hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, a0.phase);
-    HIP_TRY(hipGetLastError());
+    if (use_rep) {
+        hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, a0.phase);
+        HIP_TRY(hipGetLastError());
+    }
     if (c->timing && evk > 0) { HIP_TRY(hipEventRecord(c->ev[evk][1], c->stream)); c->ev_valid[evk] = true; }
     if (c->timing && evk == 0) { HIP_TRY(hipEventRecord(c->ring[slot][1], c->stream)); c->ring_count++; c->ev_valid[0] = true; }
     return ORT_OK;
@@ -1174,6 +1208,88 @@ int ort_attach_buffers(ort_ctx *c, void *d_image, void *d_counters)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->d_image = d_image ? (int32_t *)d_image : c->own_image;
     c->d_counters = d_counters ? (unsigned long long *)d_counters : c->own_counters;
+    return ORT_OK;
+}
+
+// RCCL, resolved lazily: a process that never reduces never loads it, and a process that already
+// holds an RCCL (PyTorch-ROCm bundles one under the same SONAME) gets that very library back
+// from dlopen instead of a second copy.
+namespace {
+struct Rccl {
+    void *lib;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*GroupStart)();
+    ncclResult_t (*GroupEnd)();
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    const char *(*GetErrorString)(ncclResult_t);
+    int n;                                   // communicators currently held ...
+    int devices[ORT_MAX_DEVICES];            // ... for these devices, in this order
+    ncclComm_t comms[ORT_MAX_DEVICES];
+} g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return ORT_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(ORT_E_NOCOMM, "librccl.so.1 cannot be loaded (ort_allreduce needs RCCL)");
+#define ORT_SYM(field, name)                                                               \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));              \
+    if (!g_rccl.field) return fail(ORT_E_NOCOMM, "librccl.so.1 lacks " name)
+    ORT_SYM(CommInitAll, "ncclCommInitAll");
+    ORT_SYM(CommDestroy, "ncclCommDestroy");
+    ORT_SYM(GroupStart, "ncclGroupStart");
+    ORT_SYM(GroupEnd, "ncclGroupEnd");
+    ORT_SYM(AllReduce, "ncclAllReduce");
+    ORT_SYM(GetErrorString, "ncclGetErrorString");
+#undef ORT_SYM
+    g_rccl.lib = h;
+    return ORT_OK;
+}
+
+int rccl_fail(const char *what, ncclResult_t r)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+    return ORT_E_NOCOMM;
+}
+#define RCCL_TRY(expr)                                                   \
+    do {                                                                 \
+        ncclResult_t r_ = (expr);                                        \
+        if (r_ != ncclSuccess) return rccl_fail(#expr, r_);              \
+    } while (0)
+}  // namespace
+
+int ort_allreduce(ort_ctx **ctxs, int n)
+{
+    if (!ctxs || n < 1 || n > ORT_MAX_DEVICES) return fail(ORT_E_INVALID, "ctxs NULL or n outside 1..ORT_MAX_DEVICES");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return fail(ORT_E_INVALID, "a context is NULL");
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j]->device == ctxs[i]->device) return fail(ORT_E_INVALID, "two contexts on one device: RCCL ranks are devices");
+    }
+    int rc = rccl_load();
+    if (rc) return rc;
+    bool same = g_rccl.n == n;
+    for (int i = 0; same && i < n; ++i) same = g_rccl.devices[i] == ctxs[i]->device;
+    if (!same) {
+        for (int i = 0; i < g_rccl.n; ++i) (void)g_rccl.CommDestroy(g_rccl.comms[i]);
+        g_rccl.n = 0;
+        int devs[ORT_MAX_DEVICES];
+        for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+        RCCL_TRY(g_rccl.CommInitAll(g_rccl.comms, n, devs));
+        for (int i = 0; i < n; ++i) g_rccl.devices[i] = devs[i];
+        g_rccl.n = n;
+    }
+    // one group: image (int32 x 321 602 = 1.29 MB) and counters (uint64 x 8) of every device, each on
+    // its context's stream, so the sums are ordered after the traces already queued there
+    RCCL_TRY(g_rccl.GroupStart());
+    for (int i = 0; i < n; ++i) {
+        ort_ctx *c = ctxs[i];
+        RCCL_TRY(g_rccl.AllReduce(c->d_image, c->d_image, ORT_IMAGE_BINS, ncclInt32, ncclSum, g_rccl.comms[i], c->stream));
+        RCCL_TRY(g_rccl.AllReduce(c->d_counters, c->d_counters, ORT_NUM_COUNTERS, ncclUint64, ncclSum, g_rccl.comms[i], c->stream));
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
     return ORT_OK;
 }
 

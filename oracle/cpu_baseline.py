@@ -12,7 +12,9 @@ number of rays and prints one JSON object.
       flang and does not scale).
   kind "port": oracle/libort_oracle.so — the plain-C restatement, same loop.
 
-Only the loop is timed (no parsing, no file output), as for the GPU.
+Only the loop is timed (no parsing, no file output), as for the GPU.  Each timing runs in a
+fresh process with OMP_NUM_THREADS = the physical cores, then every hardware thread; the best is
+reported with both counts stated (`cores`, `threads`).
 """
 import argparse
 import json
@@ -24,45 +26,75 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rays", type=int, default=20_000_000)
-    ap.add_argument("--phase", type=int, default=2)
-    ap.add_argument("--kind", choices=["auto", "reference", "port"], default="auto")
-    args = ap.parse_args()
+def physical_cores(cpus):
+    """Distinct (socket, core) pairs among the logical CPUs this process may run on."""
+    cores, cur = set(), {}
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ":" in ln:
+                k, v = [x.strip() for x in ln.split(":", 1)]
+                cur[k] = v
+            elif not ln.strip() and cur:
+                if int(cur.get("processor", -1)) in cpus:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+    except OSError:
+        pass
+    return len(cores) or len(cpus)
 
-    os.environ.setdefault("OMP_NUM_THREADS", str(len(os.sched_getaffinity(0))))
-    cores = int(os.environ["OMP_NUM_THREADS"])      # = threads actually used
-    os.environ.setdefault("OMP_PROC_BIND", "false")
 
-    import numpy as np
+def run_once(kind: str, rays: int, phase: int, threads: int):
+    """One timing in a fresh process (the OpenMP team size is fixed at first use)."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", kind, "--rays", str(rays),
+                          "--phase", str(phase)], env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not line:
+        raise RuntimeError(f"{kind} worker failed: {out.stderr[-400:]}")
+    return json.loads(line[-1])
+
+
+def worker(kind: str, rays: int, phase: int):
+    import numpy as np  # noqa: F401
     from opticalraytrace_amd.params import Settings, resource_dir
     from opticalraytrace_amd.system import OpticalSystem
-    from oracle.binding import Oracle, Reference, reference_available
+    from oracle.binding import Oracle, Reference
 
-    s = Settings(nphotons=args.rays, make_images=True, bottle_file="clearBottle-large.params",
+    s = Settings(nphotons=rays, make_images=True, bottle_file="clearBottle-large.params",
                  L2_file="planoConvex-f39.9mm.params", L3_file="achromaticDoublet-f50.0mm.params")
     osys = OpticalSystem.from_settings(s)
     orc = Oracle(osys)
     seed = 123456789
-    # exact intersection count of the sample (the oracle counts them; the Fortran cannot)
     warm = 1_000_000                                        # first large call pays thread/arena start-up
-
-    def time_port(n):
-        orc.trace(args.phase, 0, warm, seed)
-        t0 = time.perf_counter()
-        _, c = orc.trace(args.phase, 0, n, seed)
-        return time.perf_counter() - t0, int(c[2 + args.phase - 1])
-
-    def time_reference(n):
+    if kind == "reference":
         ref = Reference(s, resource_dir())
-        ref.trace(args.phase, 0, warm, seed)
+        ref.trace(phase, 0, warm, seed)
         t0 = time.perf_counter()
-        ref.trace(args.phase, 0, n, seed)
+        ref.trace(phase, 0, rays, seed)
         dt = time.perf_counter() - t0
-        _, c = orc.trace(args.phase, 0, n, seed)            # untimed: the oracle counts the intersections
-        return dt, int(c[2 + args.phase - 1])
+        _, c = orc.trace(phase, 0, rays, seed)              # untimed: the oracle counts the intersections
+    else:
+        orc.trace(phase, 0, warm, seed)
+        t0 = time.perf_counter()
+        _, c = orc.trace(phase, 0, rays, seed)
+        dt = time.perf_counter() - t0
+    print(json.dumps({"seconds": dt, "intersections": int(c[2 + phase - 1])}))
 
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=50_000_000)
+    ap.add_argument("--phase", type=int, default=2)
+    ap.add_argument("--kind", choices=["auto", "reference", "port"], default="auto")
+    ap.add_argument("--worker", choices=["reference", "port"], default=None, help="internal: one timing")
+    args = ap.parse_args()
+    if args.worker:
+        return worker(args.worker, args.rays, args.phase)
+
+    from oracle.binding import reference_available
+    cpus = os.sched_getaffinity(0)
+    n_threads, n_cores = len(cpus), physical_cores(cpus)
     kind = args.kind
     if kind == "auto":
         kind = "reference" if reference_available() else "port"
@@ -74,20 +106,34 @@ def main():
                 break
     except OSError:
         pass
-    dt, isect = time_reference(args.rays) if kind == "reference" else time_port(args.rays)
+    # thread counts tried: one per physical core, and every hardware thread; the best is reported
+    tried = sorted({n_cores, n_threads})
+    sweep = {}
+    for k in ([kind] if kind == "port" else ["reference", "port"]):
+        for t in tried:
+            r = run_once(k, args.rays, args.phase, t)
+            sweep[f"{k}@{t}"] = {"threads": t, "seconds": r["seconds"], "value": r["intersections"] / r["seconds"],
+                                 "rays_per_s": args.rays / r["seconds"]}
+            isect = r["intersections"]
+    best_t = max(tried, key=lambda t: sweep[f"{kind}@{t}"]["value"])
+    best = sweep[f"{kind}@{best_t}"]
     extra = {}
     if kind == "reference":                                 # also report the C restatement
-        dtp, ip = time_port(args.rays)
-        extra = {"port_value": ip / dtp,
-                 "port_sample": f"oracle/libort_oracle.so (C restatement, gcc -O2 + OpenMP, {cores} threads): "
-                                f"{args.rays} rays in {dtp:.3f} s wall"}
+        bp = max(tried, key=lambda t: sweep[f"port@{t}"]["value"])
+        extra = {"port_value": sweep[f"port@{bp}"]["value"], "port_threads": bp,
+                 "port_sample": "oracle/libort_oracle.so (C restatement, gcc -O2 + OpenMP)"}
     what = ("oracle/_ref: the reference's own Fortran path sources compiled with flang -O2, OpenMP over rays"
             if kind == "reference" else "oracle/libort_oracle.so: C restatement, gcc -O2, OpenMP over rays")
     print(json.dumps({
-        "value": isect / dt, "unit": "intersections/s", "cores": cores, "kind": kind,
-        "sample": f"{args.rays} rays of phase {args.phase} (BASELINE configs[1] system, seed {seed}), "
-                  f"{isect} intersections in {dt:.3f} s wall on {cores} threads; {what}",
-        "rays_per_s": args.rays / dt, "seconds": dt, "cpu": cpu_model, **extra}))
+        "value": best["value"], "unit": "intersections/s",
+        "cores": min(n_cores, best_t),                      # physical cores the best run occupied
+        "threads": best_t, "physical_cores_available": n_cores, "hardware_threads_available": n_threads,
+        "kind": kind,
+        "sample": f"{args.rays} rays of phase {args.phase} (BASELINE configs[1] system, seed 123456789), "
+                  f"{isect} intersections in {best['seconds']:.3f} s wall on {best_t} threads "
+                  f"(best of threads = {tried}); {what}",
+        "rays_per_s": best["rays_per_s"], "seconds": best["seconds"], "cpu": cpu_model,
+        "thread_sweep": sweep, **extra}))
 
 
 if __name__ == "__main__":

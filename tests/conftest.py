@@ -28,16 +28,17 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session")
 def hip_library():
-    """Path of the in-tree libort_hip.so, built here when hipcc is available."""
-    from opticalraytrace_amd.capi import library_path
+    """Path of the in-tree libort_hip.so.  `make` (a no-op when the library is newer than every
+    source the Makefile lists) runs wherever hipcc exists; a library whose ort_build_id() is not the
+    hash of the sources next to it fails the session: a stale binary cannot pass silently."""
+    from opticalraytrace_amd.capi import build_id, library_path, source_build_id
     p = library_path()
-    src = os.path.join(os.path.dirname(p), "ort_hip.hip")
-    hdr = os.path.join(os.path.dirname(p), "ort_device.h")
-    stale = (not os.path.exists(p)) or any(os.path.getmtime(p) < os.path.getmtime(f) for f in (src, hdr))
-    if stale and os.path.exists("/opt/rocm/bin/hipcc"):
-        subprocess.run(["make", "-C", os.path.dirname(p)], check=True, capture_output=True)
+    if os.path.exists("/opt/rocm/bin/hipcc") and not os.environ.get("ORT_HIP_LIB"):
+        subprocess.run(["make", "-C", os.path.dirname(p), "libort_hip.so"], check=True, capture_output=True)
     if not os.path.exists(p):
         pytest.fail(f"{p} missing and cannot be built: the product has no fallback")
+    if not os.environ.get("ORT_HIP_LIB") and build_id() != source_build_id():
+        pytest.fail(f"{p} was built from other sources (ort_build_id {build_id()} != {source_build_id()})")
     return p
 
 

@@ -30,12 +30,19 @@ def test_struct_layout_matches_header(hip_library):
     assert lib.ort_abi_version() == capi.ABI_VERSION
 
 
+def test_library_is_built_from_the_sources_in_this_tree(hip_library):
+    """ort_build_id() = hash of the kernel sources (csrc/Makefile): a stale binary is detected."""
+    assert capi.build_id() == capi.source_build_id()
+    assert len(capi.build_id()) == 16 and capi.build_id() != "unstamped"
+
+
 def test_invalid_arguments_return_codes_without_a_device(hip_library):
     lib = capi.load_library()
     h = C.c_void_p()
     assert lib.ort_create(None, 0, None, C.byref(h)) == -1          # ORT_E_INVALID before any device work
     assert lib.ort_trace(None, 2, 0, 10, 1) == -1
     assert lib.ort_read(None, None, None) == -1
+    assert lib.ort_allreduce(None, 1) == -1 and lib.ort_allreduce(None, 0) == -1
     assert b"NULL" in lib.ort_last_error()
 
 

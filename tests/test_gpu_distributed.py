@@ -1,0 +1,158 @@
+"""The multi-GPU path as far as ONE MI355X can exercise it, through the product code:
+RayTracer + ort_attach_buffers + RCCL (`nccl` backend) all-reduce on the tracer's stream, shards of
+the global ray range traced by separate contexts, the C-ABI ort_allreduce, and bench.py's own
+rank launcher.  The world-size 2 / 3 shard + reduce logic runs under gloo in
+test_distributed_gloo.py; the 8-GPU run is the driver's."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import make_system
+from parity import SEED
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 300_007        # odd: uneven shards
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def plain(hip_library):
+    """The single-context run everything below must reproduce bit for bit."""
+    from opticalraytrace_amd.tracer import RayTracer
+    _, osys = make_system("large")
+    t = RayTracer(osys, device=0)
+    try:
+        res = t.run(N, seed=SEED)
+    finally:
+        t.close()
+    assert res.image[0].sum() > 0 and res.image[1].sum() > 0.3 * N
+    return osys, res
+
+
+def test_rccl_reduce_on_one_rank_equals_plain_run(plain):
+    """init_process_group("nccl", world_size=1): RayTracer.run() with the all-reduce forced — the
+    collective really runs on the attached torch tensors, stream-ordered after the trace."""
+    import torch
+    import torch.distributed as dist
+    from opticalraytrace_amd.tracer import RayTracer
+    osys, want = plain
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        t = RayTracer(osys, device=0, rank=0, world=1)
+        try:
+            t.reset()
+            for phase in (1, 2):
+                t.trace_phase(phase, N, SEED)
+            t.reduce(force=True)                    # RCCL all-reduce of image + counters
+            got = t.result(N)
+            # twice: the reduce of a second run must see the second run's trace, not race it
+            t.reset()
+            for phase in (1, 2):
+                t.trace_phase(phase, N, SEED)
+            t.reduce(force=True)
+            again = t.result(N)
+        finally:
+            t.close()
+    finally:
+        dist.destroy_process_group()
+    for r in (got, again):
+        assert np.array_equal(r.image, want.image)
+        assert np.array_equal(r.counters, want.counters)
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_shards_on_separate_contexts_sum_to_the_single_run(plain, world):
+    """Rank r of `world` traces shard_range(N, r, world) on its own context (all on this one GPU);
+    the integer sum of the shard images / counters is the single run's, bit for bit."""
+    from opticalraytrace_amd.tracer import RayTracer, shard_range
+    osys, want = plain
+    img = np.zeros_like(want.image, dtype=np.int64)
+    cnt = np.zeros(8, dtype=np.uint64)
+    covered = 0
+    tracers = [RayTracer(osys, device=0, rank=r, world=world) for r in range(world)]
+    try:
+        for t in tracers:
+            t.reset()
+            for phase in (1, 2):
+                t.trace_phase(phase, N, SEED)
+        for r, t in enumerate(tracers):
+            res = t.result(N)
+            covered += shard_range(N, r, world)[1]
+            assert 0 < res.image.sum() < want.image.sum()
+            img += res.image
+            cnt += res.counters
+    finally:
+        for t in tracers:
+            t.close()
+    assert covered == N
+    assert np.array_equal(img, want.image.astype(np.int64))
+    assert np.array_equal(cnt, want.counters)
+
+
+def test_c_abi_allreduce(plain):
+    """ort_allreduce over the contexts of one process (here: one — a box with one GPU): RCCL is
+    resolved at run time, the group call runs on the context's stream and leaves the sums of a
+    one-rank communicator, i.e. the run itself."""
+    import ctypes as C
+    from opticalraytrace_amd import capi
+    osys, want = plain
+    lib = capi.load_library()
+    assert lib.ort_allreduce(None, 1) == -1
+    with capi.Context(osys, device=0) as a, capi.Context(osys, device=0) as b:
+        arr = (C.c_void_p * 2)(a._h, b._h)
+        assert lib.ort_allreduce(arr, 2) == -1 and b"one device" in lib.ort_last_error()
+        assert lib.ort_allreduce(arr, 0) == -1
+        a.reset()
+        for phase in (1, 2):
+            a.trace(phase, 0, N, SEED)
+        capi.allreduce([a])
+        capi.allreduce([a])                         # the communicator is kept between calls
+        img, cnt = a.read()
+    assert np.array_equal(img, want.image)
+    assert np.array_equal(cnt, want.counters)
+
+
+def _bench(*flags, timeout=600):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, cwd=ROOT,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_starts_its_own_ranks_or_fails_cleanly():
+    """`python bench.py --gpus 2` as the driver issues it (no launcher): on a box with fewer GPUs a
+    message and a non-zero exit, no traceback; with enough GPUs the line says n_gpus 2."""
+    import torch
+    p = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-fast", "--no-fp32")
+    if torch.cuda.device_count() < 2:
+        assert p.returncode != 0 and "GPU(s)" in p.stderr and "Traceback" not in p.stderr
+        assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    else:
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["value"] > 0
+
+
+def test_bench_one_rank_through_rccl():
+    """The N > 1 code path of bench.py on one rank (--force-dist: process group, barrier, RCCL
+    all-reduce inside the timed region, max over ranks)."""
+    p = _bench("--gpus", "1", "--steps", "3", "--warmup", "1", "--force-dist", "--no-fast", "--no-fp32",
+               "--rays", "1000000")
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 1e9
+    assert abs(line["config"]["intersections_per_step"] / 1e6 - 6.31) < 0.05      # 6.31 per point ray
+    assert line["roofline"]["bound"] == "valu_fp64" and 0 < line["roofline"]["frac"] < 1
