@@ -335,6 +335,59 @@ __device__ inline VecT<T> vnormalise_f(VecT<T> a, bool need, bool &rare, bool x_
     return vnormalise(a);
 }
 
+// Normalisation of a vector whose length is KNOWN up to rounding: the normal of a sphere or a
+// circular cylinder at a point of the surface (|N| = radius), a direction that was already divided
+// by its length (|v| = 1).  With t0 the known length, h0 = 1/(2 t0), k0 = h0/(2 t0^2):
+//   e  = s - t0^2                  (one fma: exact up to 2^-53 |e|)
+//   g1 = t0 + e h0                 sqrt(s) to |x|^2/8 + one rounding,  x = e/t0^2, |x| < 2^-32
+//   h1 = h0 - e k0                 1/(2 sqrt s) to 2^-52
+//   t  = g1 + (s - g1^2) h1        the residual correction that ends the compiler's own square-root
+//                                  expansion: the correctly rounded sqrt(s), i.e. the bits of sqrt(s)
+//   r  = 2 h1 refined by one Newton step on t: 1/t to within an ulp, as after the compiler's two
+//        steps on the v_rcp seed; then the three quotients exactly as div3_f
+// No v_rsq, no v_rcp, 8 instructions instead of 15 (+ 2 quarter-rate seeds) in front of the
+// quotients.  A lane whose s is not within 2^-32 of t0^2 (it is not on the surface: only garbage
+// lanes and rays the quadratic flagged already) raises `rare`.
+// tests/csrc/check_exact_ops.hip compares with v / sqrt(v.v) over 2^28 operand sets per mode.
+template <bool FILT, class T>
+__device__ inline VecT<T> vnormalise_est(VecT<T> a, T t0, T h0, T k0, T s_tol, bool need, bool &rare, bool x_zero = false)
+{
+    if constexpr (FILT && std::is_same<T, double>::value) {
+        const double s = a.x * a.x + a.y * a.y + a.z * a.z;
+        const double e = __builtin_fma(-t0, t0, s);
+        const double g1 = __builtin_fma(e, h0, t0);
+        const double h1 = __builtin_fma(-e, k0, h0);
+        const double d = __builtin_fma(-g1, g1, s);
+        const double t = __builtin_fma(d, h1, g1);
+        const double y = h1 + h1;
+        const double e2 = __builtin_fma(-t, y, 1.0);
+        const double r = __builtin_fma(y, e2, y);
+        const double mx = a.x * r, my = a.y * r, mz = a.z * r;
+        Vec q;
+        q.x = __builtin_fma(__builtin_fma(-t, mx, a.x), r, mx);
+        q.y = __builtin_fma(__builtin_fma(-t, my, a.y), r, my);
+        q.z = __builtin_fma(__builtin_fma(-t, mz, a.z), r, mz);
+        const bool odd = (!x_zero && !(fabs(a.x) > 0x1p-300)) || !(fabs(a.y) > 0x1p-300) || !(fabs(a.z) > 0x1p-300);
+        ORT_RARE(1, need && (odd || !(fabs(e) < s_tol)));
+        return q;
+    }
+    return vnormalise(a);
+}
+
+// x / y for operands that need neither v_div_scale's rescaling nor v_div_fixup's special cases
+// (the caller's guard keeps |x|, |y| and |x / y| between 2^-700 and 2^700, y away from the
+// subnormals): the compiler's division sequence with those two stages left out — bit for bit x / y.
+__device__ inline double div_plain(double x, double y)
+{
+    double r = __builtin_amdgcn_rcp(y);
+    double e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double m = x * r;
+    return __builtin_fma(__builtin_fma(-y, m, x), r, m);
+}
+
 template <class T> struct RayT { VecT<T> pos, dir; };
 using Ray = RayT<double>;
 
@@ -376,6 +429,10 @@ __device__ inline double rsq_approx(double s)
     return __builtin_fma(y, e, y);
 }
 __device__ inline fastd rcp_approx(fastd y) { return fastd(rcp_approx(y.v)); }
+// a b + c in one rounding, for decision-only arithmetic (the traced state never uses it)
+__device__ inline double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ inline fastd fmad(fastd a, fastd b, fastd c) { return fastd(__builtin_fma(a.v, b.v, c.v)); }
+__device__ inline float fmad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ inline fastd rsq_approx(fastd s) { return fastd(rsq_approx(s.v)); }
 
 // The staged system as the kernels see it.  For T = double this is ort_system itself (the
@@ -401,7 +458,7 @@ template <> struct SysTypes<fastd> { using Sys = ort_system; using Surf = ort_su
 // but fp64 arithmetic lives in the vector unit): formed once per workgroup next to the staged
 // system, by the very operations the per-ray code would use, so nothing changes bit-wise.  Only
 // the filtered path reads them; the literal path recomputes from the surface record.
-template <class T> struct SurfAuxT { T r2, ap2, ap_tol, eta2, ell_sa, ell_sb; };
+template <class T> struct SurfAuxT { T r2, ap2, ap_tol, eta2, ell_sa, ell_sb, rh, rk, r2_tol; };
 template <class T, class Surf>
 __host__ __device__ inline SurfAuxT<T> make_aux(const Surf &s)
 {
@@ -413,6 +470,11 @@ __host__ __device__ inline SurfAuxT<T> make_aux(const Surf &s)
     a.eta2 = e * e;                        // refract: eta**2
     a.ell_sa = T(1.) / (r * r);            // intersect_ellipse: 1/semia**2, 1/semib**2 (inf for other kinds: unused)
     a.ell_sb = T(1.) / (rb * rb);
+    // vnormalise_est: the normal of a sphere / cylinder has length radius up to rounding, so its
+    // square root and reciprocal start from these estimates instead of v_rsq / v_rcp seeds
+    a.rh = T(0.5) / r;                     // 1 / (2 |N|)
+    a.rk = a.rh / (T(2.) * a.r2);          // d(1/(2 sqrt s))/ds at s = r^2, negated
+    a.r2_tol = T(0x1p-32) * a.r2;          // |N.N - r^2| beyond this: not a point of the surface, literal path
     return a;
 }
 
@@ -443,8 +505,7 @@ template <> __device__ inline bool aperture_present<float>(float a)
 // operands chosen by selects:
 //   q > 0 : roots c/q <= q/a ; c/q < 0 <=> c < 0  -> t = c < 0 ? q/a : c/q   (always a hit)
 //   q < 0 : q/a < 0 ; hit <=> c/q >= 0 <=> c <= 0 -> t = c/q
-// Range guards: D in (1e-200, 1e200) (hence |hb| < 1e105, 1e-100 < |q| < 2e105: no quotient
-// leaves the normal range for a < 1e10 and |c| > 1e-200; a = 0 or NaN makes D fail).
+// Range guards: on the two operands of the quotient, see `ok`.
 // ----------------------------------------------------------------------------
 template <bool FILT, class T>
 __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit, bool &rare)
@@ -458,15 +519,31 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
         const T sq = sqrt_f<true, T>(D, false, unused);   // range: see `ok`; NaN when neg (misses)
         const bool bpos = hb > T(0.0);
         const T q = -(hb + (bpos ? sq : -sq));        // :249-253
-        // c = 0 (a ray that starts exactly on the surface) is left to the literal path as well,
-        // so that below c is either < 0 or > 0
-        const bool ok = D > T(1e-10) * hh && D > T(1e-200) && D < T(1e200) && a < T(1e10) && fabs(c) > T(1e-200);
         const bool qpos = !bpos;                      // q = -(hb + s) < 0 for hb > 0, = s - hb > 0 otherwise (s > 0)
         const bool cneg = c < T(0.0);
         const bool use_qa = qpos && cneg;
-        t = ORT_DIV(use_qa ? q : c, use_qa ? a : q);
+        const T num = use_qa ? q : c, den = use_qa ? a : q;
+        // The one quotient is formed without v_div_scale's rescaling and v_div_fixup's special cases
+        // (div_plain), which is x / y bit for bit while the operands stay well inside the normal range.
+        // Tested for every lane: |D| > 1e-10 hb^2 (not tangent), |D| < 2^900 (hb^2 and a c far from
+        // overflow: D and the reference's b^2 - 4 a c then have the same sign — the scaling by 4 is
+        // exact), a in (2^-100, 2^100), |c| > 2^-300 (a c is a normal number; c = 0 — a ray that
+        // starts exactly on the surface — and a quotient c/q that would underflow to a signed zero,
+        // which the reference's root ordering treats as a root at distance 0, go to the literal
+        // path).  For a lane with real roots also |q| = |hb| + sqrt(D) in (2^-300, 2^300): sqrt(D) <=
+        // |q| and D > 2^-640 are inside sqrt_f's range, |c| < 2^701, every quotient in (2^-1000, 2^1000).
+        // (tools/check_quadratic.py replays these guards on the CPU over all exponents.)
+        const bool common = (fabs(D) > T(1e-10) * hh) & (fabs(D) < T(0x1p900)) & (a > T(0x1p-100)) & (a < T(0x1p100)) &
+                            (fabs(c) > T(0x1p-300));
+        const bool ok = common & (neg | ((fabs(q) > T(0x1p-300)) & (fabs(q) < T(0x1p300))));
+#if defined(ORT_ABL_FASTDIV)
+        t = ORT_DIV(num, den);
+#else
+        if constexpr (std::is_same<T, double>::value) t = div_plain(num, den);
+        else t = num / den;
+#endif
         hit = (qpos || cneg) && !neg;
-        ORT_RARE(2, live && !neg && !ok);             // tangent, degenerate, on the surface, or NaN
+        ORT_RARE(2, live && !ok);                     // tangent, degenerate, on the surface, out of range, or NaN
     } else {
         const T b = T(2.0) * hb;
         const T discrim = b * b - T(4.0) * a * c;
@@ -556,18 +633,23 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
     if constexpr (FILT) {
         // fresnel's two amplitude ratios with numerator and denominator divided by n2:
         // (n1 c1 - n2 c2)/(n1 c1 + n2 c2) = (eta c1 - c2)/(eta c1 + c2), likewise the other
+        // and u < R is tested on the cross-multiplied form (every factor below is positive)
+        //   2 u B^2 E^2 < A^2 E^2 + C^2 B^2,   A = eta c1 - c2, B = eta c1 + c2, C = eta c2 - c1, E = eta c2 + c1
+        // — ten multiply-adds, no reciprocal; relative error of either side < 1e-15.
         const T ec2 = eta * c2;
-        const T f1 = m * rcp_approx(ec1 + c2);
-        const T f2 = (ec2 - c1) * rcp_approx(ec2 + c1);
-        const T R = T(0.5) * (f1 * f1 + f2 * f2);
+        const T B = ec1 + c2, E = ec2 + c1, Cn = ec2 - c1;
+        const T B2 = B * B, E2 = E * E, A2 = m * m, C2 = Cn * Cn;
+        const T P = B2 * E2;
+        const T rhs = fmad(A2, E2, C2 * B2);                    // = 2 R P
+        const T diff = fmad(T(-0.5), rhs, u * P);               // = (u - R) P
         // Total internal reflection is an everyday outcome at the rim of the plano-convex lens
         // (6 % of the ring rays): k < -1e-6 means eta^2 (1 - c1^2) > 1 + 1e-6, so fresnel's
         // `sint2 > 1` (:353) holds whatever its rounding and it returns 1: u <= 1 reflects.
-        // (R is NaN there and is not consulted.)  NaN anywhere else -> undecided; c1 >= 1 and
+        // (diff is NaN there and is not consulted.)  NaN anywhere else -> undecided; c1 >= 1 and
         // k within 1e-6 of zero -> literal path.
         const bool tir = k < T(-1e-6);
-        const bool decided = (c1 < T(1.0)) && (tir || ((k > T(1e-6)) && (fabs(u - R) > T(1e-10))));
-        reflected = tir || (u < R);
+        const bool decided = (c1 < T(1.0)) & (tir | ((k > T(1e-6)) & (fabs(diff) > T(1e-10) * P)));
+        reflected = tir | (diff < T(0.0));
         ORT_RARE(3, live && !decided);
     } else {
         reflected = u <= fresnel(c1, n1, n2, eta);       // :275
@@ -604,7 +686,11 @@ __device__ inline bool outside_aperture(T x, T y, T A, T A2, T A2tol, bool live,
 // the lanes still walking; every draw is consumed only by those lanes.  Always literal
 // (no filtered predicates inside the walk).
 // ----------------------------------------------------------------------------
-template <class T> __device__ inline void sincos_t(T x, T *s, T *c);
+// sine and cosine BY VALUE: results handed back through pointers end up as stack slots whenever
+// the optimiser merges two call sites (pointer phis defeat SROA: the fast-fp64 and fp32 kernels
+// carried 40 / 20 bytes of scratch per lane for exactly that)
+template <class T> struct SinCosT { T s, c; };
+template <class T> __device__ inline SinCosT<T> sincos_v(T x);
 
 // one leg: optical depth tau = -log(u) against the distance to the cylinder wall.
 // ok = false is the reference's `error stop "no intersection"`.
@@ -651,7 +737,7 @@ __device__ inline void stokes_hg(VecT<T> &dir, T hgg, T twopi, bool on, D &draws
     const bool upper = ri1 > pi;                         // :75 — the two branches mirror each other
     const T ang = upper ? twopi - ri1 : ri1;
     T sa, ca;
-    sincos_t<T>(ang, &sa, &ca);
+    { const SinCosT<T> sc_ = sincos_v<T>(ang); sa = sc_.s; ca = sc_.c; }
     const bool keep = (bmu == T(1.)) || (bmu == T(-1.));   // goto 100: direction unchanged
     T cost = costp * bmu + sintp * sinbt * ca;
     const bool mid = fabs(cost) < T(1.);
@@ -667,7 +753,7 @@ __device__ inline void stokes_hg(VecT<T> &dir, T hgg, T twopi, bool on, D &draws
     phi = phi > twopi ? phi - twopi : phi;
     phi = phi < T(0.) ? phi + twopi : phi;
     T sp, cp;
-    sincos_t<T>(phi, &sp, &cp);
+    { const SinCosT<T> sc_ = sincos_v<T>(phi); sp = sc_.s; cp = sc_.c; }
     const VecT<T> nd = {sint * cp, sint * sp, cost};
     dir = vselect(on && !keep, nd, dir);
 }
@@ -729,7 +815,7 @@ __device__ inline double scalar_const(double v)
 }
 #define ORT_SC(v) scalar_const(v)
 
-__device__ inline void sincos_small(double x, double *s, double *c)
+__device__ inline SinCosT<double> sincos_small(double x)
 {
     const double k = __builtin_rint(x * ORT_SC(6.36619772367581382433e-01));        // x * 2/pi
     double r = __builtin_fma(-k, ORT_SC(1.57079632679489655800e+00), x);
@@ -752,14 +838,40 @@ __device__ inline void sincos_small(double x, double *s, double *c)
     const int n = (int)k;
     const bool swap = (n & 1) != 0;
     const double ss = swap ? cr : sr, cc = swap ? sr : cr;
-    *s = (n & 2) ? -ss : ss;
-    *c = ((n + 1) & 2) ? -cc : cc;
+    return {(n & 2) ? -ss : ss, ((n + 1) & 2) ? -cc : cc};
+}
+// The fp32 study path: the same scheme in single precision (two-term Cody-Waite reduction with
+// fmaf, fdlibm's k_sinf / k_cosf polynomials): < 1 ulp (fp32) on [0, 2 pi]
+__device__ inline SinCosT<float> sincos_small_f32(float x)
+{
+    const float k = __builtin_rintf(x * 6.36619772367581382433e-01f);
+    float r = __builtin_fmaf(-k, 1.57079637050628662109375f, x);
+    r = __builtin_fmaf(-k, -4.37113900018624283e-8f, r);
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, 2.7557314297e-06f, -1.9841270114e-04f);
+    ps = __builtin_fmaf(z, ps, 8.3333337680e-03f);
+    ps = __builtin_fmaf(z, ps, -1.6666667163e-01f);
+    const float sr = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(z, -2.7557314297e-07f, 2.4801587642e-05f);
+    pc = __builtin_fmaf(z, pc, -1.3888889225e-03f);
+    pc = __builtin_fmaf(z, pc, 4.1666667908e-02f);
+    const float hz = 0.5f * z;
+    const float w = 1.0f - hz;
+    const float cr = w + (((1.0f - w) - hz) + z * z * pc);
+    const int n = (int)k;
+    const bool swap = (n & 1) != 0;
+    const float ss = swap ? cr : sr, cc = swap ? sr : cr;
+    return {(n & 2) ? -ss : ss, ((n + 1) & 2) ? -cc : cc};
 }
 // every call site passes an angle in [0, 2 pi] (twopi * u, a bounded fan angle, a direction's
 // azimuth); no fallback to the device library here: its constants alone would sit in 18 VGPRs
-template <> __device__ inline void sincos_t<double>(double x, double *s, double *c) { sincos_small(x, s, c); }
-template <> __device__ inline void sincos_t<fastd>(fastd x, fastd *s, fastd *c) { sincos_t<double>(x.v, &s->v, &c->v); }
-template <> __device__ inline void sincos_t<float>(float x, float *s, float *c) { sincosf(x, s, c); }
+template <> __device__ inline SinCosT<double> sincos_v<double>(double x) { return sincos_small(x); }
+template <> __device__ inline SinCosT<fastd> sincos_v<fastd>(fastd x)
+{
+    const SinCosT<double> v = sincos_small(x.v);
+    return {fastd(v.s), fastd(v.c)};
+}
+template <> __device__ inline SinCosT<float> sincos_v<float>(float x) { return sincos_small_f32(x); }
 
 // ----------------------------------------------------------------------------
 // emitters (straight-line)
@@ -772,12 +884,14 @@ __device__ inline void emit_point(const Sys &S, RayT<T> &r, D &draws, bool &rare
 {
     T phi = S.twopi * draws.template next_as<T>();
     T sinp, cosp;
-    sincos_t<T>(phi, &sinp, &cosp);
+    { const SinCosT<T> sc_ = sincos_v<T>(phi); sinp = sc_.s; cosp = sc_.c; }
     T ran = draws.template next_as<T>();
     T cost = (T(1.0) - ran) + ran * S.cos_theta_max;
     T sint = sqrt_f<FILT, T>(T(1.0) - cost * cost, true, rare);
-    r.dir = {sint * cosp, sint * sinp, cost};
+    // every emitter ends with the same six stores in the same order (pos, then dir): when the
+    // optimiser merges the emitters' tails it then merges VALUES, not the addresses of r's fields
     r.pos = {T(0.0), T(0.0), T(0.0)};
+    r.dir = {sint * cosp, sint * sinp, cost};
 }
 
 // ring, src/sourceMod.f90:250-300
@@ -787,23 +901,24 @@ __device__ inline void emit_ring(const Sys &S, RayT<T> &r, D &draws, bool &rare)
     T rr = S.ring_r1 + draws.template next_as<T>() * (S.ring_r2 - S.ring_r1);     // ranu(r1, r2)
     T theta = draws.template next_as<T>() * S.twopi;
     T st, ct;
-    sincos_t<T>(theta, &st, &ct);
+    { const SinCosT<T> sc_ = sincos_v<T>(theta); st = sc_.s; ct = sc_.c; }
     T sq = sqrt_f<FILT, T>(rr, true, rare);
     T posx = sq * ct;
     T posy = sq * st;
     T Ra = S.ring_bottle_ra;
     T q = S.ring_ellipse ? posy * Ra / S.ring_bottle_rb : posy;            // :277 vs :279
     T posz = S.ring_bottle_z + sqrt_f<FILT, T>(Ra * Ra - q * q, true, rare);
-    r.pos = {posx, posy, posz};
     rr = T(0.) + draws.template next_as<T>() * (S.ring_lens_r2 - T(0.));           // ranu(0., (radius+10e-3)**2)
     theta = draws.template next_as<T>() * S.twopi;
-    sincos_t<T>(theta, &st, &ct);
+    { const SinCosT<T> sc_ = sincos_v<T>(theta); st = sc_.s; ct = sc_.c; }
     sq = sqrt_f<FILT, T>(rr, true, rare);
-    T ex = sq * ct - r.pos.x;
-    T ey = sq * st - r.pos.y;
-    T ez = S.ring_lens_z - r.pos.z;
+    T ex = sq * ct - posx;
+    T ey = sq * st - posy;
+    T ez = S.ring_lens_z - posz;
     T dist = sqrt_f<FILT, T>(ex * ex + ey * ey + ez * ez, true, rare);
-    r.dir = vnormalise_f<FILT, T>(div3_f<FILT, T>(VecT<T>{ex, ey, ez}, dist, true, rare), true, rare);
+    // dir = vector(nxp, nyp, nzp); dir = dir%magnitude() (:292-298): the second normalisation acts on a unit vector
+    r.pos = {posx, posy, posz};
+    r.dir = vnormalise_est<FILT, T>(div3_f<FILT, T>(VecT<T>{ex, ey, ez}, dist, true, rare), T(1.), T(0.5), T(0.25), T(0x1p-32), true, rare);
 }
 
 // create_spot, src/sourceMod.f90:122-159: deterministic fan, no draws; n = 1-based loop index
@@ -814,11 +929,11 @@ __device__ inline void emit_spot(const Sys &S, RayT<T> &r, uint64_t ray)
     T phi = S.spot_dphi * (T)(n % 10);
     T theta = S.spot_dtheta * (T)(n / 10);
     T sinp, cosp, sint_unused, cost;
-    sincos_t<T>(phi, &sinp, &cosp);
-    sincos_t<T>(theta, &sint_unused, &cost);
+    { const SinCosT<T> sc_ = sincos_v<T>(phi); sinp = sc_.s; cosp = sc_.c; }
+    { const SinCosT<T> sc_ = sincos_v<T>(theta); sint_unused = sc_.s; cost = sc_.c; }
     T sint = ORT_SQRT(T(1.) - cost * cost);
-    r.dir = {sint * cosp, sint * sinp, cost};
     r.pos = {T(0.), T(0.), T(0.)};
+    r.dir = {sint * cosp, sint * sinp, cost};
 }
 
 // point_on_bottle, src/sourceMod.f90:50-89 (the "crs" source of phase 1): cone direction as
@@ -829,7 +944,7 @@ __device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws)
 {
     T phi = S.twopi * draws.template next_as<T>();
     T sinp, cosp;
-    sincos_t<T>(phi, &sinp, &cosp);
+    { const SinCosT<T> sc_ = sincos_v<T>(phi); sinp = sc_.s; cosp = sc_.c; }
     T ran = draws.template next_as<T>();
     T cost = (T(1.0) - ran) + ran * S.cos_theta_max;
     T sint = ORT_SQRT(T(1.0) - cost * cost);
@@ -884,14 +999,14 @@ __device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r
     T x = (a + draws.template next_as<T>() * (b - a)) - T(2500e-6);
     a = ((T)j - T(1.)) * dx; b = (T)j * dx;
     T y = (a + draws.template next_as<T>() * (b - a)) - T(2500e-6);
-    r.pos = {x, y, T(0.)};
     T rr = T(0.) + draws.template next_as<T>() * (S.img_lens_r2 - T(0.));
     T theta = draws.template next_as<T>() * S.twopi;
     T st, ct;
-    sincos_t<T>(theta, &st, &ct);
+    { const SinCosT<T> sc_ = sincos_v<T>(theta); st = sc_.s; ct = sc_.c; }
     T sq = ORT_SQRT(rr);
-    T ex = sq * ct - r.pos.x, ey = sq * st - r.pos.y, ez = S.img_lens_z - r.pos.z;
+    T ex = sq * ct - x, ey = sq * st - y, ez = S.img_lens_z - T(0.);
     T dist = ORT_SQRT(ex * ex + ey * ey + ez * ez);
+    r.pos = {x, y, T(0.)};
     r.dir = vnormalise(div3(VecT<T>{ex, ey, ez}, dist));
     return have;
 }
@@ -1012,7 +1127,9 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         bool out = false;
         if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, ax.ap2, ax.ap_tol, live && hit, rare);
         // normal = centre - pos, with orig%x = centre%x for the bottle (lens.f90:288-290)
-        N = vnormalise_f<FILT, T>(VecT<T>{cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z}, live && hit, rare, cyl);
+        const VecT<T> Nraw = {cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z};
+        if (kind == ORT_SURF_ELLIPSE) N = vnormalise_f<FILT, T>(Nraw, live && hit, rare, cyl);
+        else N = vnormalise_est<FILT, T>(Nraw, T(s.radius), ax.rh, ax.rk, ax.r2_tol, live && hit, rare, cyl);   // |N| = radius
         ended = !hit ? ((flags & ORT_F_MISS_IS_HELP3) ? ORT_ST_HELP3 : lost) : (out ? lost : -1);
         ended = walk_end >= 0 ? walk_end : ended;
         proceed = live && hit && !out;

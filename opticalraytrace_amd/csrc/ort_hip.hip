@@ -48,7 +48,15 @@ constexpr int kBlock = 256;
 #define ORT_MIN_WAVES 1
 #endif
 constexpr int kTimingRing = 64;         // launches kept by ort_kernel_times
-constexpr int kReplicas = 8;            // image replicas, one per XCD-sized group of workgroups
+constexpr int kReplicas = 8;            // image replicas, one per XCD (a power of two: xcc_id masks with it)
+// A replica stores one layer in 2^18 slots; bin i lives in slot (i * kSlotMul) mod 2^18 (a bijection:
+// the multiplier is odd), so neighbouring bins — the focal blob — land in unrelated 64-byte lines.
+constexpr int kSlotBits = 18;
+constexpr uint32_t kSlots = 1u << kSlotBits;
+constexpr uint32_t kSlotMul = 0x379B1u, kSlotMulInv = 0x32F51u;
+static_assert(((kSlotMul * kSlotMulInv) & (kSlots - 1)) == 1u, "kSlotMulInv must invert kSlotMul modulo 2^18");
+static_assert(ORT_IMAGE_N * ORT_IMAGE_N <= (int)kSlots, "a layer must fit the slot table");
+constexpr size_t kReplicaInts = 2 * (size_t)kSlots;   // both layers of one replica
 constexpr int kMaxBlocks = 256 * 12;    // 256 CUs x 12 workgroups = 3 rounds at 4 resident per CU: the static ranges'
                                         // cost spread (~10 %) then idles the chip for 1/3 less than with 2 rounds
 constexpr uint64_t kChunkRays = 1ull << 25;   // rays per launch of the queued kernel (bounds the re-run list: 4 B per ray)
@@ -59,8 +67,10 @@ enum { MODE_FUSED = 0, MODE_RESIDENT = 1, MODE_DEBUG = 2 };
 struct TraceArgs {
     const ort_system *sys;       // device copy (DevSystem.sys)
     const SurfAuxT<double> *aux; // DevSystem.aux[phase - 1]: read by the program kernels through scalar loads
+    const SystemT<float> *sysf;  // the same system and constants in single precision (fp32 path, program kernels)
+    const SurfAuxT<float> *auxf;
     int32_t *image;              // [2][401][401]
-    int32_t *replicas;           // [kReplicas][2][401][401] or null: see fold_kernel
+    int32_t *replicas;           // [kReplicas][2][kSlots] or null: see bin_hit, fold_kernel
     unsigned long long *counters;
     uint64_t first_ray, n_rays, rng_base;
     int phase, draw_base;
@@ -93,34 +103,44 @@ __device__ inline void stage_system(ort_system &dst, const ort_system *src)
     __syncthreads();
 }
 
-// fp32 study path: the same system, converted once per workgroup while staging
+// fp32 path: the same system in single precision (each value rounded to nearest once)
+__host__ __device__ inline void convert_surface(SurfaceT<float> &b, const ort_surface &a)
+{
+    b.cx = (float)a.cx; b.cy = (float)a.cy; b.cz = (float)a.cz; b.radius = (float)a.radius;
+    b.radius_b = (float)a.radius_b; b.n1 = (float)a.n1; b.n2 = (float)a.n2; b.eta = (float)a.eta;
+    b.aperture = (float)a.aperture; b.kind = a.kind; b.flags = a.flags;
+    b.mua = (float)a.mua; b.mus = (float)a.mus; b.hgg = (float)a.hgg; b.scat_radius = (float)a.scat_radius;
+}
+__host__ __device__ inline void convert_globals(SystemT<float> &dst, const ort_system &src)
+{
+    dst.n_surfaces[0] = src.n_surfaces[0]; dst.n_surfaces[1] = src.n_surfaces[1];
+    dst.split[0] = src.split[0]; dst.split[1] = src.split[1];
+    dst.ring_ellipse = src.ring_ellipse; dst.pad = 0;
+    dst.cos_theta_max = (float)src.cos_theta_max;
+    dst.ring_r1 = (float)src.ring_r1; dst.ring_r2 = (float)src.ring_r2;
+    dst.ring_lens_r2 = (float)src.ring_lens_r2; dst.ring_lens_z = (float)src.ring_lens_z;
+    dst.ring_bottle_ra = (float)src.ring_bottle_ra; dst.ring_bottle_rb = (float)src.ring_bottle_rb;
+    dst.ring_bottle_z = (float)src.ring_bottle_z;
+    dst.bin_width = (float)src.bin_width; dst.inv_bin_width = (float)src.inv_bin_width;
+    dst.na_cos_min = (float)src.na_cos_min; dst.twopi = (float)src.twopi;
+    dst.spot_dphi = (float)src.spot_dphi; dst.spot_dtheta = (float)src.spot_dtheta;
+    dst.crs_sigma = (float)src.crs_sigma; dst.crs_radius = (float)src.crs_radius;
+    dst.crs_cy = (float)src.crs_cy; dst.crs_cz = (float)src.crs_cz;
+    dst.img_lens_r2 = (float)src.img_lens_r2; dst.img_lens_z = (float)src.img_lens_z;
+    dst.emitter[0] = src.emitter[0]; dst.emitter[1] = src.emitter[1];
+}
+inline void convert_system(SystemT<float> &dst, const ort_system &src)      // host
+{
+    for (int i = 0; i < 2 * ORT_MAX_SURFACES; ++i)
+        convert_surface(dst.surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES], src.surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES]);
+    convert_globals(dst, src);
+}
+// ... and converted once per workgroup while staging (generic kernels)
 __device__ inline void stage_system(SystemT<float> &dst, const ort_system *src)
 {
-    for (int i = threadIdx.x; i < 2 * ORT_MAX_SURFACES; i += blockDim.x) {
-        const ort_surface &a = src->surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES];
-        SurfaceT<float> &b = dst.surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES];
-        b.cx = (float)a.cx; b.cy = (float)a.cy; b.cz = (float)a.cz; b.radius = (float)a.radius;
-        b.radius_b = (float)a.radius_b; b.n1 = (float)a.n1; b.n2 = (float)a.n2; b.eta = (float)a.eta;
-        b.aperture = (float)a.aperture; b.kind = a.kind; b.flags = a.flags;
-        b.mua = (float)a.mua; b.mus = (float)a.mus; b.hgg = (float)a.hgg; b.scat_radius = (float)a.scat_radius;
-    }
-    if (threadIdx.x == 0) {
-        dst.n_surfaces[0] = src->n_surfaces[0]; dst.n_surfaces[1] = src->n_surfaces[1];
-        dst.split[0] = src->split[0]; dst.split[1] = src->split[1];
-        dst.ring_ellipse = src->ring_ellipse; dst.pad = 0;
-        dst.cos_theta_max = (float)src->cos_theta_max;
-        dst.ring_r1 = (float)src->ring_r1; dst.ring_r2 = (float)src->ring_r2;
-        dst.ring_lens_r2 = (float)src->ring_lens_r2; dst.ring_lens_z = (float)src->ring_lens_z;
-        dst.ring_bottle_ra = (float)src->ring_bottle_ra; dst.ring_bottle_rb = (float)src->ring_bottle_rb;
-        dst.ring_bottle_z = (float)src->ring_bottle_z;
-        dst.bin_width = (float)src->bin_width; dst.inv_bin_width = (float)src->inv_bin_width;
-        dst.na_cos_min = (float)src->na_cos_min; dst.twopi = (float)src->twopi;
-        dst.spot_dphi = (float)src->spot_dphi; dst.spot_dtheta = (float)src->spot_dtheta;
-        dst.crs_sigma = (float)src->crs_sigma; dst.crs_radius = (float)src->crs_radius;
-        dst.crs_cy = (float)src->crs_cy; dst.crs_cz = (float)src->crs_cz;
-        dst.img_lens_r2 = (float)src->img_lens_r2; dst.img_lens_z = (float)src->img_lens_z;
-        dst.emitter[0] = src->emitter[0]; dst.emitter[1] = src->emitter[1];
-    }
+    for (int i = threadIdx.x; i < 2 * ORT_MAX_SURFACES; i += blockDim.x)
+        convert_surface(dst.surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES], src->surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES]);
+    if (threadIdx.x == 0) convert_globals(dst, *src);
     __syncthreads();
 }
 
@@ -132,32 +152,52 @@ __device__ inline void stage_aux(SurfAuxT<T> *aux, const Surf *surf, int ns)
     __syncthreads();
 }
 
-// Where this workgroup bins its hits.  The point-source image is a blob of a few thousand
-// 64-byte lines; with one image every wave of the chip queues its atomics on those same
-// lines (measured: +0.19 ms on a 0.75 ms launch at 4 waves/SIMD).  So the hits go to one of
-// kReplicas private copies — workgroups b and b+8 share one, which under the observed
-// round-robin placement is one XCD — and fold_kernel adds the copies into the image
-// afterwards.  Integer adds commute: the image is bit-identical either way.
+// Where this workgroup bins its hits.  With one image, every wave of the chip queues its atomics
+// on the same few thousand 64-byte lines of the focal blob (measured in round 1: +0.19 ms on a
+// 0.75 ms launch).  So the hits go to one of kReplicas private copies, one per XCD, read from the
+// hardware (HW_REG_XCC_ID; blockIdx % 8 only says which blocks share an XCD while the placement is
+// round-robin, which it is not while the tail of a previous kernel occupies some XCDs).
+// A hit is a no-return atomic that the L2 forwards to the memory side (the 8 L2s are not coherent
+// with each other: TCC_EA0_ATOMIC counts one request, and one 32-byte DRAM write, per hit).  The
+// blob is ~17 000 bins, half of the hits on 1000 of them: stored row by row that is ~100 very hot
+// lines per replica, and how those happen to fall on the memory channels decided the launch time
+// — the same kernel took 0.40 or 0.48 ms (fast fp64: 0.34 - 0.55 ms) depending on where the
+// context's buffers lay (TCC_EA0_WRREQ_STALL x 3 in the slow placements).  So within a replica the
+// bins are scattered over 2^18 slots by a multiplicative hash: every hot bin gets a line of its own
+// and the load spreads over all channels, whatever the placement.  fold_kernel undoes the hash.
+// Integer adds commute: the image is bit-identical either way.
+__device__ inline int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & (kReplicas - 1); }   // hwreg(HW_REG_XCC_ID, 0, 4)
+
+__device__ inline void bin_hit(int32_t *layer, int xp, int yp, bool replicated)
+{
+    const uint32_t bin = (uint32_t)((xp + 200) + ORT_IMAGE_N * (yp + 200));         // imageMod.f90:55-56
+    atomicAdd(&layer[replicated ? (bin * kSlotMul) & (kSlots - 1) : bin], 1);
+}
+
 __device__ inline int32_t *hist_layer(const TraceArgs &a)
 {
-    int32_t *base = a.replicas ? a.replicas + (size_t)(blockIdx.x % kReplicas) * ORT_IMAGE_BINS : a.image;
-    return base + (size_t)(a.phase - 1) * ORT_IMAGE_N * ORT_IMAGE_N;
+    if (a.replicas) return a.replicas + (size_t)xcc_id() * kReplicaInts + (size_t)(a.phase - 1) * kSlots;
+    return a.image + (size_t)(a.phase - 1) * ORT_IMAGE_N * ORT_IMAGE_N;
 }
 
 // image[layer] += sum of the replicas' layer; replicas are left zero for the next launch.
+// Thread j sums slot j of the 8 replicas (coalesced) and adds it to the bin the slot belongs to.
 __global__ __launch_bounds__(256) void fold_kernel(int32_t *image, int32_t *replicas, int phase)
 {
     const int nb = ORT_IMAGE_N * ORT_IMAGE_N;
-    const size_t off = (size_t)(phase - 1) * nb;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+    int32_t *img = image + (size_t)(phase - 1) * nb;
+    int32_t *rep = replicas + (size_t)(phase - 1) * kSlots;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < kSlots; j += gridDim.x * blockDim.x) {
+        const uint32_t bin = (j * kSlotMulInv) & (kSlots - 1);
+        if (bin >= (uint32_t)nb) continue;        // 39 % of the slots belong to no bin and are never written
         int s = 0;
 #pragma unroll
         for (int r = 0; r < kReplicas; ++r) {
-            int32_t *p = replicas + (size_t)r * ORT_IMAGE_BINS + off + i;
+            int32_t *p = rep + (size_t)r * kReplicaInts + j;
             int v = *p;
             if (v) { s += v; *p = 0; }
         }
-        if (s) image[off + i] += s;
+        if (s) img[bin] += s;
     }
 }
 
@@ -188,6 +228,8 @@ __device__ inline void walk_pass(const Sys &S, const Surf *surf, const SurfAuxT<
 struct DevSystem {
     ort_system sys;
     SurfAuxT<double> aux[2][ORT_MAX_SURFACES];
+    SystemT<float> sysf;                         // fp32 path: converted once on the host (round to nearest,
+    SurfAuxT<float> auxf[2][ORT_MAX_SURFACES];   // as v_cvt_f32_f64 would), constants formed in fp32
 };
 
 // The program kernels know each step's surface index at compile time, so they read its record
@@ -195,12 +237,21 @@ struct DevSystem {
 // memory = scalar loads (s_load_dwordx*) into SGPRs.  The values then feed the vector
 // instructions as scalar operands instead of occupying VGPRs (an LDS read lands in VGPRs), which
 // is what lets the unrolled kernel fit 128 VGPRs without spilling.
-typedef const __attribute__((address_space(4))) ort_surface *const_surf_t;
-typedef const __attribute__((address_space(4))) SurfAuxT<double> *const_aux_t;
+template <class T> struct ConstPtrs {       // fp64 and fast fp64 read the fp64 records
+    typedef const __attribute__((address_space(4))) ort_surface *surf_t;
+    typedef const __attribute__((address_space(4))) SurfAuxT<double> *aux_t;
+    typedef ort_surface Surf;
+};
+template <> struct ConstPtrs<float> {
+    typedef const __attribute__((address_space(4))) SurfaceT<float> *surf_t;
+    typedef const __attribute__((address_space(4))) SurfAuxT<float> *aux_t;
+    typedef SurfaceT<float> Surf;
+};
 
-__device__ inline ort_surface load_surface(const_surf_t p)
+template <class T>
+__device__ inline typename ConstPtrs<T>::Surf load_surface(typename ConstPtrs<T>::surf_t p)
 {
-    ort_surface s;
+    typename ConstPtrs<T>::Surf s;
     s.cx = p->cx; s.cy = p->cy; s.cz = p->cz; s.radius = p->radius; s.radius_b = p->radius_b;
     s.n1 = p->n1; s.n2 = p->n2; s.eta = p->eta; s.aperture = p->aperture;
     s.mua = p->mua; s.mus = p->mus; s.hgg = p->hgg; s.scat_radius = p->scat_radius;
@@ -209,11 +260,12 @@ __device__ inline ort_surface load_surface(const_surf_t p)
 }
 
 template <class T>
-__device__ inline SurfAuxT<T> load_aux(const_aux_t p)
+__device__ inline SurfAuxT<T> load_aux(typename ConstPtrs<T>::aux_t p)
 {
     SurfAuxT<T> a;
     a.r2 = T(p->r2); a.ap2 = T(p->ap2); a.ap_tol = T(p->ap_tol); a.eta2 = T(p->eta2);
     a.ell_sa = T(p->ell_sa); a.ell_sb = T(p->ell_sb);
+    a.rh = T(p->rh); a.rk = T(p->rk); a.r2_tol = T(p->r2_tol);
     return a;
 }
 
@@ -293,12 +345,12 @@ template <> struct Prog<PROG_POINT_ELLIPSE> {
 
 // steps [K, K1) of program P, each entered only while some lane of the wave is alive
 template <bool FILT, class T, bool KEEP, int P, int K, int K1, class Sys, class D>
-__device__ inline void walk_fixed(const Sys &S, const_surf_t surf, const_aux_t aux, RayT<T> &r, D &draws,
+__device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t surf, typename ConstPtrs<T>::aux_t aux, RayT<T> &r, D &draws,
                                   int &nis, int &st, int &xp, int &yp, bool &rare)
 {
     if constexpr (K < K1) {
         if (wave_any(st < 0)) {
-            const ort_surface s = load_surface(surf + K);
+            const typename ConstPtrs<T>::Surf s = load_surface<T>(surf + K);
             const SurfAuxT<T> ax = load_aux<T>(aux + K);
 #ifdef ORT_ISA_MARKERS      // tools/isa_budget.py: comment lines that delimit the steps in the listing
             asm volatile("; ORT_STEP_BEGIN %0" ::"n"(K));
@@ -455,7 +507,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             isect += (unsigned)nis;
             if (st == ORT_ST_BINNED) {
                 binned++;
-                atomicAdd(&layer[(xp + 200) + ORT_IMAGE_N * (yp + 200)], 1);   // imageMod.f90:55-56
+                bin_hit(layer, xp, yp, a.replicas != nullptr);
             } else if (st >= ORT_ST_LOST_BOTTLE) {
                 lost++;                                                       // optics_system.f90:32,42; main.f90:151
                 if (st == ORT_ST_HELP3) help3++;
@@ -502,8 +554,10 @@ __device__ inline int lane_prefix(unsigned long long mask)
 template <int MODE, bool FILT, bool ANYSRC, class T, int PROG = PROG_GENERIC, bool SCAT = ANYSRC>
 __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) void trace_queue_kernel(TraceArgs a)
 {
-    static_assert(PROG == PROG_GENERIC || (FILT && !ANYSRC && !SCAT), "programs exist for the lean filtered kernel only");
-    __shared__ ort_system S;
+    static_assert(PROG == PROG_GENERIC || (!ANYSRC && !SCAT && (FILT || std::is_same<T, float>::value)),
+                  "programs exist for the lean kernels only: filtered (fp64, fast fp64) or fp32");
+    static_assert(!FILT || !std::is_same<T, float>::value, "the fp32 path evaluates every predicate literally");
+    __shared__ typename SysTypes<T>::Sys S;
     __shared__ double Q[kWavesPerBlock][kQueueFields][kQueueCap];
     // intersections evaluated before the queue point: `split` for every survivor unless a surface
     // scatters (extended instantiation), so only that one carries the count through the queue
@@ -529,9 +583,17 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
         if (split <= 0 || split >= ns) split = ns;      // no queue point: one segment
     }
     const int ph = phase - 1;
-    const ort_surface *surf = S.surfaces[ph];
-    const const_surf_t csurf = (const_surf_t)a.sys->surfaces[ph];     // program kernels: scalar loads
-    const const_aux_t caux = (const_aux_t)a.aux;
+    const typename SysTypes<T>::Surf *surf = S.surfaces[ph];
+    // program kernels: scalar loads from the device copy in the kernel's own precision
+    typename ConstPtrs<T>::surf_t csurf;
+    typename ConstPtrs<T>::aux_t caux;
+    if constexpr (std::is_same<T, float>::value) {
+        csurf = (typename ConstPtrs<T>::surf_t)a.sysf->surfaces[ph];
+        caux = (typename ConstPtrs<T>::aux_t)a.auxf;
+    } else {
+        csurf = (typename ConstPtrs<T>::surf_t)a.sys->surfaces[ph];
+        caux = (typename ConstPtrs<T>::aux_t)a.aux;
+    }
     int32_t *layer = hist_layer(a);
     const uint64_t n = a.n_rays;
     const uint64_t ns_in = a.in_stride;
@@ -550,7 +612,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
         if (st == ORT_ST_BINNED) {
             binned++;
 #ifndef ORT_ABL_NOATOMIC
-            atomicAdd(&layer[(xp + 200) + ORT_IMAGE_N * (yp + 200)], 1);      // imageMod.f90:55-56
+            bin_hit(layer, xp, yp, a.replicas != nullptr);
 #endif
         } else if (st >= ORT_ST_LOST_BOTTLE) {
             lost++;                                                          // optics_system.f90:32,42; main.f90:151
@@ -710,7 +772,7 @@ struct ort_ctx {
     bool own_stream;
     DevSystem *d_sys;
     int32_t *d_image, *own_image;
-    int32_t *d_replicas;         // kReplicas zeroed images (scratch between trace and fold)
+    int32_t *d_replicas;         // kReplicas x 2 layers x kSlots, zero between launches (scratch between trace and fold)
     uint32_t *d_redo_list;       // re-run list of the queued filtered kernel, redo_cap entries
     size_t redo_cap;
     unsigned int *d_redo_ctl;    // [2]: entries, re-run workgroups done; zero between launches
@@ -767,6 +829,9 @@ static int upload_system(ort_ctx *c, const ort_system *sys)
     h.sys = *sys;
     for (int p = 0; p < 2; ++p)
         for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.aux[p][k] = make_aux<double>(sys->surfaces[p][k]);
+    convert_system(h.sysf, *sys);
+    for (int p = 0; p < 2; ++p)
+        for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.auxf[p][k] = make_aux<float>(h.sysf.surfaces[p][k]);
     HIP_TRY(hipMemcpyAsync(c->d_sys, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ORT_OK;
@@ -774,21 +839,21 @@ static int upload_system(ort_ctx *c, const ort_system *sys)
 
 // The lean queued kernel (default emitters, no scattering, filtered predicates): specialised for
 // the surface program the staged system matches, generic otherwise.
-template <class T>
+template <class T, bool FILT = true>
 static void launch_lean(ort_ctx *c, int mode, const TraceArgs &a, int grid)
 {
 #define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
     const int prog = c->prog[a.phase - 1];
 #define ORT_CASE(P)                                                                                        \
     case P:                                                                                                \
-        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, T, P>));           \
-        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, T, P>));                           \
+        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, FILT, false, T, P>));           \
+        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, FILT, false, T, P>));                           \
         break;
     switch (prog) {
         ORT_PROGRAMS(ORT_CASE)
     default:
-        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, T>));
-        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, false, T>));
+        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, FILT, false, T>));
+        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, FILT, false, T>));
     }
 #undef ORT_CASE
 #undef ORT_LAUNCH
@@ -821,8 +886,8 @@ static int create_on_device(ort_ctx *c, const ort_system *sys)
     HIP_TRY(hipMalloc(&c->d_sys, sizeof(DevSystem)));
     HIP_TRY(hipMalloc(&c->own_image, ORT_IMAGE_BINS * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->own_counters, ORT_NUM_COUNTERS * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(&c->d_replicas, (size_t)kReplicas * ORT_IMAGE_BINS * sizeof(int32_t)));
-    HIP_TRY(hipMemsetAsync(c->d_replicas, 0, (size_t)kReplicas * ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMalloc(&c->d_replicas, kReplicas * kReplicaInts * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(c->d_replicas, 0, kReplicas * kReplicaInts * sizeof(int32_t), c->stream));
     HIP_TRY(hipMalloc(&c->d_redo_ctl, 2 * sizeof(unsigned int)));
     HIP_TRY(hipMemsetAsync(c->d_redo_ctl, 0, 2 * sizeof(unsigned int), c->stream));
     c->d_image = c->own_image;
@@ -944,10 +1009,12 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
             launch_lean<fastd>(c, mode, a, grid);
         }
     } else if (c->precision == 1) {
-        // fp32 study path (BASELINE configs[4]): lockstep kernel, literal predicates
-        if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, false, float, true>));
-        else if (mode == MODE_RESIDENT) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, float, true>));
-        else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, float, true>));
+        // fp32 path (BASELINE configs[4]): literal predicates; queued program kernels for the default
+        // emitters in clear media, the lockstep kernel for everything else
+        if (mode == MODE_DEBUG) ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, float, true>));
+        else if (queued && !anysrc) launch_lean<float, false>(c, mode, a, grid);
+        else if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, false, float, true>));
+        else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, float, true>));
     } else if (mode == MODE_DEBUG) {
         if (filt) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, double, true>));
         else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, double, true>));
@@ -992,14 +1059,15 @@ static int reserve_list(ort_ctx *c, uint64_t n_rays)
 static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
 {
     a0.sys = &c->d_sys->sys; a0.aux = c->d_sys->aux[a0.phase - 1];
+    a0.sysf = &c->d_sys->sysf; a0.auxf = c->d_sys->auxf[a0.phase - 1];
     a0.image = c->d_image; a0.counters = c->d_counters;
     const bool use_rep = (c->variant & 4) == 0 && mode != MODE_DEBUG;
     a0.replicas = use_rep ? c->d_replicas : nullptr;
     a0.img_cdf = c->d_img_cdf;
     a0.in_stride = a0.n_rays;
     if (a0.n_rays == 0) return ORT_OK;
-    const bool queued = (c->variant & 1) && mode != MODE_DEBUG && c->precision != 1;
-    const bool filt = (c->variant & 2) == 0;
+    const bool queued = (c->variant & 1) && mode != MODE_DEBUG;
+    const bool filt = (c->variant & 2) == 0 && c->precision != 1;      // fp32: literal predicates, nothing is deferred
     const bool anysrc = c->emitter[a0.phase - 1] != (a0.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT) || c->scatter[a0.phase - 1];
     // The queued filtered kernel defers the rays that sit on a decision boundary to a list, which
     // the literal lockstep kernel traces right after it.  Every ray of a launch could be on it

@@ -90,8 +90,77 @@ __global__ void approx_err(uint64_t n, double *out)
     out[4 * t + 0] = e_rcp; out[4 * t + 1] = e_rsq; out[4 * t + 2] = e_seed_rcp; out[4 * t + 3] = e_seed_rsq;
 }
 
+// Round-2 forms.  (a) vnormalise_est: vectors of length t0 (1 + x), |x| up to 2^-30 (the guard is
+// 2^-32 on the square: about half of the larger ones must be flagged, none may mismatch), t0 over
+// the tracer's radii (mode 1) or 2^-200 .. 2^200 (mode 2; mode 0: 2^-20 .. 2^20 with x of a few
+// ulps).  (b) div_plain inside its guard.  (c) solve_and_pick<filtered> against the literal
+// solveQuadratic + root choice wherever it does not flag.
+__global__ void check2(uint64_t n, int mode, unsigned long long *bad)
+{
+    unsigned long long bn = 0, rn = 0, bd = 0, nd = 0, bq = 0, rq = 0, hq = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = mix(8 * i + 5);
+        // (a)
+        const int et = mode == 2 ? (int)(b & 511) % 401 - 200 : (mode == 1 ? (int)(b & 15) - 12 : (int)(b & 63) % 41 - 20);
+        const double t0 = ldexp(1.0 + (double)(mix(8 * i + 6) >> 12) * 0x1p-52, et);
+        double dx = operand(8 * i + 0, 1), dy = operand(8 * i + 1, 1), dz = operand(8 * i + 2, 1);
+        const bool cyl = (b >> 20) & 1;
+        if (cyl) dx = 0.0;
+        const double len = sqrt(dx * dx + dy * dy + dz * dz);
+        const uint64_t bx = mix(8 * i + 7);
+        const double mag = mode == 0 ? ldexp((double)(bx & 255), -52) : ldexp((double)(bx >> 12) * 0x1p-52, -30 - (int)(bx & 31));
+        const double x = (bx & 2048) ? mag : -mag;
+        const double sc = t0 * (1.0 + x) / len;
+        const ort::Vec v = {dx * sc, dy * sc, dz * sc};
+        bool rare = false;
+        const ort::Vec u = ort::vnormalise_est<true, double>(v, t0, 0.5 / t0, (0.5 / t0) / (2.0 * (t0 * t0)), 0x1p-32 * (t0 * t0), true, rare, cyl);
+        const double l2 = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+        if (rare || !(len > 0.0)) rn++;
+        else if (!same(u.x, v.x / l2) || !same(u.y, v.y / l2) || !same(u.z, v.z / l2)) bn++;
+        // (b)
+        const double p = operand(8 * i + 3, mode == 1 ? 1 : 2), q = operand(8 * i + 4, mode == 1 ? 1 : 2);
+        if (fabs(p) > 0x1p-300 && fabs(p) < 0x1p300 && fabs(q) > 0x1p-300 && fabs(q) < 0x1p300) {
+            nd++;
+            if (!same(ort::div_plain(p, q), p / q)) bd++;
+        }
+        // (c) a ray against a sphere: a = d.d, hb = d.L, c = L.L - R^2 with operands of the mode
+        {
+            const int m = mode == 1 ? 1 : mode;
+            const double a = mode == 1 ? 1.0 + ldexp((double)(bx >> 40), -60) - 0x1p-37 : fabs(operand(8 * i + 3, m));
+            const double hb = operand(8 * i + 4, m), c = operand(8 * i + 2, m);
+            double tf, tl;
+            bool hf, hl, rf = false, rl = false;
+            ort::solve_and_pick<true, double>(a, hb, c, true, tf, hf, rf);
+            ort::solve_and_pick<false, double>(a, hb, c, true, tl, hl, rl);
+            if (rf) rq++;
+            else if (hf != hl || (hl && !same(tf, tl))) bq++;
+            else if (hl) hq++;
+        }
+    }
+    atomicAdd(&bad[0], bn); atomicAdd(&bad[1], rn); atomicAdd(&bad[2], bd); atomicAdd(&bad[3], nd);
+    atomicAdd(&bad[4], bq); atomicAdd(&bad[5], rq); atomicAdd(&bad[6], hq);
+}
+
 int main()
 {
+    {
+        unsigned long long *d2, h2[7];
+        if (hipMalloc(&d2, sizeof(h2)) != hipSuccess) { printf("no device\n"); return 2; }
+        for (int mode = 0; mode < 3; ++mode) {
+            (void)hipMemset(d2, 0, sizeof(h2));
+            const uint64_t n = 1ull << 28;
+            check2<<<4096, 256>>>(n, mode, d2);
+            if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
+            (void)hipMemcpy(h2, d2, sizeof(h2), hipMemcpyDeviceToHost);
+            printf("est  %d operands %llu : mismatches normalise_est %llu div_plain %llu quadratic %llu ; flagged normalise_est %llu "
+                   "quadratic %llu ; compared div_plain %llu quadratic hits %llu\n",
+                   mode, (unsigned long long)n, h2[0], h2[2], h2[4], h2[1], h2[5], h2[3], h2[6]);
+            if (h2[0] || h2[2] || h2[4]) return 1;
+            // the checks must not be vacuous: most operand sets are compared, not flagged
+            if (h2[1] > n / 2 || h2[3] < n / 4 || (mode == 1 && h2[6] < n / 8)) { printf("vacuous\n"); return 1; }
+        }
+        (void)hipFree(d2);
+    }
     unsigned long long *d_bad, h[6];
     if (hipMalloc(&d_bad, sizeof(h)) != hipSuccess) { printf("no device\n"); return 2; }
     int rc = 0;

@@ -17,7 +17,9 @@ def test_expanded_sqrt_and_division_are_bit_identical():
         r = subprocess.run(["make", "-C", os.path.join(ROOT, "opticalraytrace_amd", "csrc"), "check"],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
-    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("mode")]
     assert len(lines) == 3 and all("mismatches sqrt 0 div3 0 normalise 0" in ln for ln in lines), out.stdout
+    est = [ln for ln in out.stdout.splitlines() if ln.startswith("est ")]
+    assert len(est) == 3 and all("mismatches normalise_est 0 div_plain 0 quadratic 0" in ln for ln in est), out.stdout

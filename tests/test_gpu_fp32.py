@@ -83,3 +83,66 @@ def test_fp32_image_deviation(ctx):
     assert abs(res["lost_fp32"] - res["lost_fp64"]) / n < 1e-4
     assert res["l1_fraction"] < 2e-3
     assert int(c32[5]) == int(i32[1].sum())
+
+
+@pytest.mark.parametrize("name", ["large", "large_iris_before", "small_iris_after", "ellipse",
+                                  "small_f60_nobottle", "large_crs"])
+def test_fp32_queued_kernel_equals_fp32_lockstep_kernel(hip_library, name):
+    """fp32 runs on the queued program kernels (variant bit 0, default) exactly as fp64 does; per-ray
+    arithmetic and draw order are those of the fp32 lockstep kernel, so images and counters of the
+    two are identical — for every surface program and for a system that takes the generic walk."""
+    from opticalraytrace_amd.capi import Context
+    _, osys = make_system(name)
+    n = 300_000
+    with Context(osys) as c:
+        c.set_precision(1)
+        out = []
+        for variant in (1, 0):
+            c.set_kernel_variant(variant)
+            c.reset()
+            c.trace(1, 0, n, SEED)
+            c.trace(2, 5, n, SEED)
+            out.append(c.read())
+    (iq, cq), (il, cl) = out
+    assert int(cq[2]) > n and int(cq[3]) > n
+    assert np.array_equal(iq, il) and np.array_equal(cq, cl)
+
+
+def test_config4_fp32_full_size(ctx):
+    """BASELINE configs[4] at its stated size on one GPU: ring + point layers through the full stack,
+    1e9 rays per layer, fp32 — against the fp64 run of the same rays: totals, per-bin deltas, and
+    size-independent properties.  (Its 8-GPU leg is the same shards summed by RCCL:
+    tests/test_gpu_distributed.py, tests/test_distributed_gloo.py.)"""
+    osys, c = ctx
+    n, parts = 1_000_000_000, 4
+    runs = []
+    for prec in (0, 1):
+        c.set_precision(prec)
+        c.reset()
+        for phase in (1, 2):
+            for k in range(parts):
+                c.trace(phase, k * (n // parts), n // parts, SEED)
+        runs.append(c.read())
+    c.set_precision(0)
+    (i64, c64), (i32, c32) = runs
+    res = {"rays_per_layer": n}
+    for layer, name in ((0, "ring"), (1, "point")):
+        a, b = i64[layer].astype(np.int64), i32[layer].astype(np.int64)
+        assert int(b.sum()) == int(c32[4 + layer])                        # image == counter, fp32 too
+        d = np.abs(a - b)
+        # Poisson scale of a bin: a delta is "visible" when it exceeds the bin's own shot noise
+        sig = np.sqrt(np.maximum(a, 1))
+        res[name] = dict(binned_fp64=int(a.sum()), binned_fp32=int(b.sum()), l1_bin_delta=int(d.sum()),
+                         l1_fraction=float(d.sum() / max(a.sum(), 1)), max_abs_bin_delta=int(d.max()),
+                         max_delta_over_shot_noise=float((d / sig).max()),
+                         bins_beyond_3_sigma=int((d > 3 * sig).sum()),
+                         lost_fp64=int(c64[layer]), lost_fp32=int(c32[layer]),
+                         isect_fp64=int(c64[2 + layer]), isect_fp32=int(c32[2 + layer]))
+        r = res[name]
+        assert abs(r["binned_fp32"] - r["binned_fp64"]) / max(r["binned_fp64"], 1) < 5e-4
+        assert abs(r["lost_fp32"] - r["lost_fp64"]) / n < 1e-4
+        assert abs(r["isect_fp32"] - r["isect_fp64"]) / r["isect_fp64"] < 1e-4
+    assert res["point"]["l1_fraction"] < 2e-3                 # rays hop to a neighbouring bin: 2 counts per hop
+    assert abs(int(c32[3]) / n - 6.315) < 0.002 and abs(int(c32[2]) / n - 1.553) < 0.002
+    assert int(i32.max()) < 2 ** 31 - 1
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "fp32_config4_1e9.json"), "w"), indent=1)

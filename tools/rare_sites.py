@@ -15,6 +15,8 @@ SITES = ["sqrt range", "div3 shared", "quadratic", "fresnel", "aperture", "NA", 
 n = 10_000_000
 ctx = capi.Context(OpticalSystem.from_settings(Settings(nphotons=n, bottle_file="clearBottle-large.params")))
 lib = capi.load_library()
+if len(sys.argv) > 1:
+    ctx.set_precision(int(sys.argv[1]))
 buf = (ctypes.c_ulonglong * 16)()
 prev = [0] * 16
 for phase in (2, 1):
