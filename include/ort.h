@@ -166,7 +166,7 @@ int ort_reset(ort_ctx *ctx);                       /* image = 0, counters = 0 (s
 /* The hot loop.  Replaces one OpenMP `do i = 1, nphotons` loop of
  * src/main.f90:90-109 (phase 1, ring) or :127-162 (phase 2, point) over the
  * global ray indices [first_ray, first_ray + n_rays): emit, trace, bin into the
- * context's device image and counters.  Draws are ORT-RNG-v1 keyed on
+ * context's device image and counters.  Draws are ORT-RNG-v2 keyed on
  * (seed, phase, global ray index, draw index), so any partition of the index
  * range over calls, contexts or GPUs accumulates the same image.
  * Asynchronous on the context's stream. */

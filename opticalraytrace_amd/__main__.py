@@ -1,0 +1,100 @@
+"""`python -m opticalraytrace_amd <settings>` — the process-level drop-in for `bin/raytrace <settings>`.
+
+The reference is started as `cd bin && ./raytrace <file>` (install.sh:70-72); it reads
+`../res/<file>` (src/setupMod.f90:51-56), the lens / bottle files next to it, and writes under
+`../data/<folder>/` (src/setupMod.f90:124-131, src/main.f90:168-185): three raw float64 images, one
+appended `trans-stats.dat` row, two "transmitted" lines on stdout.  Same contract here, the two
+OpenMP loops running on the MI355X:
+
+    python -m opticalraytrace_amd settings.params            # from bin/: ../res/settings.params -> ../data/
+    python -m opticalraytrace_amd res/test_0.params --data data
+    python -m opticalraytrace_amd test_0.params --res res --data data --device 1
+
+Exit status: 0, or non-zero with a message on stderr where the reference would `error stop`
+(unreadable / truncated input files, an unknown light source, ...) — which is what
+`runner.py:47` (`subprocess.run(..., check=True)`) relies on.  Started under
+`torch.distributed.run` (WORLD_SIZE > 1) every rank traces its shard of the rays, the image is
+summed over RCCL and rank 0 writes the files.  There is no CPU fallback: without a HIP device
+the run fails (exit status 3)."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+from .params import ParamsError, Settings
+
+
+def _locate(settings: str, res: str | None):
+    """(settings path, res dir): a bare name is looked up in --res (default ../res, as the
+    reference does from bin/); an existing path brings its own directory as res."""
+    if res is not None:
+        p = settings if os.path.isabs(settings) or os.path.exists(settings) else os.path.join(res, settings)
+        return p, res
+    if os.path.exists(settings):
+        return settings, os.path.dirname(os.path.abspath(settings))
+    return os.path.join("..", "res", settings), os.path.join("..", "res")
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="python -m opticalraytrace_amd", description=__doc__,
+                                 formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("settings", help="settings file (20 positional lines, src/setupMod.f90:57-133)")
+    ap.add_argument("--res", default=None, help="directory of the settings / .params files (default ../res)")
+    ap.add_argument("--data", default=None, help="output root (default ../data, or data/ next to an explicit --res)")
+    ap.add_argument("--device", type=int, default=None, help="HIP device (default LOCAL_RANK or 0)")
+    ap.add_argument("--quiet", action="store_true")
+    args = ap.parse_args(argv)
+
+    path, res_dir = _locate(args.settings, args.res)
+    data_dir = args.data or (os.path.join("..", "data") if args.res is None and not os.path.exists(args.settings)
+                             else "data")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    device = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    try:
+        settings = Settings.from_file(path)
+        settings.validate()
+        from .system import OpticalSystem
+        system = OpticalSystem.from_settings(settings, res_dir)    # reads the lens / bottle files
+    except (ParamsError, OSError) as e:
+        print(f"raytrace: {e}", file=sys.stderr)
+        return 1
+    try:
+        from .capi import OrtError
+        from .tracer import (RayTracer, append_stats, output_basename, write_images,
+                             write_tracker_files)
+        group = None
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(device)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        tracer = RayTracer(system, device=device, rank=rank, world=world, process_group=group)
+        try:
+            res = tracer.run()
+            folder = os.path.join(data_dir, settings.data_folder)
+            if rank == 0:
+                os.makedirs(folder, exist_ok=True)                  # setupMod.f90:124-131
+                if settings.use_tracker and world == 1:             # main.f90:72-74 (serial only there too)
+                    write_tracker_files(tracer, system, folder)
+        finally:
+            tracer.close()
+        if rank == 0:
+            append_stats(folder, system, res)
+            if not args.quiet:                                      # main.f90:180-181
+                print(f"Ring  transmitted:  {res.ring_transmitted:8.2f}%")
+                print(f"Point transmitted:  {res.point_transmitted:8.2f}%")
+            if settings.make_images and not settings.use_tracker:   # main.f90:183-185
+                write_images(res.image, os.path.join(folder, output_basename(system) + "_image"))
+        if world > 1:
+            dist.destroy_process_group()
+    except (OrtError, RuntimeError) as e:
+        print(f"raytrace: {e}", file=sys.stderr)
+        return 3
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -27,12 +27,16 @@
 namespace ort {
 
 // ----------------------------------------------------------------------------
-// ORT-RNG-v1: counter-based uniforms keyed on (seed, phase, global ray, draw).
+// ORT-RNG-v2: counter-based uniforms keyed on (seed, phase, global ray, draw).
 // Replaces the semantics of ran2() = one U[0,1) per call (src/random_mod.f90:39-46);
 // the reference's own generator is the Fortran runtime's and is not reproducible
 // across compilers or thread counts (SURVEY §7 "hard parts").
-//   base = mix64(seed ^ (GOLDEN*phase)); z = base + GOLDEN*((ray<<24) + k + 1)
-//   u = (mix64(z) >> 11) * 2^-53
+//   c = (ray << 24) + k                      linear draw counter of draw k of a ray (k < 2^24)
+//   h = mix64(base + GOLDEN * ((c >> 1) + 1)),   base = mix64(seed ^ (GOLDEN * phase))
+//   u = (k even ? h >> 32 : h & 0xffffffff) * 2^-32
+// One SplitMix64 finaliser serves TWO consecutive draws (v1 spent one per draw: ~22 of the ~210
+// vector instructions per surface).  In a surface program every live lane of a wave is at the
+// same draw index, known at compile time, so the odd draws reuse the hash of the even ones.
 // ----------------------------------------------------------------------------
 constexpr uint64_t kGolden = 0x9E3779B97F4A7C15ull;
 
@@ -49,90 +53,136 @@ __host__ __device__ inline uint64_t stream_base(uint64_t seed, int phase)
     return mix64(seed ^ (kGolden * (uint64_t)phase));
 }
 
-// the global ray index back from a draw counter z = base + GOLDEN*((ray<<24) + k), k < 2^24:
-// GOLDEN is odd, so it has an inverse modulo 2^64
+// the hash input of pair j of a ray: zray + GOLDEN * (j + 1), zray = base + GOLDEN * (ray << 23)
+// (= base + GOLDEN * (((ray << 24) + 2 j) >> 1)).  GOLDEN is odd, so the ray index comes back from
+// zray through its inverse modulo 2^64.
 constexpr uint64_t kGoldenInv = 0xF1DE83E19937733Dull;
 static_assert(kGolden * kGoldenInv == 1ull, "kGoldenInv must invert kGolden modulo 2^64");
-__host__ __device__ inline uint64_t ray_of_counter(uint64_t z, uint64_t base) { return ((z - base) * kGoldenInv) >> 24; }
+__host__ __device__ inline uint64_t zray_of(uint64_t base, uint64_t ray) { return base + kGolden * (ray << 23); }
+__host__ __device__ inline uint64_t ray_of_zray(uint64_t zray, uint64_t base) { return ((zray - base) * kGoldenInv) >> 23; }
 
-// top 53 bits of x as a double in [0,1) = (double)(x >> 11) * 2^-53, exactly, without int->fp64
-// conversions or a multiply: with hi = top 21 bits and lo = next 32 bits,
-//   A = 2^31 + hi * 2^-21   (exponent word 0x41E.., hi in the low mantissa word: ulp(A) = 2^-21)
-//   B = 2^-1 + lo * 2^-53   (exponent word 0x3FE.., ulp(B) = 2^-53)
-// and (A - (2^31 + 2^-1)) + B = hi * 2^-21 + lo * 2^-53: both steps are exact (each result is
-// representable), and that is the 53-bit fraction.
-__device__ inline double bits_to_unit(uint64_t x)
+// a 32-bit draw as a double in [0,1) = w * 2^-32, exactly, without an int->fp64 conversion:
+// 2^52 + w has w in the low mantissa word (exponent word 0x433..., ulp = 1)
+__device__ inline double bits_to_unit(uint32_t w)
 {
-    const uint32_t hi = (uint32_t)(x >> 43);               // top 21 bits
-    const uint32_t lo = (uint32_t)(x >> 11);               // next 32 bits
-    const double A = __hiloint2double(0x41E00000, (int)hi);
-    const double B = __hiloint2double(0x3FE00000, (int)lo);
-    return (A - 0x1.00000001p31) + B;
+    return (__hiloint2double(0x43300000, (int)w) - 0x1p52) * 0x1p-32;
 }
+// fp32 path: the top 24 bits of the SAME draw, so a ray sees (to 2^-24) the same uniform
+__device__ inline float bits_to_unit_f32(uint32_t w) { return (float)(w >> 8) * 0x1.0p-24f; }
+template <class T> __device__ inline T unit_from(uint32_t w)
+{
+    if constexpr (sizeof(T) == 8) return T(bits_to_unit(w));
+    else return bits_to_unit_f32(w);
+}
+__device__ inline uint32_t draw_word(uint64_t h, bool odd) { return odd ? (uint32_t)h : (uint32_t)(h >> 32); }
 
-// Per-ray draw source.  peek() is the next uniform, advance(c) consumes it where c.
-// Keyed stream, or (parity entry) an explicit table: draw k at table[k*stride].
+// Per-ray draw source of the parity / debug entry.  peek() is the next uniform, advance(c)
+// consumes it where c.  Keyed stream, or an explicit table: draw k at table[k*stride].
 struct Draws {
-    uint64_t z;            // base + GOLDEN*((ray<<24) + k)
+    uint64_t c;            // keyed: (ray << 24) + k
+    uint64_t base;
     const double *table;
     int64_t stride;
     int len;
     int k;                 // draws consumed so far
 
-    __device__ inline void init_keyed(uint64_t base, uint64_t ray, int first_draw)
+    __device__ inline void init_keyed(uint64_t b, uint64_t ray, int first_draw)
     {
-        table = nullptr; stride = 0; len = 0; k = first_draw;
-        z = base + kGolden * ((ray << 24) + (uint64_t)first_draw);
+        table = nullptr; stride = 0; len = 0; k = first_draw; base = b;
+        c = (ray << 24) + (uint64_t)first_draw;
     }
     __device__ inline void init_table(const double *t, int64_t s, int l, int first_draw)
     {
-        table = t; stride = s; len = l; k = first_draw; z = 0;
+        table = t; stride = s; len = l; k = first_draw; c = 0; base = 0;
     }
     __device__ inline double peek() const
     {
         if (table) return k < len ? table[(int64_t)k * stride] : 0.5;
-        return bits_to_unit(mix64(z + kGolden));
+        return bits_to_unit(draw_word(mix64(base + kGolden * ((c >> 1) + 1ull)), (c & 1ull) != 0));
     }
-    __device__ inline void advance(bool c)
+    __device__ inline void advance(bool cnd)
     {
-        k += c ? 1 : 0;
-        z += c ? kGolden : 0ull;
+        k += cnd ? 1 : 0;
+        c += cnd ? 1ull : 0ull;
     }
     __device__ inline double next() { double u = peek(); advance(true); return u; }
-    __device__ inline void take(bool c, const Draws &o) { k = c ? o.k : k; z = c ? o.z : z; }   // same stream
+    __device__ inline void take(bool cnd, const Draws &o) { k = cnd ? o.k : k; c = cnd ? o.c : c; }   // same stream
     template <class T> __device__ inline T peek_as() const { return (T)peek(); }
     template <class T> __device__ inline T next_as() { return (T)next(); }
 };
 
-// fp32 path: the top 24 bits of the SAME 64-bit draw, so a ray sees (to 2^-24) the same uniform
-__device__ inline float bits_to_unit_f32(uint64_t x) { return (float)(uint32_t)(x >> 40) * 0x1.0p-24f; }
-
-// keyed-only variant used by the production kernels (one 64-bit counter per lane)
+// keyed-only variant of the bulk kernels that walk a list they do not know at compile time
+// (generic walk, lockstep kernel): the linear counter per lane, one hash per draw
 struct KeyedDraws {
-    uint64_t z;
+    uint64_t c;            // (ray << 24) + k
+    uint64_t base;
+    __device__ inline void init_keyed(uint64_t b, uint64_t ray, int first_draw)
+    {
+        base = b;
+        c = (ray << 24) + (uint64_t)first_draw;
+    }
+    __device__ inline uint32_t word() const
+    {
+#ifdef ORT_ABL_NORNG
+        return 0xBAE147AEu;
+#else
+        return draw_word(mix64(base + kGolden * ((c >> 1) + 1ull)), (c & 1ull) != 0);
+#endif
+    }
+    __device__ inline double peek() const { return bits_to_unit(word()); }
+    __device__ inline void advance(bool cnd) { c += cnd ? 1ull : 0ull; }
+    __device__ inline void take(bool cnd, const KeyedDraws &o) { c = cnd ? o.c : c; }
+    __device__ inline double next() { const double u = peek(); c += 1ull; return u; }
+    template <class T> __device__ inline T peek_as() const { return unit_from<T>(word()); }
+    template <class T> __device__ inline T next_as()
+    {
+        const T u = peek_as<T>();
+        c += 1ull;
+        return u;
+    }
+    __device__ inline uint64_t ray() const { return c >> 24; }
+    // queue image of the state (one 64-bit word)
+    __device__ inline uint64_t pack() const { return c; }
+    __device__ inline void unpack(uint64_t w, uint64_t b) { c = w; base = b; }
+    __device__ inline uint64_t ray_of_packed(uint64_t w, uint64_t) const { return w >> 24; }
+};
+
+// Draw source of the surface-program kernels: every live lane of a wave is at the same draw
+// index K, a compile-time constant of the program step, so nothing is counted per lane: the
+// state is the ray's zray, and at<K>() hashes pair K/2 at the even draw and keeps the hash for
+// the odd one (FRESH: the hash is not at hand — first draw after the queue — and is formed again).
+struct ProgDraws {
+    uint64_t zray;
+    uint64_t h;
+    int k;                 // sequential interface of the emitters: folds to constants in their straight-line code
     __device__ inline void init_keyed(uint64_t base, uint64_t ray, int first_draw)
     {
-        z = base + kGolden * ((ray << 24) + (uint64_t)first_draw);
+        zray = zray_of(base, ray);
+        h = 0;
+        k = first_draw;
     }
-#ifdef ORT_ABL_NORNG
-    __device__ inline double peek() const { return 0.73; }
-#else
-    __device__ inline double peek() const { return bits_to_unit(mix64(z + kGolden)); }
-#endif
-    __device__ inline void advance(bool c) { z += c ? kGolden : 0ull; }
-    __device__ inline void take(bool c, const KeyedDraws &o) { z = c ? o.z : z; }
-    __device__ inline double next() { z += kGolden; return bits_to_unit(mix64(z)); }
-    template <class T> __device__ inline T peek_as() const
+    template <class T, int K, bool FRESH> __device__ inline T at()
     {
-        if constexpr (sizeof(T) == 8) return peek();
-        else return bits_to_unit_f32(mix64(z + kGolden));
+#ifdef ORT_ABL_NORNG
+        return T(0.73);
+#else
+        if constexpr ((K & 1) == 0 || FRESH) h = mix64(zray + kGolden * (uint64_t)(K / 2 + 1));
+        return unit_from<T>(draw_word(h, (K & 1) != 0));
+#endif
     }
     template <class T> __device__ inline T next_as()
     {
-        T u = peek_as<T>();
-        z += kGolden;
+        if ((k & 1) == 0) h = mix64(zray + kGolden * (uint64_t)(k / 2 + 1));
+        const T u = unit_from<T>(draw_word(h, (k & 1) != 0));
+        k += 1;
         return u;
     }
+    __device__ inline uint64_t pack() const { return zray; }
+    __device__ inline void unpack(uint64_t w, uint64_t) { zray = w; h = 0; k = 0; }
+    __device__ inline uint64_t ray_of_packed(uint64_t w, uint64_t base) const { return ray_of_zray(w, base); }
+    // the dynamic interface is never instantiated for a program (surface_step takes the static one)
+    template <class T> __device__ inline T peek_as() const { return T(0.5); }
+    __device__ inline void advance(bool) {}
 };
 
 // Development-only ablation switches (tools/ablate.sh): they BREAK the numerics contract
@@ -1098,7 +1148,10 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
 // of the bulk kernels; the host picks it when no surface carries ORT_F_SCATTER).
 // KEEP = false lets lanes whose ray has ended carry garbage in r (the bulk kernels read only
 // st/xp/yp/nis of such lanes); KEEP = true freezes r where the ray ended (debug / tracker output).
-template <bool FILT, class T, bool EXT, bool KEEP = true, int KIND = -1, int FLAGS = -1, int HASAP = -1, class Sys, class Surf, class D>
+// DK >= 0 (surface programs): this step's draw index is the compile-time constant DK for every live
+// lane (ProgDraws::at); DK < 0: the draw source counts per lane.
+template <bool FILT, class T, bool EXT, bool KEEP = true, int KIND = -1, int FLAGS = -1, int HASAP = -1, int DK = -1, bool FRESH = false,
+          class Sys, class Surf, class D>
 __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<T> &ax, RayT<T> &r, D &draws,
                                     int &nis, int &st, int &xp, int &yp, bool &rare)
 {
@@ -1155,8 +1208,13 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         ended = out ? lost : -1;
         proceed = live && !out;
     }
-    const T u = draws.template peek_as<T>();
-    draws.advance(proceed);
+    T u;
+    if constexpr (DK >= 0) {
+        u = draws.template at<T, DK, FRESH>();
+    } else {
+        u = draws.template peek_as<T>();
+        draws.advance(proceed);
+    }
     const bool reflected = reflect_refract<FILT, KEEP, T>(r.dir, N, s.n1, s.n2, s.eta, ax.eta2, u, proceed, rare);
     const bool dies = reflected && (flags & ORT_F_SKIP_ON_REFLECT);
     st = live ? (proceed ? (dies ? lost : -1) : ended) : st;

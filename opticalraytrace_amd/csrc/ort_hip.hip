@@ -343,8 +343,20 @@ template <> struct Prog<PROG_POINT_ELLIPSE> {
     static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 0};
 };
 
-// steps [K, K1) of program P, each entered only while some lane of the wave is alive
-template <bool FILT, class T, bool KEEP, int P, int K, int K1, class Sys, class D>
+// draws a ray has consumed before step K of program P: the emitter's (point 2, ring 4:
+// src/sourceMod.f90:31-37, :266-286) plus one per refracting surface passed (an iris and the image
+// plane draw nothing)
+template <int P> constexpr int draw_index(int K)
+{
+    int d = Prog<P>::phase == 1 ? 4 : 2;
+    for (int j = 0; j < K; ++j)
+        if (Prog<P>::kind[j] != ORT_SURF_IRIS && Prog<P>::kind[j] != ORT_SURF_IMAGE) d++;
+    return d;
+}
+
+// steps [K, K1) of program P, each entered only while some lane of the wave is alive.  FRESH: no
+// hash is at hand for the next odd draw (the walk starts behind the queue)
+template <bool FILT, class T, bool KEEP, int P, int K, int K1, bool FRESH, class Sys, class D>
 __device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t surf, typename ConstPtrs<T>::aux_t aux, RayT<T> &r, D &draws,
                                   int &nis, int &st, int &xp, int &yp, bool &rare)
 {
@@ -355,12 +367,13 @@ __device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t su
 #ifdef ORT_ISA_MARKERS      // tools/isa_budget.py: comment lines that delimit the steps in the listing
             asm volatile("; ORT_STEP_BEGIN %0" ::"n"(K));
 #endif
-            surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K]>(
+            constexpr bool draws_here = Prog<P>::kind[K] != ORT_SURF_IRIS && Prog<P>::kind[K] != ORT_SURF_IMAGE;
+            surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH>(
                 S, s, ax, r, draws, nis, st, xp, yp, rare);
 #ifdef ORT_ISA_MARKERS
             asm volatile("; ORT_STEP_END %0" ::"n"(K));
 #endif
-            walk_fixed<FILT, T, KEEP, P, K + 1, K1>(S, surf, aux, r, draws, nis, st, xp, yp, rare);
+            walk_fixed<FILT, T, KEEP, P, K + 1, K1, FRESH && !draws_here>(S, surf, aux, r, draws, nis, st, xp, yp, rare);
         }
     }
 }
@@ -448,7 +461,13 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             Draws d;
             if (a.u) d.init_table(a.u + ic, (int64_t)n, a.nu, a.draw_base);
             else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
-            if (!have_in && !emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
+            if (!have_in) {
+                const Draws d_none = d;
+                const bool emitted = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf);
+                st = emitted ? st : ORT_ST_LOST_TELESCOPE;
+                d.take(!emitted, d_none);                // an exhausted image source emits nothing and draws nothing
+                if (!emitted) r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(0.)}};
+            }
             em = r;
             if (a.path) {
                 // tracker: the walk of `walk`, recording the pushes of src/stackMod.f90
@@ -574,6 +593,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     double (*q)[kQueueCap] = Q[wave];
     int *qn = QN[wave];
     constexpr bool fixed = PROG != PROG_GENERIC;        // surface program known at compile time
+    using DrawsT = typename std::conditional<fixed, ProgDraws, KeyedDraws>::type;
     int phase = a.phase, ns, split;
     if constexpr (fixed) {
         phase = Prog<PROG>::phase; ns = Prog<PROG>::n; split = Prog<PROG>::split;   // host: match_program
@@ -636,20 +656,21 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             qhead = (qhead + m) & (kQueueCap - 1);
             qcount -= m;
             RayT<T> r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}};
-            KeyedDraws d;
-            d.z = 0;
+            DrawsT d;
+            uint64_t dw = 0;                             // the queued image of the draw state
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
             if (act) {
                 r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
                 r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
-                d.z = (uint64_t)__double_as_longlong(q[6][slot]);
+                dw = (uint64_t)__double_as_longlong(q[6][slot]);
                 nis = SCAT ? qn[slot] : split;
             }
+            d.unpack(dw, a.rng_base);
             bool rare = false;
-            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
+            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n, true>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
             else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
-                if (FILT && rare) defer(ray_of_counter(d.z, a.rng_base) - a.first_ray);
+                if (FILT && rare) defer(d.ray_of_packed(dw, a.rng_base) - a.first_ray);
                 else finish(st, nis, xp, yp);
             }
             __builtin_amdgcn_wave_barrier();
@@ -660,7 +681,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             next += 64;
             const uint64_t ic = act ? i : hi - 1;        // clamped: idle lanes recompute the last ray, unused
             RayT<T> r;
-            KeyedDraws d;
+            DrawsT d;
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
             bool rare = false;
             if (MODE == MODE_RESIDENT) {
@@ -671,7 +692,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
                 if (!emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare)) st = ORT_ST_LOST_TELESCOPE;
             }
-            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
+            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split, false>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
             else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
             const bool deferred = FILT && rare && act;
             const bool survive = act && st < 0 && !deferred;
@@ -680,7 +701,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 const int slot = (qhead + qcount + lane_prefix(mask)) & (kQueueCap - 1);
                 q[0][slot] = (double)r.pos.x; q[1][slot] = (double)r.pos.y; q[2][slot] = (double)r.pos.z;
                 q[3][slot] = (double)r.dir.x; q[4][slot] = (double)r.dir.y; q[5][slot] = (double)r.dir.z;
-                q[6][slot] = __longlong_as_double((long long)d.z);
+                q[6][slot] = __longlong_as_double((long long)d.pack());
                 if (SCAT) qn[slot] = nis;
             } else if (deferred) {
                 defer(i);
@@ -843,7 +864,10 @@ template <class T, bool FILT = true>
 static void launch_lean(ort_ctx *c, int mode, const TraceArgs &a, int grid)
 {
 #define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
-    const int prog = c->prog[a.phase - 1];
+    // a program's draw indices are compile-time constants: they assume the emitter's own number of
+    // draws in front of the first surface (resident bundles may come with another draw_base)
+    int prog = c->prog[a.phase - 1];
+    if (mode != MODE_FUSED && a.draw_base != (a.phase == 1 ? 4 : 2)) prog = PROG_GENERIC;
 #define ORT_CASE(P)                                                                                        \
     case P:                                                                                                \
         if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, FILT, false, T, P>));           \

@@ -12,7 +12,7 @@ the OpenMP build is the same walk restarted per thread).  Rays beyond the histog
 stale ray there; here they are counted as lost.
 
 The reference draws the 262 144 rounding uniforms from the still unseeded runtime generator;
-here draw k of the (i, j) loop is ORT-RNG-v1(seed, phase 0, ray 0, k).
+here draw k of the (i, j) loop is ORT-RNG-v2(seed, phase 0, ray 0, k).
 """
 from __future__ import annotations
 

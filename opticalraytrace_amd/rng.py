@@ -1,8 +1,9 @@
-"""ORT-RNG-v1 on the host (numpy), for the few draws the host itself consumes
+"""ORT-RNG-v2 on the host (numpy), for the few draws the host itself consumes
 (the image-source histogram rounding, reference src/sourceMod.f90:396-407).
 
-    base = mix64(seed ^ (GOLDEN * phase));  z = base + GOLDEN * ((ray << 24) + k + 1)
-    u    = (mix64(z) >> 11) * 2^-53          (mix64 = SplitMix64 finaliser)
+    base = mix64(seed ^ (GOLDEN * phase));  c = (ray << 24) + k
+    h    = mix64(base + GOLDEN * ((c >> 1) + 1))         (mix64 = SplitMix64 finaliser)
+    u    = (k even ? h >> 32 : h & 0xffffffff) * 2^-32   (one hash serves two consecutive draws)
 
 Same definition as csrc/ort_device.h (device) — restated, not shared.
 """
@@ -27,5 +28,7 @@ def uniforms(seed: int, phase: int, ray: int, draws) -> np.ndarray:
     k = np.asarray(draws, dtype=np.uint64)
     with np.errstate(over="ignore"):
         base = mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ (GOLDEN * np.uint64(phase)))
-        z = base + GOLDEN * ((np.uint64(ray) << np.uint64(24)) + k + np.uint64(1))
-    return (mix64(z) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+        c = (np.uint64(ray) << np.uint64(24)) + k
+        h = mix64(base + GOLDEN * ((c >> np.uint64(1)) + np.uint64(1)))
+    w = np.where((c & np.uint64(1)) != 0, h & np.uint64(0xFFFFFFFF), h >> np.uint64(32))
+    return w.astype(np.float64) * 2.0 ** -32

@@ -7,7 +7,7 @@ number of rays and prints one JSON object.
 
   kind "reference": oracle/_ref/libort_ref.so — the reference's own Fortran path
       sources (point, bottle%forward, telescope, makeImage) compiled with flang,
-      OpenMP `parallel do` over rays as src/main.f90:83-89, fed ORT-RNG-v1 draws
+      OpenMP `parallel do` over rays as src/main.f90:83-89, fed ORT-RNG-v2 draws
       (the unmodified reference's random_number is one locked generator under
       flang and does not scale).
   kind "port": oracle/libort_oracle.so — the plain-C restatement, same loop.

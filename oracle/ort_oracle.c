@@ -16,9 +16,9 @@
 
 /* ---------------------------------------------------------------- RNG ---- */
 /* Semantics of ran2(): one U[0,1) per call (src/random_mod.f90:39-46).  The
- * generator itself is the compiler runtime's and is replaced by ORT-RNG-v1:
- *   base = mix64(seed ^ (GOLDEN*phase)); z = base + GOLDEN*((ray<<24)+k+1);
- *   u = (mix64(z) >> 11) * 2^-53.                                            */
+ * generator itself is the compiler runtime's and is replaced by ORT-RNG-v2:
+ *   c = (ray<<24) + k;  h = mix64(base + GOLDEN*((c>>1) + 1)),  base = mix64(seed ^ (GOLDEN*phase));
+ *   u = (k even ? h >> 32 : h & 0xffffffff) * 2^-32      (one hash serves two consecutive draws) */
 #define GOLDEN 0x9E3779B97F4A7C15ull
 
 static inline uint64_t mix64(uint64_t z)
@@ -32,8 +32,10 @@ static inline uint64_t mix64(uint64_t z)
 double orc_uniform(uint64_t seed, int32_t phase, uint64_t ray, int32_t draw)
 {
     uint64_t base = mix64(seed ^ (GOLDEN * (uint64_t)phase));
-    uint64_t z = base + GOLDEN * ((ray << 24) + (uint64_t)draw + 1ull);
-    return (double)(mix64(z) >> 11) * 0x1.0p-53;
+    uint64_t c = (ray << 24) + (uint64_t)draw;
+    uint64_t h = mix64(base + GOLDEN * ((c >> 1) + 1ull));
+    uint32_t w = (c & 1ull) ? (uint32_t)h : (uint32_t)(h >> 32);
+    return (double)w * 0x1.0p-32;
 }
 
 typedef struct {

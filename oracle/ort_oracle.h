@@ -84,12 +84,12 @@ double orc_uniform(uint64_t seed, int32_t phase, uint64_t ray, int32_t draw);
 
 /* init_emit_image, src/sourceMod.f90:363-408, serial semantics (nphotonsLocal = nphotons):
  * img is the 512x512 float64 file content as read (first index fastest); rounding draw k of
- * the (i, j) loop is ORT-RNG-v1(seed, phase 0, ray 0, k).  counts_scan receives imgin in the
+ * the (i, j) loop is ORT-RNG-v2(seed, phase 0, ray 0, k).  counts_scan receives imgin in the
  * order emit_image scans it. */
 void orc_init_emit_image(const double *img, int32_t nphotons, uint64_t seed, int32_t *counts_scan);
 
 /* Parity entry.  SoA [6][n] (x,y,z,dx,dy,dz).  pos_dir_in NULL => emit with the
- * phase's source.  u NULL => ORT-RNG-v1 keyed on (seed, phase, first_ray+i);
+ * phase's source.  u NULL => ORT-RNG-v2 keyed on (seed, phase, first_ray+i);
  * else u is [nu][n] and draw k of ray i is u[k*n+i], k starting at draw_base.
  * Any output pointer may be NULL. */
 int orc_trace_rays(const orc_system *sys, int phase, int64_t n,

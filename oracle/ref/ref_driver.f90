@@ -292,7 +292,7 @@ contains
     end subroutine ortref_trace_rays
 
     ! Bulk entry: the reference loop bodies (main.f90:90-109, :127-162) over
-    ! global ray indices [first, first+n) with ORT-RNG-v1 keyed draws, OpenMP
+    ! global ray indices [first, first+n) with ORT-RNG-v2 keyed draws, OpenMP
     ! over rays exactly as main.f90:83-89 (atomic image, reduction on the counter).
     subroutine ortref_trace(phase, first, n, seed, image, lost) bind(C, name="ortref_trace")
         integer(c_int), value :: phase

@@ -12,13 +12,13 @@
  * the functions below.  Two modes:
  *
  *   table mode  — the k-th draw of the current ray is u[k] from a caller table
- *   keyed mode  — the k-th draw of ray i of phase p is ORT-RNG-v1(seed,p,i,k)
+ *   keyed mode  — the k-th draw of ray i of phase p is ORT-RNG-v2(seed,p,i,k)
  *
- * ORT-RNG-v1 (the same definition is restated, independently, in
+ * ORT-RNG-v2 (the same definition is restated, independently, in
  * oracle/ort_oracle.c and in the HIP kernels):
- *   base = mix64(seed ^ (GOLDEN * phase))
- *   z    = base + GOLDEN * ((ray << 24) + k + 1)
- *   u    = (mix64(z) >> 11) * 2^-53,   mix64 = SplitMix64 finaliser
+ *   base = mix64(seed ^ (GOLDEN * phase)),   c = (ray << 24) + k
+ *   h    = mix64(base + GOLDEN * ((c >> 1) + 1)),   mix64 = SplitMix64 finaliser
+ *   u    = (k even ? h >> 32 : h & 0xffffffff) * 2^-32
  */
 #include <stdint.h>
 #include <stddef.h>
@@ -36,7 +36,8 @@ static inline uint64_t mix64(uint64_t z)
 static _Thread_local const double *tl_table;   /* table mode when non-NULL */
 static _Thread_local int64_t  tl_table_stride;
 static _Thread_local int32_t  tl_table_len;
-static _Thread_local uint64_t tl_zray;         /* keyed mode: base + GOLDEN*(ray<<24) */
+static _Thread_local uint64_t tl_base;         /* keyed mode: mix64(seed ^ GOLDEN*phase) */
+static _Thread_local uint64_t tl_ray;
 static _Thread_local int32_t  tl_draw;         /* draws consumed by the current ray */
 
 void ortref_rng_table(const double *u, int64_t stride, int32_t len, int32_t first_draw)
@@ -46,9 +47,9 @@ void ortref_rng_table(const double *u, int64_t stride, int32_t len, int32_t firs
 
 void ortref_rng_key(uint64_t seed, int32_t phase, uint64_t ray, int32_t first_draw)
 {
-    uint64_t base = mix64(seed ^ (GOLDEN * (uint64_t)phase));
+    tl_base = mix64(seed ^ (GOLDEN * (uint64_t)phase));
     tl_table = NULL;
-    tl_zray = base + GOLDEN * (ray << 24);
+    tl_ray = ray;
     tl_draw = first_draw;
 }
 
@@ -61,6 +62,8 @@ double ortref_draw(void)
         if (k >= tl_table_len) return 0.5;   /* never reached on the checked path */
         return tl_table[(int64_t)k * tl_table_stride];
     }
-    uint64_t z = tl_zray + GOLDEN * (uint64_t)(k + 1);
-    return (double)(mix64(z) >> 11) * 0x1.0p-53;
+    uint64_t c = (tl_ray << 24) + (uint64_t)k;
+    uint64_t h = mix64(tl_base + GOLDEN * ((c >> 1) + 1ull));
+    uint32_t w = (c & 1ull) ? (uint32_t)h : (uint32_t)(h >> 32);
+    return (double)w * 0x1.0p-32;
 }

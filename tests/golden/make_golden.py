@@ -18,7 +18,7 @@ uniform draws, rays) and the outputs the reference produced for them:
     p{1,2}_ndraws  draws consumed
     p{1,2}x_*      the same rays re-traced from EXPLICIT input (pos_dir_in = emitted,
                    draws starting at index 4 / 2): no transcendental on that path
-    img{1,2}_idx/_cnt  sparse image of 100000 keyed rays (ORT-RNG-v1, seed 123456789)
+    img{1,2}_idx/_cnt  sparse image of 100000 keyed rays (ORT-RNG-v2, seed 123456789)
     img{1,2}_lost      the reference's rcount / pcount for that run
 """
 import os

@@ -1,6 +1,6 @@
 """Statistical comparison of two Monte-Carlo images of the same set-up that were produced
 with DIFFERENT random streams (the unmodified reference program uses the Fortran
-runtime's random_number; this build uses ORT-RNG-v1)."""
+runtime's random_number; this build uses ORT-RNG-v2)."""
 import numpy as np
 
 

@@ -1,0 +1,83 @@
+"""`python -m opticalraytrace_amd <settings>` = `bin/raytrace <settings>` at the process boundary
+(install.sh:70-72, src/setupMod.f90:51-56): same inputs, same output files, a non-zero exit where the
+reference would `error stop` (what runner.py:47 `check=True` relies on)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from opticalraytrace_amd.params import Settings, resource_dir
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tree(tmp_path, **over):
+    """The reference's run tree: <tmp>/{bin,res,data}; res holds the .params files and a settings
+    file in runner.py's format (runner.py:106-108)."""
+    for d in ("bin", "res", "data"):
+        os.makedirs(tmp_path / d, exist_ok=True)
+    for f in os.listdir(resource_dir()):
+        if f.endswith(".params"):
+            shutil.copy(os.path.join(resource_dir(), f), tmp_path / "res" / f)
+    s = Settings(**{**dict(nphotons=200_000, make_images=True, data_folder="images"), **over})
+    s.write(str(tmp_path / "res" / "test_0.params"))
+    return s
+
+
+def _run(cwd, *args):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    return subprocess.run([sys.executable, "-m", "opticalraytrace_amd", *args], cwd=cwd, env=env,
+                          capture_output=True, text=True, timeout=600)
+
+
+def test_bad_inputs_exit_non_zero_with_a_message(tmp_path):
+    _tree(tmp_path)
+    bin_dir = str(tmp_path / "bin")
+    p = _run(bin_dir, "nothing.params")                               # open(status="old") fails in the reference
+    assert p.returncode == 1 and "nothing.params" in p.stderr and "Traceback" not in p.stderr
+    # a 14-line bottle file: the reference dies with "End of file" (src/lens.f90:205)
+    base = open(tmp_path / "res" / "clearBottle-small.params").read().splitlines()[:12]
+    with open(tmp_path / "res" / "clearBottle-14.params", "w") as f:
+        f.write("\n".join(base + ["0.", "0."]) + "\n")
+    Settings(nphotons=1000, bottle_file="clearBottle-14.params").write(str(tmp_path / "res" / "bad.params"))
+    p = _run(bin_dir, "bad.params")
+    assert p.returncode == 1 and "exactly 12" in p.stderr
+    Settings(nphotons=1000, light_source="laser").write(str(tmp_path / "res" / "src.params"))
+    p = _run(bin_dir, "src.params")
+    assert p.returncode == 1 and "source type" in p.stderr            # setupMod.f90:98
+    assert not os.listdir(tmp_path / "data")                          # nothing was written
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="this box has a GPU")
+def test_without_a_gpu_the_run_fails_loudly(tmp_path):
+    _tree(tmp_path, nphotons=1000)
+    p = _run(str(tmp_path / "bin"), "test_0.params")
+    assert p.returncode == 3 and "HIP" in p.stderr and "fallback" in p.stderr
+
+
+@pytest.mark.gpu
+def test_entry_point_writes_what_run_settings_writes(tmp_path, hip_library):
+    from opticalraytrace_amd.tracer import run_settings
+    s = _tree(tmp_path, bottle_file="clearBottle-large.params", iris="before", iris_size=0.8)
+    p = _run(str(tmp_path / "bin"), "test_0.params")                  # as install.sh does: from bin/, bare name
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "Ring  transmitted:" in p.stdout and "Point transmitted:" in p.stdout
+    got_dir = tmp_path / "data" / "images"
+    names = sorted(f for f in os.listdir(got_dir) if f.endswith(".dat") and "image" in f)
+    assert len(names) == 3 and names[0].startswith("point_bottle_T_Ra_")
+    want_root = tmp_path / "want"
+    res = run_settings(s, str(tmp_path / "res"), str(want_root), verbose=False)
+    for n in names:
+        a = np.fromfile(got_dir / n)
+        b = np.fromfile(want_root / "images" / n)
+        assert a.size == 401 * 401 and np.array_equal(a, b), n
+    assert np.fromfile(got_dir / names[2]).sum() == res.image.sum()   # -total = ring + point
+    rows = open(got_dir / "trans-stats.dat").read().splitlines()
+    assert len(rows) == 2 and rows == open(want_root / "images" / "trans-stats.dat").read().splitlines()
+    # explicit paths instead of the bin/ layout
+    p = _run(str(tmp_path), "res/test_0.params", "--data", "data2", "--quiet")
+    assert p.returncode == 0 and p.stdout == ""
+    assert sorted(f for f in os.listdir(tmp_path / "data2" / "images") if "image" in f) == names

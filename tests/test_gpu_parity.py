@@ -102,7 +102,7 @@ def test_random_rays_vs_oracle_bit_exact(ctxs, name, phase):
 
 @pytest.mark.parametrize("phase", [1, 2])
 def test_keyed_draws_match_oracle(ctxs, phase):
-    """ORT-RNG-v1 on the device == oracle: keyed rays (no table) give identical outcomes."""
+    """ORT-RNG-v2 on the device == oracle: keyed rays (no table) give identical outcomes."""
     osys, ctx = ctxs("large")
     orc = _oracle(osys)
     n = 4096 + 3
@@ -339,7 +339,13 @@ def test_image_source_on_the_gpu(ctxs):
     want = orc.trace_rays(2, n, seed=SEED, first_ray=0)
     got = ctx.trace_rays(2, n, seed=SEED, first_ray=0)
     assert np.array_equal(got["n_draws"], want["n_draws"])
-    assert rel_err(got["emitted"], want["emitted"]) <= 1e-12
+    # emitted rays: sin / cos within an ulp of glibc's => every component within a few ulps OF THE
+    # VECTOR'S LENGTH (a component that nearly cancels — cos(theta) ~ 0 — has no relative accuracy
+    # of its own on either side)
+    for k in (0, 3):
+        w = want["emitted"][k:k + 3]
+        scale = np.maximum(np.sqrt((w * w).sum(0)), 1e-300)
+        assert (np.abs(got["emitted"][k:k + 3] - w) / scale).max() <= 1e-15
     assert (got["status"] != want["status"]).sum() <= 2
     # rays beyond the histogram total are "lost", none emitted
     from opticalraytrace_amd.image_source import cdf, histogram, load_image

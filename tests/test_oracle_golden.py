@@ -59,7 +59,8 @@ def test_oracle_matches_golden_images(name):
 
 
 def test_rng_known_answers():
-    """ORT-RNG-v1 pinned numerically (SplitMix64 finaliser; independent Python restatement)."""
+    """ORT-RNG-v2 pinned numerically (SplitMix64 finaliser, one hash per pair of draws; independent
+    Python restatement), and the host's own numpy restatement (opticalraytrace_amd/rng.py)."""
     M = (1 << 64) - 1
     G = 0x9E3779B97F4A7C15
 
@@ -70,13 +71,16 @@ def test_rng_known_answers():
 
     def uni(seed, phase, ray, k):
         base = mix(seed ^ ((G * phase) & M))
-        z = (base + G * (((ray << 24) + k + 1) & M)) & M
-        return (mix(z) >> 11) * 2.0 ** -53
+        c = ((ray << 24) + k) & M
+        h = mix((base + G * ((c >> 1) + 1)) & M)
+        return ((h & 0xFFFFFFFF) if (c & 1) else (h >> 32)) * 2.0 ** -32
 
     orc = Oracle()
     for seed, phase, ray, k in [(SEED, 1, 0, 0), (SEED, 2, 12345678901, 8), (0, 2, 2 ** 31 - 1, 3),
                                 (2 ** 63 + 5, 1, 999, 15)]:
         assert orc.uniform(seed, phase, ray, k) == uni(seed, phase, ray, k)
+        from opticalraytrace_amd.rng import uniforms
+        assert float(uniforms(seed, phase, ray, [k])[0]) == uni(seed, phase, ray, k)
     us = np.array([orc.uniform(SEED, 2, i, i % 9) for i in range(20000)])
     assert 0.0 <= us.min() and us.max() < 1.0
     assert abs(us.mean() - 0.5) < 0.01 and abs(us.var() - 1 / 12) < 0.005
