@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ORT_ABI_VERSION 1
+#define ORT_ABI_VERSION 2
 #define ORT_MAX_SURFACES 12
 #define ORT_IMAGE_N 401
 #define ORT_IMAGE_BINS (2 * 401 * 401)
@@ -56,6 +56,8 @@ extern "C" {
 #define ORT_EMIT_SPOT 2      /* create_spot     src/sourceMod.f90:122-159 (phase 2: spot source, no draws) */
 #define ORT_EMIT_CRS 3       /* point_on_bottle src/sourceMod.f90:50-89   (phase 1: crs source) */
 #define ORT_EMIT_IMAGE 4     /* emit_image/emit src/sourceMod.f90:303-361 (phase 2: image source; needs ort_set_image_source) */
+#define ORT_EMIT_ISORS 5     /* iSORS(ring=.true.) src/sourceMod.f90:162-247 (phase 1: isors source; its phase 2 is
+                                `point` started at bottle%centre%z, src/main.f90:140: point_offset below) */
 #define ORT_IMAGE_SOURCE_CELLS (512 * 512)
 
 /* surface flags */
@@ -116,6 +118,15 @@ typedef struct ort_system {
     double crs_sigma, crs_radius, crs_cy, crs_cz;
     /* image source, emit (src/sourceMod.f90:325-361): lens%radius**2 and lens%fb of the 843 nm L2 */
     double img_lens_r2, img_lens_z;
+    /* point emitter's start height: 0, or bottle%centre%z for the isors source (src/main.f90:140) */
+    double point_offset;
+    /* isors source, iSORS (src/sourceMod.f90:162-247): Gaussian sigma of the beam (ring_width), the
+     * axicon cone (k = (radius/height)**2, height; n = 1.4), base_pos = (seperation + beam_width) /
+     * tan(alpha (n - 1)), the z the ray is put at beside the bottle (radiusa + centre%z +
+     * epsilon(1.)), the bottle's inner wall it is carried to (circular: rad1 = rad2 = radiusa -
+     * thickness; elliptical: semi-axes minus thickness; centre y, z), lens%radius**2, lens%fb */
+    double isors_sigma, isors_k, isors_height, isors_base_pos, isors_z;
+    double isors_rad1, isors_rad2, isors_cy, isors_cz, isors_lens_r2, isors_lens_z;
 } ort_system;
 
 /* per-ray status written by ort_trace_rays */
@@ -125,7 +136,8 @@ typedef struct ort_system {
 #define ORT_ST_LOST_BOTTLE 3
 #define ORT_ST_LOST_TELESCOPE 4
 #define ORT_ST_HELP3 5
-#define ORT_ST_NO_INTERSECTION 6  /* tauint found no wall: reference aborts (src/surfaces.f90:33-39); counted as lost */
+#define ORT_ST_NO_INTERSECTION 6  /* tauint found no wall, or the isors source no bottle: the reference aborts
+                                     (src/surfaces.f90:33-39, src/sourceMod.f90:216-218); counted as lost */
 
 /* counters[ORT_NUM_COUNTERS] */
 #define ORT_C_LOST_RING 0     /* rcount, src/main.f90:40, optics_system.f90:32,42 */

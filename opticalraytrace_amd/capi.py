@@ -15,7 +15,7 @@ import numpy as np
 
 from .system import MAX_SURFACES, OpticalSystem, TWOPI
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 IMAGE_N = 401
 IMAGE_BINS = 2 * IMAGE_N * IMAGE_N
 NUM_COUNTERS = 8
@@ -25,7 +25,7 @@ ST_BINNED, ST_NA_REJECT, ST_OFF_GRID, ST_LOST_BOTTLE, ST_LOST_TELESCOPE, ST_HELP
 (C_LOST_RING, C_LOST_POINT, C_ISECT_RING, C_ISECT_POINT,
  C_BINNED_RING, C_BINNED_POINT, C_HELP3_RING, C_HELP3_POINT) = range(8)
 
-EMIT_RING, EMIT_POINT, EMIT_SPOT, EMIT_CRS, EMIT_IMAGE = range(5)
+EMIT_RING, EMIT_POINT, EMIT_SPOT, EMIT_CRS, EMIT_IMAGE, EMIT_ISORS = range(6)
 
 _ERRORS = {-1: "ORT_E_INVALID", -2: "ORT_E_NODEVICE", -3: "ORT_E_HIP", -4: "ORT_E_NOMEM", -5: "ORT_E_NOCOMM"}
 
@@ -55,7 +55,12 @@ class OrtSystem(C.Structure):
                 ("bin_width", C.c_double), ("inv_bin_width", C.c_double), ("na_angle", C.c_double), ("na_cos_min", C.c_double),
                 ("twopi", C.c_double), ("spot_dphi", C.c_double), ("spot_dtheta", C.c_double),
                 ("crs_sigma", C.c_double), ("crs_radius", C.c_double), ("crs_cy", C.c_double),
-                ("crs_cz", C.c_double), ("img_lens_r2", C.c_double), ("img_lens_z", C.c_double)]
+                ("crs_cz", C.c_double), ("img_lens_r2", C.c_double), ("img_lens_z", C.c_double),
+                ("point_offset", C.c_double),
+                ("isors_sigma", C.c_double), ("isors_k", C.c_double), ("isors_height", C.c_double),
+                ("isors_base_pos", C.c_double), ("isors_z", C.c_double), ("isors_rad1", C.c_double),
+                ("isors_rad2", C.c_double), ("isors_cy", C.c_double), ("isors_cz", C.c_double),
+                ("isors_lens_r2", C.c_double), ("isors_lens_z", C.c_double)]
 
 
 def pack_system(osys: OpticalSystem) -> OrtSystem:
@@ -91,7 +96,7 @@ def pack_system(osys: OpticalSystem) -> OrtSystem:
     cs.twopi = TWOPI
     # emitters per phase (src/main.f90:95-101, :132-142)
     src = osys.settings.light_source
-    cs.emitter[0] = EMIT_CRS if src == "crs" else EMIT_RING
+    cs.emitter[0] = {"crs": EMIT_CRS, "isors": EMIT_ISORS}.get(src, EMIT_RING)
     cs.emitter[1] = {"spot": EMIT_SPOT, "image": EMIT_IMAGE}.get(src, EMIT_POINT)
     l2p = osys.L2[1]                          # main.f90:133: emit_image(imgin, pos, dir, L2) after the 843 nm rebuild
     cs.img_lens_r2 = l2p.radius * l2p.radius
@@ -103,6 +108,21 @@ def pack_system(osys: OpticalSystem) -> OrtSystem:
     cs.crs_sigma = osys.crs_spot_size
     cs.crs_radius = b.radiusa + b.thickness
     cs.crs_cy, cs.crs_cz = b.centre[1], b.centre[2]
+    # isors source (src/sourceMod.f90:162-247, src/main.f90:97,140)
+    cs.point_offset = b.centre[2] if src == "isors" else 0.0
+    s = osys.settings
+    axicon_n, radius, height = 1.4, 12.7e-3, 1.1e-3                 # sourceMod.f90:180-182
+    alpha = math.atan(height / radius)
+    cs.isors_sigma = s.ring_width
+    cs.isors_k = (radius / height) * (radius / height)
+    cs.isors_height = height
+    cs.isors_base_pos = (s.isors_offset + s.ring_width) / math.tan(alpha * (axicon_n - 1.))
+    cs.isors_z = b.radiusa + b.centre[2] + 2.0 ** -52               # epsilon(1.) of a real*8
+    cs.isors_rad1 = b.radiusa - b.thickness
+    cs.isors_rad2 = (b.radiusb - b.thickness) if b.ellipse else (b.radiusa - b.thickness)
+    cs.isors_cy, cs.isors_cz = b.centre[1], b.centre[2]
+    cs.isors_lens_r2 = l2.radius * l2.radius
+    cs.isors_lens_z = l2.fb
     return cs
 
 

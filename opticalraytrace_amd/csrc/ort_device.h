@@ -498,6 +498,8 @@ template <class T> struct SystemT {
     T cos_theta_max, ring_r1, ring_r2, ring_lens_r2, ring_lens_z, ring_bottle_ra, ring_bottle_rb, ring_bottle_z;
     T bin_width, inv_bin_width, na_cos_min, twopi;
     T spot_dphi, spot_dtheta, crs_sigma, crs_radius, crs_cy, crs_cz, img_lens_r2, img_lens_z;
+    T point_offset;
+    T isors_sigma, isors_k, isors_height, isors_base_pos, isors_z, isors_rad1, isors_rad2, isors_cy, isors_cz, isors_lens_r2, isors_lens_z;
     int32_t emitter[2];
 };
 template <class T> struct SysTypes { using Sys = SystemT<T>; using Surf = SurfaceT<T>; };
@@ -940,7 +942,7 @@ __device__ inline void emit_point(const Sys &S, RayT<T> &r, D &draws, bool &rare
     T sint = sqrt_f<FILT, T>(T(1.0) - cost * cost, true, rare);
     // every emitter ends with the same six stores in the same order (pos, then dir): when the
     // optimiser merges the emitters' tails it then merges VALUES, not the addresses of r's fields
-    r.pos = {T(0.0), T(0.0), T(0.0)};
+    r.pos = {T(0.0), T(0.0), T(0.0) + T(S.point_offset)};       // :45; offset = bottle%centre%z for the isors source (main.f90:140)
     r.dir = {sint * cosp, sint * sinp, cost};
 }
 
@@ -1025,6 +1027,92 @@ __device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws)
     r.dir = {sint * cosp, sint * sinp, cost};
 }
 
+// rang, src/random_mod.f90:59-85: polar Box-Muller, a variable number of draws (predicated loop)
+template <class T, class D>
+__device__ inline void rang(D &draws, T sigma, T &gx, T &gy)
+{
+    T x = T(0.), y = T(0.), s = T(1.);
+    bool more = true;
+    while (wave_any(more)) {                               // do while(s >= 1.)
+        T u1 = draws.template peek_as<T>();
+        draws.advance(more);
+        T u2 = draws.template peek_as<T>();
+        draws.advance(more);
+        T xn = T(-1.) + u1 * (T(1.) - T(-1.));             // ranu(-1., 1.)
+        T yn = T(-1.) + u2 * (T(1.) - T(-1.));
+        x = more ? xn : x;
+        y = more ? yn : y;
+        s = more ? y * y + x * x : s;
+        more = more && (s >= T(1.));
+    }
+    T cst = ORT_SQRT(T(-2.) * log(s) / s);
+    gx = T(0.) + sigma * (x * cst);
+    gy = T(0.) + sigma * (y * cst);
+}
+
+// iSORS(ring = .true.), src/sourceMod.f90:162-247 (the "isors" source of phase 1, src/main.f90:97):
+// a Gaussian beam dropped along -z onto an axicon (glass cone, n = 1.4), refracted or reflected
+// there (one draw; the flag is not looked at), carried base_pos / dir%z on, put beside the bottle
+// and brought to its inner wall; then aimed at a uniform point of the lens disc.  Returns false
+// where the reference aborts (`error stop "no intersection with bottle!"`, :216-218: the beam
+// reflected at the axicon and flies away from the bottle): the ray ends as ORT_ST_NO_INTERSECTION
+// with no further draw.  Literal arithmetic throughout (intersect_cone = src/surfaces.f90:179-224).
+template <class T, class Sys, class D>
+__device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws)
+{
+    T gx, gy;
+    rang<T>(draws, T(S.isors_sigma), gx, gy);
+    const T height = T(S.isors_height), k = T(S.isors_k);
+    VecT<T> pos = {T(0.) + gx, T(0.) + gy, T(0.) + T(2.) * height};
+    VecT<T> dir = {T(0.), T(0.), T(-1.)};
+    // intersect_cone: centre = 0
+    const T Lz = pos.z - T(0.);
+    const T a = dir.x * dir.x + dir.y * dir.y - (k * (dir.z * dir.z));
+    const T hb = (dir.x * pos.x) + (dir.y * pos.y) - (k * dir.z * (Lz - height));      // b = 2.*(...)
+    const T c = pos.x * pos.x + pos.y * pos.y - (k * ((Lz - height) * (Lz - height)));
+    T t;
+    bool cone, unused = false;
+    solve_and_pick<false, T>(a, hb, c, true, t, cone, unused);
+    bool ok = true;
+    {
+        const VecT<T> hitp = vadd(pos, vscale(dir, t));
+        VecT<T> N = {T(2.) * (hitp.x - T(0.)) / k, T(2.) * (hitp.y - T(0.)) / k, -(T(2.) * (hitp.z - T(0.))) + T(2.) * height};
+        N = vnormalise(vscale(N, T(-1.)));
+        const T u = draws.template peek_as<T>();
+        draws.advance(cone);
+        VecT<T> d2 = dir;
+        (void)reflect_refract<false, true, T>(d2, N, T(1.4), T(1.), T(1.4) / T(1.), T(0.), u, true, unused);
+        const T tt = T(S.isors_base_pos) / d2.z;
+        VecT<T> p2 = vadd(hitp, vscale(d2, tt));
+        p2.z = T(S.isors_z);
+        // bottle inner wall: circular (rad1 = rad2) or elliptical cylinder about x
+        const RayT<T> probe = {p2, d2};
+        T tb;
+        bool hitb;
+        if (__builtin_amdgcn_readfirstlane(S.ring_ellipse))
+            intersect_ellipse<false, T>(probe, T(S.isors_cy), T(S.isors_cz), T(S.isors_rad1), T(S.isors_rad2), T(0.), T(0.), true, tb, hitb, unused);
+        else
+            intersect_quadric<false, T>(probe, T(0.), T(S.isors_cy), T(S.isors_cz), T(S.isors_rad1), T(0.), true, true, tb, hitb, unused);
+        ok = !cone || hitb;
+        const VecT<T> p3 = vadd(p2, vscale(d2, tb));
+        pos = vselect(cone, vselect(hitb, p3, p2), pos);    // at the abort the ray sits beside the bottle
+        dir = vselect(cone, d2, dir);
+    }
+    T rr = T(0.) + draws.template peek_as<T>() * (T(S.isors_lens_r2) - T(0.));      // ranu(0., L1%radius**2)
+    draws.advance(ok);
+    T theta = draws.template peek_as<T>() * S.twopi;
+    draws.advance(ok);
+    T st, ct;
+    { const SinCosT<T> sc_ = sincos_v<T>(theta); st = sc_.s; ct = sc_.c; }
+    T sq = ORT_SQRT(rr);
+    T ex = sq * ct - pos.x, ey = sq * st - pos.y, ez = T(S.isors_lens_z) - pos.z;
+    T dist = ORT_SQRT(ex * ex + ey * ey + ez * ez);
+    const VecT<T> aimed = vnormalise(div3(VecT<T>{ex, ey, ez}, dist));
+    r.pos = pos;
+    r.dir = vselect(ok, aimed, dir);
+    return ok;
+}
+
 // emit_image + emit, src/sourceMod.f90:303-361: ray `ray` (serial order) starts in the histogram
 // cell s with cdf[s] <= ray < cdf[s+1] (binary search in the 2 MB table, L2-resident), at a
 // uniform point of the 9.8 um cell, aimed at a uniform point of the lens disc.  Returns false
@@ -1061,30 +1149,32 @@ __device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r
     return have;
 }
 
-// the phase's emitter (wave-uniform choice; src/main.f90:95-101, :132-142).  Returns false for
-// a ray the source cannot emit (image source exhausted).
+// the phase's emitter (wave-uniform choice; src/main.f90:95-101, :132-142).  Returns -1, or the
+// ORT_ST_* status of a ray the source cannot emit (image source exhausted: the reference re-uses a
+// stale ray; isors: the reference aborts).
 // ANYSRC = false instantiates only the two default emitters (ring for phase 1, point for phase
 // 2): the bulk kernels are compiled once for that case so that the rarely used emitters do not
 // cost registers (143 vs 121 VGPRs, i.e. 3 vs 4 waves per SIMD) on the path that is benchmarked.
 template <class T, bool ANYSRC, bool FILT = false, class Sys, class D>
-__device__ inline bool emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf, bool &rare)
+__device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf, bool &rare)
 {
     const int e = __builtin_amdgcn_readfirstlane(S.emitter[phase - 1]);
     if (!ANYSRC) {
         if (phase == 1) emit_ring<T, FILT>(S, r, draws, rare);
         else emit_point<T, FILT>(S, r, draws, rare);
-        return true;
+        return -1;
     }
     bool unused = false;                                  // the other emitters are literal throughout
     if (e == ORT_EMIT_RING) emit_ring<T>(S, r, draws, unused);
     else if (e == ORT_EMIT_POINT) emit_point<T>(S, r, draws, unused);
     else if (e == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray);
     else if (e == ORT_EMIT_CRS) emit_crs<T>(S, r, draws);
-    else return emit_image<T>(S, cdf, r, draws, ray);
-    return true;
+    else if (e == ORT_EMIT_ISORS) return emit_isors<T>(S, r, draws) ? -1 : ORT_ST_NO_INTERSECTION;
+    else return emit_image<T>(S, cdf, r, draws, ray) ? -1 : ORT_ST_LOST_TELESCOPE;
+    return -1;
 }
 template <class T, bool ANYSRC, class Sys, class D>
-__device__ inline bool emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf)
+__device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf)
 {
     bool unused = false;
     return emit<T, ANYSRC, false>(S, phase, r, draws, ray, cdf, unused);

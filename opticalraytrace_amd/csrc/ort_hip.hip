@@ -127,6 +127,12 @@ __host__ __device__ inline void convert_globals(SystemT<float> &dst, const ort_s
     dst.crs_sigma = (float)src.crs_sigma; dst.crs_radius = (float)src.crs_radius;
     dst.crs_cy = (float)src.crs_cy; dst.crs_cz = (float)src.crs_cz;
     dst.img_lens_r2 = (float)src.img_lens_r2; dst.img_lens_z = (float)src.img_lens_z;
+    dst.point_offset = (float)src.point_offset;
+    dst.isors_sigma = (float)src.isors_sigma; dst.isors_k = (float)src.isors_k; dst.isors_height = (float)src.isors_height;
+    dst.isors_base_pos = (float)src.isors_base_pos; dst.isors_z = (float)src.isors_z;
+    dst.isors_rad1 = (float)src.isors_rad1; dst.isors_rad2 = (float)src.isors_rad2;
+    dst.isors_cy = (float)src.isors_cy; dst.isors_cz = (float)src.isors_cz;
+    dst.isors_lens_r2 = (float)src.isors_lens_r2; dst.isors_lens_z = (float)src.isors_lens_z;
     dst.emitter[0] = src.emitter[0]; dst.emitter[1] = src.emitter[1];
 }
 inline void convert_system(SystemT<float> &dst, const ort_system &src)      // host
@@ -463,10 +469,11 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
             if (!have_in) {
                 const Draws d_none = d;
-                const bool emitted = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf);
-                st = emitted ? st : ORT_ST_LOST_TELESCOPE;
-                d.take(!emitted, d_none);                // an exhausted image source emits nothing and draws nothing
-                if (!emitted) r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(0.)}};
+                const int est = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf);
+                st = est < 0 ? st : est;
+                const bool exhausted = est == ORT_ST_LOST_TELESCOPE;
+                d.take(exhausted, d_none);               // an exhausted image source emits nothing and draws nothing
+                if (exhausted) r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(0.)}};
             }
             em = r;
             if (a.path) {
@@ -499,7 +506,10 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
         } else {
             KeyedDraws d;
             d.init_keyed(a.rng_base, a.first_ray + ic, have_in ? a.draw_base : 0);
-            if (!have_in && !emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf)) st = ORT_ST_LOST_TELESCOPE;
+            if (!have_in) {
+                const int est = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf);
+                st = est < 0 ? st : est;
+            }
             const RayT<T> r0 = r;
             const KeyedDraws d0 = d;
             const int st0 = st;
@@ -690,7 +700,8 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 r.dir = {T(a.pos_dir_in[3 * ns_in + ic]), T(a.pos_dir_in[4 * ns_in + ic]), T(a.pos_dir_in[5 * ns_in + ic])};
             } else {
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                if (!emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare)) st = ORT_ST_LOST_TELESCOPE;
+                const int est = emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
+                st = est < 0 ? st : est;
             }
             if constexpr (fixed) walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split, false>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
             else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
@@ -780,7 +791,7 @@ int check_system(const ort_system *sys)
                 return fail(ORT_E_INVALID, "the image plane must be the last surface, and only the last");
         }
         if (sys->split[p] < 0 || sys->split[p] > n) return fail(ORT_E_INVALID, "split out of range");
-        if (sys->emitter[p] < ORT_EMIT_RING || sys->emitter[p] > ORT_EMIT_IMAGE) return fail(ORT_E_INVALID, "bad emitter");
+        if (sys->emitter[p] < ORT_EMIT_RING || sys->emitter[p] > ORT_EMIT_ISORS) return fail(ORT_E_INVALID, "bad emitter");
     }
     return ORT_OK;
 }

@@ -1,13 +1,14 @@
-"""Experiment sweeps of the reference's `runner.py` that stay on the hot path.
+"""Experiment sweeps of the reference's `runner.py`.
 
-    python -m opticalraytrace_amd.sweeps -p -i -o -l [--nphotons N] [--data-dir DIR]
+    python -m opticalraytrace_amd.sweeps -s -p -b -i -o -l --isors [--nphotons N] [--data-dir DIR]
 
 Same flags, same loops, same settings defaults and the same `data/<folder>/` outputs as
-runner.py (`-p` :136-155, `-i` :158-186, `-o` :189-208, `-l` :232-261); every simulation is
-one `run_settings` call on ONE reused GPU context instead of one
-`./install.sh -n 32 -f <settings>` process (runner.py:26-47).  `-s` (spot diagrams: spot source
-+ ray-path tracker dumps, runner.py:113-133) is supported too; `-b` (Bessel image source) and
-the iSORS comparison use emitters outside this path and are refused with a message.
+runner.py (`-s` :113-133, `-p` :136-155, `-b` :209-228, `-i` :158-186, `-o` :189-208, `-l` :232-261,
+and `iSORS_vs_Bessel` :267-320, which runner.py defines but wires to no flag: `--isors` here);
+every simulation is one `run_settings` call on ONE reused GPU context instead of one
+`./install.sh -n 32 -f <settings>` process (runner.py:26-47).  `-b` needs the Bessel image
+`bessel-smear.dat` (bpm.py's output, not shipped by the reference) in the res directory and fails
+with a clear message without it.
 """
 from __future__ import annotations
 
@@ -73,6 +74,58 @@ class Sweep:
             self.run(f"test_{i}.params", light_source="point", make_images=True,
                      bottle_file=bottle, use_bottle=use, data_folder="images")
 
+    def bessel_images(self, bottles=BOTTLES) -> None:      # -b, runner.py:209-228
+        from .params import ParamsError
+        src = os.path.join(self.res_dir, Settings().image_source)
+        if not os.path.exists(src):
+            raise ParamsError(f"{src}: the image source file (bpm.py's Bessel beam, 512 x 512 float64) is "
+                              "missing — the reference opens it with status='old' (src/sourceMod.f90:381)")
+        for i, (bottle, use) in enumerate(bottles):
+            self.run(f"test_{i}.params", light_source="image", make_images=True,
+                     bottle_file=bottle, use_bottle=use, data_folder="images")
+
+    def isors_vs_bessel(self) -> None:                     # iSORS_vs_Bessel, runner.py:267-320
+        """isors source against the point source with the bottle moved so that the Bessel ring has
+        the same spatial offset; 7 offsets 0 ... 1.5 mm each."""
+        import math
+        ring_width, alpha_deg, n_axicon, l2_file = 0.5e-3, 5.0, 1.45, "planoConvex-f39.9mm.params"
+        from .params import GlassBottle, PlanoConvex
+        l2fb = PlanoConvex.from_file(os.path.join(self.res_dir, l2_file), 785e-9).fb
+        # runner.py reads radius a from clearBottle-small_0.0mm.params — a 14-line file the reference's
+        # own reader cannot open (SURVEY quirk 18); the same bottle is clearBottle-small.params
+        bottle0 = "clearBottle-small_0.0mm.params"
+        if not os.path.exists(os.path.join(self.res_dir, bottle0)):
+            bottle0 = "clearBottle-small.params"
+        radius_a = GlassBottle.from_file(os.path.join(self.res_dir, bottle0), 785e-9).radiusa
+        alpha = alpha_deg * math.pi / 180.0
+        init_dist = 97.3e-3                                # distance from axicon to L1 (runner.py:295)
+        common = dict(use_tracker=False, make_images=True, image_diameter=1e-2, data_folder="iSORS_vs_Bessel",
+                      use_bottle=True, ring_width=ring_width, alpha=alpha_deg, n_axicon=n_axicon, L2_file=l2_file)
+        k = 0
+        for source in ("isors", "point"):
+            for j in range(7):
+                offset = 1.5e-3 * j / 6.0                  # np.linspace(0., 1.5e-3, 7)
+                if source == "isors":
+                    bottle = bottle0
+                else:                                      # create_bottle_file(prop_offset), runner.py:322-347
+                    prop = (l2fb * (offset + ring_width)) / (init_dist * math.tan(alpha * (n_axicon - 1))) - radius_a
+                    bottle = self._isors_bottle_file(prop, j)
+                self.run(f"test_{k}.params", light_source=source, isors_offset=offset, bottle_file=bottle, **common)
+                k += 1
+
+    def _isors_bottle_file(self, z: float, j: int) -> str:
+        """clearBottle-small_iSORS.params of runner.py:322-347, written next to the outputs (the
+        packaged res directory is not touched; one file per offset, so that the kept settings files
+        stay runnable); an absolute path, which the readers accept."""
+        lines = ["2.d-3", "17.5d-3", "17.5d-3", "0.0", "0.0", repr(float(z)), "1.5130", "0.003169", "0.003962",
+                 "1.35265", "0.00306", "0.00002"]
+        d = os.path.abspath(self.settings_dir or self.data_dir)
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, f"clearBottle-small_iSORS_{j}.params")
+        with open(path, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        return path
+
     def iris_experiment(self, bottles=BOTTLES) -> None:    # -i, runner.py:158-186
         for i, (bottle, use) in enumerate(bottles):
             for iris in IRISES:
@@ -110,7 +163,8 @@ def main(argv: Optional[Iterable[str]] = None) -> int:
                                  formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("-s", "--spot", action="store_true", help="Create spot diagrams.")
     ap.add_argument("-p", "--point", action="store_true", help="Create point/ring images.")
-    ap.add_argument("-b", "--bessel", action="store_true", help="(not on this path)")
+    ap.add_argument("-b", "--bessel", action="store_true", help="Create bessel/ring diagrams.")
+    ap.add_argument("--isors", action="store_true", help="iSORS vs Bessel comparison (runner.py iSORS_vs_Bessel).")
     ap.add_argument("-o", "--offset", action="store_true", help="Run offset experiment on large bottle.")
     ap.add_argument("-i", "--iris", action="store_true", help="Run iris experiment on bottles.")
     ap.add_argument("-l", "--lens", action="store_true", help="Run lens experiments.")
@@ -120,12 +174,19 @@ def main(argv: Optional[Iterable[str]] = None) -> int:
     ap.add_argument("--res-dir", default=None)
     ap.add_argument("--device", type=int, default=0)
     args = ap.parse_args(argv)
-    if args.bessel:
-        print("-b needs the image emitter (SURVEY §8 f2): not on the MI355X hot path", file=sys.stderr)
-        return 2
     sw = Sweep(args.nphotons, args.res_dir, args.data_dir, args.device, verbose=True,
                settings_dir=os.path.join(args.data_dir, "settings"))
+    from .params import ParamsError
     try:
+        if args.bessel or args.all:
+            try:
+                sw.bessel_images()
+            except ParamsError as e:
+                print(f"-b: {e}", file=sys.stderr)
+                if not args.all:
+                    return 2
+        if args.isors:
+            sw.isors_vs_bessel()
         if args.spot or args.all:
             sw.spot_diagrams()
         if args.point or args.all:

@@ -97,11 +97,8 @@ class OpticalSystem:
     def from_settings(cls, settings: Settings, res_dir: Optional[str] = None) -> "OpticalSystem":
         res_dir = res_dir or resource_dir()
         s = settings
-        if s.light_source not in ("point", "spot", "crs", "image"):
-            # `isors` aborts in the reference itself (`error stop "no intersection with bottle!"`,
-            # src/sourceMod.f90:217) as soon as one ray reflects at the axicon (2.8 % per ray).
-            raise ParamsError(f"light source {s.light_source!r} is not implemented on the "
-                              "MI355X path (point, spot, crs and image are)")
+        if s.light_source not in ("point", "spot", "crs", "image", "isors"):
+            raise ParamsError("No such source type!")              # setupMod.f90:98
         wl = s.wavelength
         bottle = GlassBottle.from_file(os.path.join(res_dir, s.bottle_file), wl)
         L2, L3 = [], []
@@ -122,7 +119,10 @@ class OpticalSystem:
         if a.fb <= bottle.radiusa + bottle.centre[2]:          # main.f90:54-58
             bottle.centre[2] = a.fb - bottle.radiusa - 2e-3
             moved = True
-        distance = bottle.radiusa + bottle.centre[2]           # main.f90:63 (not isors)
+        if s.light_source == "isors":                          # main.f90:60-64
+            distance = bottle.radiusa + s.isors_offset
+        else:
+            distance = bottle.radiusa + bottle.centre[2]
         bessel = distance * L1_FB * math.tan(alpha * (s.n_axicon - 1)) / a.fb   # main.f90:66
         r1 = bessel - s.ring_width                             # main.f90:68-70
         half = bessel / 2.0

@@ -58,7 +58,8 @@ class OrcSystem(C.Structure):
                [("img_counts", C.POINTER(C.c_int32))]
 
 
-SOURCE_CODES = {"point": 0, "spot": 1, "crs": 2, "image": 4}
+SOURCE_CODES = {"point": 0, "spot": 1, "crs": 2, "isors": 3, "image": 4}
+ISORS_NO_RING = 5      # test-only source code: iSORS(ring = .false.) in phase 1 (pins bottle_backward_sub)
 
 
 def build_oracle(force: bool = False) -> str:
@@ -112,7 +113,7 @@ def _ip(a):
 
 
 class Oracle:
-    def __init__(self, osys=None):
+    def __init__(self, osys=None, source_override=None):
         self.lib = C.CDLL(build_oracle())
         L = self.lib
         L.orc_sellmeier.restype = C.c_double
@@ -129,6 +130,8 @@ class Oracle:
                                 _IP, C.POINTER(C.c_uint64), C.c_int]
         L.orc_init_emit_image.argtypes = [_DP, C.c_int32, C.c_uint64, _IP]
         self.sys = fill_system(osys) if osys is not None else None
+        if source_override is not None:
+            self.sys.source = source_override
         self._counts = None
         if osys is not None and osys.settings.light_source == "image":
             # the oracle builds its own histogram from the image file (its own init_emit_image)
@@ -176,7 +179,7 @@ def reference_available() -> bool:
 class Reference:
     """The reference's own Fortran path (oracle/_ref/libort_ref.so)."""
 
-    def __init__(self, settings, res_dir: str, image_seed: int = 123456789):
+    def __init__(self, settings, res_dir: str, image_seed: int = 123456789, source_override=None):
         self.lib = C.CDLL(REF_SO)
         L = self.lib
         L.ortref_init.restype = C.c_int
@@ -196,8 +199,8 @@ class Reference:
                            s.fibre_offset, iris_mode, s.iris_size, int(s.use_bottle))
         assert rc == 0
         L.ortref_set_source.argtypes = [C.c_int, C.c_int] + [C.c_double] * 5
-        L.ortref_set_source(SOURCE_CODES[s.light_source], s.nphotons, s.isors_offset, s.crs_spot_size,
-                            s.alpha, s.n_axicon, s.ring_width)
+        L.ortref_set_source(source_override if source_override is not None else SOURCE_CODES[s.light_source],
+                            s.nphotons, s.isors_offset, s.crs_spot_size, s.alpha, s.n_axicon, s.ring_width)
         self.counts = None
         if s.light_source == "image":
             L.ortref_image_source.argtypes = [C.c_char_p, C.c_int, C.c_int64, _IP]

@@ -73,6 +73,9 @@ static void rang(draws_t *d, double *x, double *y, double avg, double sigma)
 }
 
 static const double PI_F = 3.14159265358979323846;   /* 4.*atan(1.), src/constants.f90:5 */
+/* sin / cos of iSORS' lens-point angle (src/sourceMod.f90:229-230): separate calls, see emit_ring for
+ * the one pair flang lowers to sincos() */
+#define ISORS_SINCOS(x, s, c) do { *(c) = cos(x); *(s) = sin(x); } while (0)
 
 /* ------------------------------------------------------- vector_class ---- */
 static inline orc_vec v(double x, double y, double z) { orc_vec r = {x, y, z}; return r; }
@@ -155,6 +158,20 @@ static int intersect_ellipse(orc_vec orig, orc_vec dir, double *t, orc_vec centr
     double a = semia2div * (dir.z * dir.z) + semib2div * (dir.y * dir.y);
     double b = 2 * (semia2div * dir.z * L.z + semib2div * dir.y * L.y);
     double c = semia2div * (L.z * L.z) + semib2div * (L.y * L.y) - 1;
+    double t0, t1;
+    if (!solveQuadratic(a, b, c, &t0, &t1)) return 0;
+    return pick_root(t0, t1, t);
+}
+
+/* intersect_cone, src/surfaces.f90:179-224 — apex up, axis along z, `centre` under the apex at the base */
+static int intersect_cone(orc_vec orig, orc_vec dir, double *t, orc_vec centre, double radius, double height)
+{
+    double k = radius / height;
+    k = k * k;
+    orc_vec L = vsub(orig, centre);
+    double a = dir.x * dir.x + dir.y * dir.y - (k * (dir.z * dir.z));
+    double b = 2. * ((dir.x * L.x) + (dir.y * L.y) - (k * dir.z * (L.z - height)));
+    double c = L.x * L.x + L.y * L.y - (k * ((L.z - height) * (L.z - height)));
     double t0, t1;
     if (!solveQuadratic(a, b, c, &t0, &t1)) return 0;
     return pick_root(t0, t1, t);
@@ -552,6 +569,90 @@ static void emit_crs(const orc_system *S, orc_vec *pos, orc_vec *dir, draws_t *d
     *dir = v(sint * cosp, sint * sinp, cost);
 }
 
+/* bottle_backward_sub, src/lens.f90:352-423: air -> glass -> contents, from outside.  Reached only
+ * from iSORS(ring = .false.), which no call site of the reference uses (src/main.f90:97 passes
+ * .true., :141 is commented out); restated and pinned for completeness.  Returns skip. */
+static int bottle_backward(const orc_bottle *B, orc_vec *pos, orc_vec *dir, draws_t *d)
+{
+    double t;
+    int flag;
+    orc_vec orig, normal;
+    if (B->ellipse) flag = intersect_ellipse(*pos, *dir, &t, B->centre, B->radiusa, B->radiusb);
+    else flag = intersect_cylinder(*pos, *dir, &t, B->centre, B->radiusa);
+    if (!flag) return 1;
+    *pos = vadd(*pos, vscale(*dir, t));
+    orig = *pos;
+    orig.x = B->centre.x;
+    normal = vmagnitude(vsub(orig, B->centre));
+    reflect_refract(dir, normal, 1., B->nbottle, &flag, d);
+    if (flag) return 1;
+    if (B->ellipse) flag = intersect_ellipse(*pos, *dir, &t, B->centre, B->radiusa - B->thickness, B->radiusb - B->thickness);
+    else flag = intersect_cylinder(*pos, *dir, &t, B->centre, B->radiusa - B->thickness);
+    if (!flag) return 1;
+    *pos = vadd(*pos, vscale(*dir, t));
+    orig = *pos;
+    orig.x = B->centre.x;
+    normal = vmagnitude(vsub(orig, B->centre));
+    reflect_refract(dir, normal, B->nbottle, B->ncontents, &flag, d);
+    return flag ? 1 : 0;
+}
+
+/* iSORS, src/sourceMod.f90:162-247: Gaussian beam through an axicon (a cone of glass, n = 1.4),
+ * carried to the bottle, then aimed at a random point of the lens.  ring = 1 is what src/main.f90:97
+ * calls.  Returns 0 where the reference aborts — `error stop "no intersection with bottle!"`
+ * (:216-218): the beam reflected at the axicon (2.8 % of the rays) and flies away from the bottle —
+ * having drawn nothing further; the caller counts the ray as lost (ORC_NO_INTERSECTION). */
+static int emit_isors(const orc_system *S, orc_vec *pos, orc_vec *dir, draws_t *d, int ring)
+{
+    const double twopi = 2. * PI_F;
+    const orc_bottle *B = &S->bottle;
+    const orc_plano *L1 = &S->L2[0];
+    const double axicon_n = 1.4, radius = 12.7e-3, height = 1.1e-3;
+    double alpha = atan(height / radius);
+    double k = (radius / height) * (radius / height);
+    double base_pos = (S->isors_offset + S->ring_width) / tan(alpha * (axicon_n - 1.));
+    orc_vec centre = v(0., 0., 0.);
+    double posx, posy, t;
+    int flag;
+    rang(d, &posx, &posy, 0., S->ring_width);
+    *pos = vadd(centre, v(posx, posy, 2 * height));
+    *dir = v(0., 0., -1.);
+    flag = intersect_cone(*pos, *dir, &t, centre, radius, height);
+    if (flag) {
+        *pos = vadd(*pos, vscale(*dir, t));
+        orc_vec normal = v(2 * (pos->x - centre.x) / k, 2 * (pos->y - centre.y) / k,
+                           -(2 * (pos->z - centre.z)) + 2 * height);
+        normal = vscale(normal, -1.);
+        normal = vmagnitude(normal);
+        reflect_refract(dir, normal, axicon_n, 1., &flag, d);
+        t = base_pos / dir->z;
+        *pos = vadd(*pos, vscale(*dir, t));
+        pos->z = B->radiusa + B->centre.z + 0x1p-52;          /* epsilon(1.) of a real*8 */
+        if (ring) {
+            if (B->ellipse) flag = intersect_ellipse(*pos, *dir, &t, B->centre, B->radiusa - B->thickness, B->radiusb - B->thickness);
+            else flag = intersect_cylinder(*pos, *dir, &t, B->centre, B->radiusa - B->thickness);
+            if (!flag) return 0;
+            *pos = vadd(*pos, vscale(*dir, t));
+        } else {
+            (void)bottle_backward(B, pos, dir, d);            /* skip is not looked at */
+            t = (B->centre.z - pos->z) / dir->z;
+            *pos = vadd(*pos, vscale(*dir, t));
+        }
+    }
+    double r = ring ? ranu(d, 0., L1->radius * L1->radius) : ranu(d, 0., (L1->radius + 10e-3) * (L1->radius + 10e-3));
+    double theta = ran2(d) * twopi;
+    double st, ct;
+    ISORS_SINCOS(theta, &st, &ct);
+    posx = sqrt(r) * ct;
+    posy = sqrt(r) * st;
+    orc_vec lp = v(posx, posy, L1->fb);
+    double ex = lp.x - pos->x, ey = lp.y - pos->y, ez = lp.z - pos->z;
+    double dist = sqrt(ex * ex + ey * ey + ez * ez);
+    *dir = v((lp.x - pos->x) / dist, (lp.y - pos->y) / dist, (lp.z - pos->z) / dist);
+    *dir = vmagnitude(*dir);
+    return 1;
+}
+
 /* init_emit_image, src/sourceMod.f90:363-408 */
 void orc_init_emit_image(const double *img, int32_t nphotons, uint64_t seed, int32_t *counts_scan)
 {
@@ -692,11 +793,15 @@ static int one_ray(const orc_system *S, int phase, int have_in, orc_vec *pos, or
     if (!have_in) {
         if (phase == 1) {                                   /* main.f90:95-101 */
             if (S->source == 2) emit_crs(S, pos, dir, d);
+            else if (S->source == 3 || S->source == 5) {       /* 5: iSORS(ring = .false.), test-only */
+                if (!emit_isors(S, pos, dir, d, S->source == 3)) { *epos = *pos; *edir = *dir; return ORC_NO_INTERSECTION; }
+            }
             else emit_ring(S, pos, dir, d);
         } else {                                            /* main.f90:132-142 */
             if (S->source == 4) {
                 if (!emit_image_ray(S, cdf, iray, pos, dir, d)) { *epos = *pos; *edir = *dir; return ORC_LOST_TELESCOPE; }
             } else if (S->source == 1) emit_spot(S->cosThetaMax, S->nphotons, (int)(iray + 1), pos, dir);
+            else if (S->source == 3) emit_point(S->cosThetaMax, S->bottle.centre.z, pos, dir, d);   /* main.f90:140 */
             else emit_point(S->cosThetaMax, 0.0, pos, dir, d);
         }
     }

@@ -52,9 +52,11 @@ typedef struct {
     orc_bottle  bottle;
     double cosThetaMax, r1, r2, img_plane, fibre_offset, image_diameter, iris_radius;
     int32_t iris_before, iris_after, use_bottle;
-    /* light source (src/setupMod.f90:85-99): 0 point, 1 spot, 2 crs.  (isors: the reference
-     * aborts — `error stop "no intersection with bottle!"`, src/sourceMod.f90:217 — as soon as a
-     * ray reflects at the axicon, 2.8 % per ray; not restated.) */
+    /* light source (src/setupMod.f90:85-99): 0 point, 1 spot, 2 crs, 3 isors, 4 image.  isors: the
+     * reference aborts — `error stop "no intersection with bottle!"`, src/sourceMod.f90:217 — as
+     * soon as a ray reflects at the axicon (2.8 % per ray); here that ray ends with
+     * ORC_NO_INTERSECTION and is counted as lost.  5 = iSORS(ring = .false.) in phase 1: a variant
+     * no call site of the reference uses, restated to pin bottle_backward_sub (tests only). */
     int32_t source;
     int32_t nphotons, pad2;        /* create_spot needs the loop length (src/main.f90:138) */
     double isors_offset, ring_width, spot_size;   /* spot_size after src/setupMod.f90:136 */
@@ -71,7 +73,7 @@ enum {
     ORC_LOST_BOTTLE = 3,     /* skip in bottle%forward (counted, phase 2) */
     ORC_LOST_TELESCOPE = 4,  /* skip in telescope (counted) */
     ORC_HELP3 = 5,           /* doublet face 3 missed: reference aborts (lens.f90:617) */
-    ORC_NO_INTERSECTION = 6  /* tauint found no cylinder crossing: reference aborts (surfaces.f90:38) */
+    ORC_NO_INTERSECTION = 6  /* tauint (surfaces.f90:38) or iSORS (sourceMod.f90:217) found no bottle crossing: reference aborts */
 };
 
 /* counters[8]: 0 lost ring (rcount), 1 lost point (pcount), 2 intersections ring,

@@ -31,7 +31,7 @@ module ortref_api
     type(glass_bottle),       save :: bot
     real,    save :: cosThetaMax, r1, r2, img_plane_1, img_diam, besselDiameter, distance
     logical, save :: use_bottle_s
-    ! source type: 0 point, 1 spot, 2 crs, 3 isors (setupMod.f90:85-99)
+    ! source type: 0 point, 1 spot, 2 crs, 3 isors (setupMod.f90:85-99); 5 = iSORS(ring=.false.) (tests)
     integer, save :: source_s = 0, nphotons_s = 100
     real,    save :: isors_offset_s = 0., ring_width_s = 0., spot_size_s = 0.
     ! image source (source_s == 4): histogram built by init_emit_image, and the working copy
@@ -127,7 +127,7 @@ contains
         offset = bot%radiusa + bot%centre%z                         ! setupMod.f90:135
         spot_size_s = (crs_spot_size*(L2a%fb - offset)) / L2a%fb    ! setupMod.f90:136
         alpha = alpha_deg * pi / 180.
-        if (source == 3) then                                       ! main.f90:60-64
+        if (source == 3 .or. source == 5) then                      ! main.f90:60-64
             distance = bot%radiusa + isors_offset
         else
             distance = (bot%radiusa + bot%centre%z)
@@ -206,6 +206,8 @@ contains
             if (.not. have_in) then                                          ! main.f90:95-101
                 if (source_s == 3) then
                     call iSORS(pos, dir, bot, L2a, isors_offset_s, ring_width_s, .true.)
+                elseif (source_s == 5) then        ! test-only: the variant no call site of main.f90 uses
+                    call iSORS(pos, dir, bot, L2a, isors_offset_s, ring_width_s, .false.)
                 elseif (source_s == 2) then
                     call point_on_bottle(pos, dir, cosThetaMax, bot, spot_size_s)
                 else
@@ -313,6 +315,8 @@ contains
             if (phase == 1) then
                 if (source_s == 3) then
                     call iSORS(pos, dir, bot, L2a, isors_offset_s, ring_width_s, .true.)
+                elseif (source_s == 5) then        ! test-only: the variant no call site of main.f90 uses
+                    call iSORS(pos, dir, bot, L2a, isors_offset_s, ring_width_s, .false.)
                 elseif (source_s == 2) then
                     call point_on_bottle(pos, dir, cosThetaMax, bot, spot_size_s)
                 else

@@ -55,6 +55,8 @@ CONFIGS = {
     # SURVEY §8 f2 emitters: spot (create_spot, runner.py -s uses 100 rays) and crs (point_on_bottle)
     "small_spot": dict(bottle_file="clearBottle-small.params", light_source="spot", nphotons=100),
     "large_crs": dict(bottle_file="clearBottle-large.params", light_source="crs", crs_spot_size=1e-3),
+    # isors (iSORS: Gaussian beam through an axicon onto the bottle, src/sourceMod.f90:162-247)
+    "small_isors": dict(bottle_file="clearBottle-small.params", light_source="isors", isors_offset=0.5e-3),
     # image source (emit_image): a synthetic integer-valued 512 x 512 source image, see source_image()
     "large_image": dict(bottle_file="clearBottle-large.params", light_source="image",
                         image_source="synthetic-source.dat", nphotons=60000),
@@ -66,6 +68,21 @@ CONFIGS = {
 
 SCATTER_BOTTLES = {"scatterBottle-contents.params": [0.0, 0.0, 20.0, 150.0],
                    "scatterBottle-both.params": [10.0, 300.0, 5.0, 80.0]}
+
+
+def isors_safe_uniforms(u, rng):
+    """Make a uniform table safe for the UNMODIFIED iSORS of the reference: a ray that reflects at
+    the axicon runs into `error stop "no intersection with bottle!"` (src/sourceMod.f90:216-218),
+    which would end the test process.  rang's first pair is put inside the unit disc (so the axicon
+    draw is draw 2) and draw 2 is kept above 0.5 (the axicon's reflectance is ~0.03): every ray
+    refracts.  The reflecting rays are exercised oracle-vs-HIP only (the reference has no
+    behaviour to offer for them)."""
+    import numpy as np
+    n = u.shape[1]
+    r, th = np.sqrt(rng.random(n)) * 0.999, rng.random(n) * 2 * np.pi
+    u[0], u[1] = (r * np.cos(th) + 1) / 2, (r * np.sin(th) + 1) / 2
+    u[2] = 0.5 + 0.5 * rng.random(n)
+    return u
 
 
 def source_image():

@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(HERE))
 
-from conftest import CONFIGS, needs_extended_res, res_dir_with_image  # noqa: E402
+from conftest import CONFIGS, isors_safe_uniforms, needs_extended_res, res_dir_with_image  # noqa: E402
 from opticalraytrace_amd.params import Settings  # noqa: E402
 from oracle.binding import Reference  # noqa: E402
 
@@ -41,7 +41,8 @@ N_RAYS = 192
 # draws the emitter of (source, phase) consumes; None = variable (crs phase 1: explicit-input
 # re-trace starts at draw 0 of a FRESH table row set instead)
 EMIT_DRAWS = {("point", 1): 4, ("point", 2): 2, ("spot", 1): 4, ("spot", 2): 0,
-              ("crs", 1): 0, ("crs", 2): 2, ("image", 1): 4, ("image", 2): 4}
+              ("crs", 1): 0, ("crs", 2): 2, ("image", 1): 4, ("image", 2): 4,
+              ("isors", 1): 0, ("isors", 2): 2}
 N_IMAGE = 100000
 SEED = 123456789          # src/main.f90:79
 
@@ -55,8 +56,10 @@ def main():
         out = {"constants": ref.constants()[:47]}
         rng = np.random.default_rng(1000 + ci)
         for phase in (1, 2):
-            n_draws = 160 if s.bottle_file.startswith("scatterBottle") else (48 if s.light_source == "crs" else 16)
+            n_draws = 160 if s.bottle_file.startswith("scatterBottle") else (48 if s.light_source in ("crs", "isors") else 16)
             u = rng.random((n_draws, n_rays))
+            if s.light_source == "isors" and phase == 1:
+                u = isors_safe_uniforms(u, rng)     # the unmodified iSORS aborts the process on a reflection
             # force both Fresnel branches on some rays (u=0 reflects, u->1 refracts)
             if s.light_source == "point":
                 u[4:9, :8] = 0.0
@@ -88,6 +91,17 @@ def main():
                 lost = int((rb["status"] >= 3).sum())
                 out["img2_u_seed"] = np.int64(77)
                 out["imgin_counts"] = ref.counts
+            elif s.light_source == "isors" and phase == 1:
+                # a keyed run would hit the reference's `error stop` at the first reflecting ray
+                # (2.8 % per ray): the fixture holds the image of table-mode rays that all refract
+                rs = np.random.default_rng(78)
+                ub = isors_safe_uniforms(rs.random((48, n_image)), rs)
+                rb = ref.trace_rays(1, n_image, u=ub)
+                img = np.zeros((2, 401, 401), np.int32)
+                ok = rb["status"] == 0
+                np.add.at(img[0], (rb["bin_xy"][1][ok] + 200, rb["bin_xy"][0][ok] + 200), 1)
+                lost = int((rb["status"] >= 3).sum())
+                out["img1_u_seed"] = np.int64(78)
             else:
                 img, lost = ref.trace(phase, 0, n_image, SEED)
             flat = img.reshape(-1)

@@ -56,7 +56,8 @@ def assert_rays_equal(got, want, exact=True, what=""):
 # draws the emitter of (light source, phase) consumes before the first surface
 # (crs phase 1 draws a variable number: its explicit-input fixtures restart at draw 0)
 EMIT_DRAWS = {("point", 1): 4, ("point", 2): 2, ("spot", 1): 4, ("spot", 2): 0,
-              ("crs", 1): 0, ("crs", 2): 2, ("image", 1): 4, ("image", 2): 4}
+              ("crs", 1): 0, ("crs", 2): 2, ("image", 1): 4, ("image", 2): 4,
+              ("isors", 1): 0, ("isors", 2): 2}
 
 
 def emit_draws(settings, phase):

@@ -49,7 +49,7 @@ def test_fortran_mirror_of_the_header_compiles_and_agrees(tmp_path, hip_library)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     got = dict(ln.split() for ln in out.stdout.splitlines() if ln.strip())
-    assert got["sizeof_surface"] == "112" and got["sizeof_system"] == "2888"      # include/ort.h
-    assert got["abi"] == "1"
+    assert got["sizeof_surface"] == "112" and got["sizeof_system"] == "2984"      # include/ort.h
+    assert got["abi"] == "2"
     assert got["create_rc"] == "-1" and got["ctx_null"] == "T"                     # ORT_E_INVALID, *out left null
     assert got["destroy_null_rc"] == "0"

@@ -65,3 +65,81 @@ def test_repeated_runs_are_ordered_with_torch_resets(hip_library):
             assert np.array_equal(r.image, first.image)
     finally:
         t.close()
+
+
+def test_isors_and_bessel_sweeps(hip_library, tmp_path):
+    """runner.py's iSORS_vs_Bessel loop (:267-320: isors source vs the point source with the bottle
+    moved to the same ring offset, 7 offsets each) and `-b` (:209-228, image source) on the GPU path;
+    a sample against the oracle, the reflecting isors rays counted where the reference aborts."""
+    import shutil
+    from conftest import res_dir_with_image
+    from opticalraytrace_amd.params import ParamsError, resource_dir
+    from opticalraytrace_amd.sweeps import Sweep
+    from opticalraytrace_amd.system import OpticalSystem
+    from oracle.binding import Oracle
+    n = 30000
+    sw = Sweep(nphotons=n, data_dir=str(tmp_path), settings_dir=str(tmp_path / "settings"))
+    try:
+        sw.isors_vs_bessel()
+        assert len(sw.results) == 14
+        with pytest.raises(ParamsError):                     # the packaged res/ holds no Bessel image
+            sw.bessel_images()
+    finally:
+        sw.close()
+    assert [s.light_source for _, s, _ in sw.results] == ["isors"] * 7 + ["point"] * 7
+    assert len(open(tmp_path / "iSORS_vs_Bessel" / "trans-stats.dat").read().splitlines()) == 15
+    for name, s, res in sw.results[::3]:
+        osys = OpticalSystem.from_settings(s, resource_dir())
+        orc = Oracle(osys)
+        img = np.zeros((2, 401, 401), np.int32); cnt = np.zeros(8, np.uint64)
+        orc.trace(1, 0, n, SEED, img, cnt); orc.trace(2, 0, n, SEED, img, cnt)
+        assert np.abs(res.image.astype(np.int64) - img).sum() <= 6, name
+        assert np.abs(res.counters.astype(np.int64) - cnt.astype(np.int64)).max() <= 3, name
+    # the isors ring moves outwards with the offset: its transmission through the fixed optics changes
+    t = [r.ring_transmitted for _, s, r in sw.results[:7]]
+    assert len(set(t)) > 3
+    # -b with an image source file present (the tests' synthetic stand-in for bpm.py's output)
+    res = res_dir_with_image(resource_dir())
+    shutil.copy(os.path.join(res, "synthetic-source.dat"), os.path.join(res, "bessel-smear.dat"))
+    sw = Sweep(nphotons=n, res_dir=res, data_dir=str(tmp_path / "b"))
+    try:
+        sw.bessel_images()
+        assert len(sw.results) == 4 and all(s.light_source == "image" for _, s, _ in sw.results)
+        # (the elliptical bottle transmits nothing from this source plane: all rays end in its wall, as in the oracle)
+        assert [r.image[1].sum() > 0 for _, _, r in sw.results] == [True, True, False, True]
+    finally:
+        sw.close()
+
+
+def test_isors_keyed_rays_vs_oracle(hip_library):
+    """Keyed isors rays, the ~3 % that reflect at the axicon included: per-ray outcome, draw count
+    and state against the oracle (ORT_ST_NO_INTERSECTION where the reference would abort), and
+    the images of both loops."""
+    from conftest import make_system
+    from opticalraytrace_amd.capi import Context
+    from oracle.binding import Oracle
+    _, osys = make_system("small_isors")
+    orc = Oracle(osys)
+    n = 40000
+    with Context(osys) as ctx:
+        for phase in (1, 2):
+            want = orc.trace_rays(phase, n, seed=SEED, first_ray=7)
+            got = ctx.trace_rays(phase, n, seed=SEED, first_ray=7)
+            assert np.array_equal(got["n_draws"], want["n_draws"])
+            assert (got["status"] != want["status"]).sum() <= 2
+            same = got["status"] == want["status"]
+            for k in (0, 3):
+                w = want["emitted"][k:k + 3]
+                scale = np.maximum(np.sqrt((w * w).sum(0)), 1e-300)
+                assert (np.abs(got["emitted"][k:k + 3] - w) / scale)[:, same].max() <= 1e-12
+            if phase == 1:
+                gone = want["status"] == 6
+                assert 0.02 < gone.mean() < 0.04 and np.array_equal(got["status"] == 6, gone)
+        ctx.reset()
+        ctx.trace(1, 0, n, SEED)
+        ctx.trace(2, 0, n, SEED)
+        img, cnt = ctx.read()
+    wimg = np.zeros((2, 401, 401), np.int32); wc = np.zeros(8, np.uint64)
+    orc.trace(1, 0, n, SEED, wimg, wc); orc.trace(2, 0, n, SEED, wimg, wc)
+    assert np.abs(img.astype(np.int64) - wimg).sum() <= 6
+    assert np.abs(cnt.astype(np.int64) - wc.astype(np.int64)).max() <= 3

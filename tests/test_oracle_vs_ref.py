@@ -6,7 +6,7 @@ Nothing here reads /root/reference at run time: the packaged .params files are u
 import numpy as np
 import pytest
 
-from conftest import CONFIGS, make_system, needs_extended_res, res_dir_with_image
+from conftest import CONFIGS, isors_safe_uniforms, make_system, needs_extended_res, res_dir_with_image
 from parity import emit_draws, merge_status
 from oracle.binding import Oracle, Reference, reference_available
 from opticalraytrace_amd.params import resource_dir
@@ -21,8 +21,11 @@ def test_oracle_equals_reference_bit_for_bit(name):
     ref = Reference(settings, res)
     orc = Oracle(osys)
     n = min(settings.nphotons, 30000)
-    u = np.random.default_rng(sum(map(ord, name))).random((160, n))
+    rng = np.random.default_rng(sum(map(ord, name)))
+    u = rng.random((160, n))
     for phase in (1, 2):
+        if settings.light_source == "isors" and phase == 1:
+            u = isors_safe_uniforms(u, rng)          # the unmodified iSORS would `error stop` on a reflection
         a = orc.trace_rays(phase, n, u=u)
         b = ref.trace_rays(phase, n, u=u)
         assert np.array_equal(merge_status(a["status"]), b["status"]), (name, phase)
@@ -39,6 +42,46 @@ def test_oracle_equals_reference_bit_for_bit(name):
         assert np.array_equal(merge_status(ax["status"]), bx["status"])
         r2 = bx["status"] <= 1
         assert np.array_equal(ax["pos_dir"][:, r2], bx["pos_dir"][:, r2])
+
+
+@pytest.mark.parametrize("bottle", ["clearBottle-small.params", "clearBottle-ellipse.params", "clearBottle-large.params"])
+@pytest.mark.parametrize("ring", [True, False])
+def test_isors_and_bottle_backward_equal_the_reference(bottle, ring):
+    """iSORS (src/sourceMod.f90:162-247) with intersect_cone (src/surfaces.f90:179-224) for circular and
+    elliptical bottles — and its ring = .false. variant, which no call site of the reference uses but
+    which is the only caller of bottle_backward_sub (src/lens.f90:352-423): emitted rays, final
+    state, outcomes and draw counts bit for bit on 20 000 rays that refract at the axicon."""
+    from opticalraytrace_amd.params import Settings
+    from opticalraytrace_amd.system import OpticalSystem
+    from oracle.binding import ISORS_NO_RING
+    s = Settings(nphotons=1000, light_source="isors", bottle_file=bottle, isors_offset=0.5e-3)
+    osys = OpticalSystem.from_settings(s)
+    over = None if ring else ISORS_NO_RING
+    n = 20000
+    rng = np.random.default_rng(3)
+    u = isors_safe_uniforms(rng.random((24, n)), rng)
+    a = Oracle(osys, source_override=over).trace_rays(1, n, u=u)
+    b = Reference(s, resource_dir(), source_override=over).trace_rays(1, n, u=u)
+    assert np.array_equal(a["emitted"], b["emitted"])
+    assert np.array_equal(a["pos_dir"], b["pos_dir"])
+    assert np.array_equal(merge_status(a["status"]), b["status"]) and np.array_equal(a["n_draws"], b["n_draws"])
+    assert (a["status"] == 0).sum() > 10 and (a["status"] == 6).sum() == 0
+
+
+def test_isors_reflecting_rays_end_where_the_reference_aborts():
+    """With free uniforms ~3 % of the rays reflect at the axicon: the reference would `error stop`
+    (sourceMod.f90:216-218); the oracle ends exactly those rays as ORC_NO_INTERSECTION after
+    rang + one draw, and counts them as lost."""
+    _, osys = make_system("small_isors")
+    orc = Oracle(osys)
+    n = 50000
+    r = orc.trace_rays(1, n, seed=123456789)
+    gone = r["status"] == 6
+    assert 0.02 < gone.mean() < 0.04
+    assert (r["n_draws"][gone] % 2 == 1).all()            # 2 per rang iteration + the axicon draw
+    assert (r["emitted"][5][gone] > 0).all()              # flying away from the bottle (+z)
+    img, cnt = orc.trace(1, 0, n, 123456789)
+    assert int(cnt[0]) >= int(gone.sum())
 
 
 def test_reference_constants_match_host_model():

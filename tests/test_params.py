@@ -120,13 +120,17 @@ def test_settings_round_trip_in_runner_layout(tmp_path):
         Settings(nphotons=20000, use_tracker=True).validate()
 
 
-def test_unsupported_sources_fail_loudly():
-    """`isors` (the reference itself aborts, sourceMod.f90:217) is refused instead of silently
-    traced as something else; point / spot / crs / image are built."""
+def test_every_source_of_the_reference_builds_and_unknown_ones_fail_loudly():
+    """setupMod.f90:85-99: image, spot, point, isors, crs — anything else is `error stop "No such
+    source type!"`, here a ParamsError.  isors changes `distance` (main.f90:60-64)."""
     with pytest.raises(ParamsError):
-        OpticalSystem.from_settings(Settings(light_source="isors"))
-    for src in ("point", "spot", "crs", "image"):
+        OpticalSystem.from_settings(Settings(light_source="laser"))
+    for src in ("point", "spot", "crs", "image", "isors"):
         OpticalSystem.from_settings(Settings(light_source=src, nphotons=100))
+    a = OpticalSystem.from_settings(Settings(light_source="isors", isors_offset=0.5e-3))
+    b = OpticalSystem.from_settings(Settings(light_source="point", isors_offset=0.5e-3))
+    assert a.distance == a.bottle.radiusa + 0.5e-3 and b.distance == b.bottle.radiusa + b.bottle.centre[2]
+    assert a.r1 != b.r1
 
 
 def test_bottle_clamp():
