@@ -255,6 +255,37 @@ double orc_dispersion(double wave, double a, double b, double c)
     return a - b * wave2 + (c / wave2);
 }
 
+/* libm entries of the scattering walk (tauint, stokes).  Development build -DORC_PERTURB
+ * (tools/scatter_sensitivity.py): each can be made to return its value moved by one ulp in half of
+ * the calls, which is what another libm (the GPU's) does to it — to measure which function's last
+ * bit the walk amplifies.  The default build calls libm directly. */
+#ifdef ORC_PERTURB
+int orc_perturb_mask = 0;       /* 1 log, 2 atan2, 4 acos, 8 sin/cos of ri1/ri3, 16 sin/cos of phi */
+static double nudge(double y, int bit)
+{
+    if (!(orc_perturb_mask & bit)) return y;
+    uint64_t b; memcpy(&b, &y, 8);
+    uint64_t h = mix64(b);
+    if (h & 1) return y;
+    return nextafter(y, (h & 2) ? INFINITY : -INFINITY);
+}
+#define M_LOG(x) nudge(log(x), 1)
+#define M_ATAN2(y, x) nudge(atan2(y, x), 2)
+#define M_ACOS(x) nudge(acos(x), 4)
+#define M_SIN1(x) nudge(sin(x), 8)
+#define M_COS1(x) nudge(cos(x), 8)
+#define M_SIN2(x) nudge(sin(x), 16)
+#define M_COS2(x) nudge(cos(x), 16)
+#else
+#define M_LOG(x) log(x)
+#define M_ATAN2(y, x) atan2(y, x)
+#define M_ACOS(x) acos(x)
+#define M_SIN1(x) sin(x)
+#define M_COS1(x) cos(x)
+#define M_SIN2(x) sin(x)
+#define M_COS2(x) cos(x)
+#endif
+
 /* tauint, src/surfaces.f90:13-50: optical depth to the next event inside the cylinder.
  * Returns 0 ok (dist = distance to the event, *tflag = 1 when that is the cylinder wall),
  * 1 for the reference's `error stop "no intersection"` (:33-39). */
@@ -262,7 +293,7 @@ static int tauint(orc_vec pos, orc_vec dir, double mua, double mus, orc_vec cent
                   double *dist, int *tflag, draws_t *d, int *nis)
 {
     double mu_tot = mua + mus;
-    double tau = -log(ran2(d));
+    double tau = -M_LOG(ran2(d));
     *tflag = 0;
     int flag = intersect_cylinder(pos, dir, dist, centre, radius);
     (*nis)++;
@@ -282,7 +313,7 @@ static void stokes(orc_vec *dir, double hgg, draws_t *d)
     double cost = dir->z;
     double sint = sqrt(1. - cost * cost);
     double g2 = hgg * hgg;
-    double phi = atan2(dir->y, dir->x);
+    double phi = M_ATAN2(dir->y, dir->x);
     double cosp, sinp;
     if (hgg == 0.0) {
         cost = 2. * ran2(d) - 1.;
@@ -305,7 +336,7 @@ static void stokes(orc_vec *dir, double hgg, draws_t *d)
         double cosi2 = 0., sini2 = 0., cosdph;
         if (ri1 > PI) {
             double ri3 = TWOPI - ri1;
-            double cosi3 = cos(ri3), sini3 = sin(ri3);
+            double cosi3 = M_COS1(ri3), sini3 = M_SIN1(ri3);
             if (bmu == 1. || bmu == -1.) goto done;
             cost = costp * bmu + sintp * sinbt * cosi3;
             if (fabs(cost) < 1.) {
@@ -320,11 +351,11 @@ static void stokes(orc_vec *dir, double hgg, draws_t *d)
             }
             cosdph = -cosi2 * cosi3 + sini2 * sini3 * bmu;
             if (fabs(cosdph) > 1.) cosdph = (cosdph > 1.) ? 1. : -1.;
-            phi = phip + acos(cosdph);
+            phi = phip + M_ACOS(cosdph);
             if (phi > TWOPI) phi = phi - TWOPI;
             if (phi < 0.) phi = phi + TWOPI;
         } else {
-            double cosi1 = cos(ri1), sini1 = sin(ri1);
+            double cosi1 = M_COS1(ri1), sini1 = M_SIN1(ri1);
             if (bmu == 1. || bmu == -1.) goto done;
             cost = costp * bmu + sintp * sinbt * cosi1;
             if (fabs(cost) < 1.) {
@@ -339,11 +370,11 @@ static void stokes(orc_vec *dir, double hgg, draws_t *d)
             }
             cosdph = -cosi1 * cosi2 + sini1 * sini2 * bmu;
             if (fabs(cosdph) > 1.) cosdph = (cosdph > 1.) ? 1. : -1.;
-            phi = phip - acos(cosdph);
+            phi = phip - M_ACOS(cosdph);
             if (phi > TWOPI) phi = phi - TWOPI;
             if (phi < 0.) phi = phi + TWOPI;
         }
-        cosp = cos(phi); sinp = sin(phi);
+        cosp = M_COS2(phi); sinp = M_SIN2(phi);
         nxp = sint * cosp; nyp = sint * sinp; nzp = cost;
     }
 done:

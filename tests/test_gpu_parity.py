@@ -365,33 +365,44 @@ def test_image_source_on_the_gpu(ctxs):
 
 @pytest.mark.parametrize("name", ["small_scatter_c", "small_scatter_bc"])
 def test_scattering_bottle_vs_oracle(ctxs, name):
-    """the random walk in the bottle (tauint + Henyey-Greenstein) for 50k keyed rays —
-    draw counts and outcomes against the oracle, the image up to a small flip budget."""
+    """the random walk in the bottle (tauint + Henyey-Greenstein `stokes`) for 1e6
+    keyed rays, ray by ray against the oracle, then the image.
+
+    No reference fixture covers scattering (no shipped bottle scatters): the oracle is pinned to the
+    compiled reference on these bottles (test_oracle_vs_ref.py), the GPU to the oracle here.
+    The walk calls log / atan2 / acos (device library) and sin / cos (sincos_small): within an ulp of
+    glibc's, not identical.  tools/scatter_sensitivity.py (CPU) moves each function's result by one
+    ulp in half of its calls: atan2 of the old azimuth and sin / cos of the scattering azimuth
+    (ri1) are the ones the walk amplifies (through 1 / (sint sinbt) and acos near +-1), each
+    putting 4e-5 ... 7e-5 of the rays beyond 1e-10 (max 3.5e-10); log, acos and the final sin / cos
+    stay below 3e-11.  Measured on the GPU (tools/scatter_tail.py, 1e6 rays): no outcome or
+    draw-count difference, 92 % of the rays identical to 1e-14, 1.4e-5 ... 2.1e-5 of them beyond
+    1e-10, max 2.9e-10.  Budgets below = those figures with a margin, as fractions of rays."""
     osys, ctx = ctxs(name)
     orc = _oracle(osys)
-    n = 50000
+    n = 1_000_000
     want = orc.trace_rays(2, n, seed=SEED, first_ray=0)
     got = ctx.trace_rays(2, n, seed=SEED, first_ray=0)
-    same = got["status"] == want["status"]
-    assert same.mean() > 0.9999, (~same).sum()
-    assert np.array_equal(got["n_draws"][same], want["n_draws"][same])
-    assert np.array_equal(got["n_isect"][same], want["n_isect"][same])
+    same = (got["status"] == want["status"]) & (got["n_draws"] == want["n_draws"]) & (got["n_isect"] == want["n_isect"])
+    assert (~same).sum() <= 10, (~same).sum()             # observed 0 of 1e6
     assert want["n_draws"].max() > 20                     # rays really scatter several times
     reach = same & (want["status"] <= 2)
-    # The walk goes through log / atan2 / sincos / acos (ocml vs glibc differ by <= 2 ulp) and
-    # stokes divides by sint*sinbt, which amplifies an ulp by up to ~1e6 for near-forward
-    # scattering: per ray, position error relative to the 10 mm image and direction error
+    assert reach.sum() > 50_000
     a, b = got["pos_dir"][:, reach], want["pos_dir"][:, reach]
-    err = np.maximum(np.abs(a[:3] - b[:3]).max(0) / 1e-2, np.abs(a[3:] - b[3:]).max(0))
-    assert (err <= REL_TOL).mean() > 0.999, (err > REL_TOL).sum()
-    assert err.max() < 1e-6
+    scale = np.maximum(np.abs(b), np.abs(b).max(axis=1, keepdims=True) * 1e-6)
+    err = (np.abs(a - b) / scale).max(axis=0)
+    assert np.mean(err > REL_TOL) < 1e-4, np.mean(err > REL_TOL)     # north_star's 1e-10: observed 2e-5 of the rays beyond it
+    assert np.mean(err > 1e-12) < 5e-3
+    assert err.max() < 1e-8                                          # observed 2.9e-10
     ctx.reset()
     ctx.trace(2, 0, n, SEED)
     img, cnt = ctx.read()
     wimg = np.zeros((2, 401, 401), np.int32); wc = np.zeros(8, np.uint64)
     orc.trace(2, 0, n, SEED, wimg, wc)
+    # image of 1e6 rays: a ray within 1e-10 of a bin edge may hop (two counts each)
     assert np.abs(img.astype(np.int64) - wimg).sum() <= 8
-    assert np.abs(cnt.astype(np.int64) - wc.astype(np.int64)).max() <= 8
+    assert np.abs(cnt.astype(np.int64) - wc.astype(np.int64)).max() <= 4
+
 
 @pytest.mark.parametrize("name", ["large", "small_iris_after", "ellipse"])
 def test_bulk_kernels_rerun_flagged_rays_literally(ctxs, name):
