@@ -174,6 +174,12 @@ int ort_set_system(ort_ctx *ctx, const ort_system *sys);
  * point loop starts in the cell with cdf[s] <= i < cdf[s+1]. */
 int ort_set_image_source(ort_ctx *ctx, const int64_t *cdf);
 int ort_reset(ort_ctx *ctx);                       /* image = 0, counters = 0 (src/main.f90:39-41) */
+/* ort_trace bins into per-XCD private copies of the image and adds them into the image when the
+ * image is next needed (ort_read, ort_reset, ort_allreduce, ort_synchronize, ort_device_image,
+ * ort_attach_buffers do it themselves).  A host that reads ATTACHED device buffers on its own
+ * (torch tensors, its own RCCL communicator) calls ort_flush first; asynchronous, on the context's
+ * stream. */
+int ort_flush(ort_ctx *ctx);
 
 /* The hot loop.  Replaces one OpenMP `do i = 1, nphotons` loop of
  * src/main.f90:90-109 (phase 1, ring) or :127-162 (phase 2, point) over the

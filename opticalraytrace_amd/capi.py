@@ -181,6 +181,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ort_destroy": (C.c_int, [vp]),
         "ort_set_system": (C.c_int, [vp, C.POINTER(OrtSystem)]),
         "ort_reset": (C.c_int, [vp]),
+        "ort_flush": (C.c_int, [vp]),
         "ort_set_image_source": (C.c_int, [vp, C.POINTER(C.c_int64)]),
         "ort_trace": (C.c_int, [vp, i32, u64, u64, u64]),
         "ort_emit": (C.c_int, [vp, i32, u64, u64, u64, vp]),
@@ -211,7 +212,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = ["ort_abi_version", "ort_build_id", "ort_allreduce", "ort_last_error", "ort_device_count", "ort_create",
-                    "ort_destroy", "ort_set_system", "ort_set_image_source", "ort_reset", "ort_trace", "ort_emit",
+                    "ort_destroy", "ort_set_system", "ort_set_image_source", "ort_reset", "ort_flush", "ort_trace", "ort_emit",
                     "ort_trace_resident", "ort_trace_rays", "ort_trace_paths", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
                     "ort_device_counters", "ort_synchronize", "ort_reserve", "ort_last_kernel_ms",
@@ -282,6 +283,11 @@ class Context:
 
     def reset(self) -> None:
         _check(self.lib, self.lib.ort_reset(self._h), "ort_reset")
+
+    def flush(self) -> None:
+        """Fold the hits still held in the per-XCD replicas into the image (needed before the
+        attached device buffers are read by anything but this library)."""
+        _check(self.lib, self.lib.ort_flush(self._h), "ort_flush")
 
     def trace(self, phase: int, first_ray: int, n_rays: int, seed: int) -> None:
         _check(self.lib, self.lib.ort_trace(self._h, phase, first_ray, n_rays, seed), "ort_trace")

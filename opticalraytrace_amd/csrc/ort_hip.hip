@@ -777,6 +777,16 @@ int grid_for(uint64_t n)
     return (int)b;
 }
 
+int redo_blocks()
+{
+    static int n = 0;
+    if (!n) {
+        const char *e = getenv("ORT_REDO_BLOCKS");       // development knob
+        n = (e && atoi(e) > 0) ? atoi(e) : kRedoBlocks;
+    }
+    return n;
+}
+
 int check_system(const ort_system *sys)
 {
     if (!sys) return fail(ORT_E_INVALID, "system is NULL");
@@ -804,7 +814,8 @@ struct ort_ctx {
     bool own_stream;
     DevSystem *d_sys;
     int32_t *d_image, *own_image;
-    int32_t *d_replicas;         // kReplicas x 2 layers x kSlots, zero between launches (scratch between trace and fold)
+    int32_t *d_replicas;         // kReplicas x 2 layers x kSlots: hits not yet folded into the image
+    bool fold_pending[2];        // per layer: the replicas hold hits (fold_kernel runs when the image is needed)
     uint32_t *d_redo_list;       // re-run list of the queued filtered kernel, redo_cap entries
     size_t redo_cap;
     unsigned int *d_redo_ctl;    // [2]: entries, re-run workgroups done; zero between launches
@@ -866,6 +877,20 @@ static int upload_system(ort_ctx *c, const ort_system *sys)
         for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.auxf[p][k] = make_aux<float>(h.sysf.surfaces[p][k]);
     HIP_TRY(hipMemcpyAsync(c->d_sys, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORT_OK;
+}
+
+// Replicas -> image.  The fold is deferred until somebody needs the image (ort_read, ort_reset,
+// ort_allreduce, ort_flush, a change of accumulators): a run of K back-to-back ort_trace calls pays
+// for one fold, not K (each is a launch that reads 8 MB: ~2 % of a 1e7-ray launch).
+static int flush_replicas(ort_ctx *c)
+{
+    for (int p = 0; p < 2; ++p) {
+        if (!c->fold_pending[p]) continue;
+        hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, p + 1);
+        HIP_TRY(hipGetLastError());
+        c->fold_pending[p] = false;
+    }
     return ORT_OK;
 }
 
@@ -1021,9 +1046,18 @@ int ort_reset(ort_ctx *c)
 {
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
+    const int rc = flush_replicas(c);                      // leaves the replicas zero
+    if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->d_image, 0, ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, ORT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
     return ORT_OK;
+}
+
+int ort_flush(ort_ctx *c)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    return flush_replicas(c);
 }
 
 // One kernel of the trace family on `grid` workgroups.
@@ -1137,14 +1171,11 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
         HIP_TRY(hipGetLastError());                         // a failed launch is reported where it happened
         if (deferring) {
             a.listed = 1;
-            launch_one(c, mode, a, kRedoBlocks, false, false, true);
+            launch_one(c, mode, a, redo_blocks(), false, false, true);
             HIP_TRY(hipGetLastError());
         }
     }
-    if (use_rep) {
-        hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, a0.phase);
-        HIP_TRY(hipGetLastError());
-    }
+    if (use_rep) c->fold_pending[a0.phase - 1] = true;     // folded when the image is next needed (flush_replicas)
     if (c->timing && evk > 0) { HIP_TRY(hipEventRecord(c->ev[evk][1], c->stream)); c->ev_valid[evk] = true; }
     if (c->timing && evk == 0) { HIP_TRY(hipEventRecord(c->ring[slot][1], c->stream)); c->ring_count++; c->ev_valid[0] = true; }
     return ORT_OK;
@@ -1294,6 +1325,7 @@ int ort_read(ort_ctx *c, int32_t *image, uint64_t *counters)
 {
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = flush_replicas(c); if (rc) return rc; }
     if (image)
         HIP_TRY(hipMemcpyAsync(image, c->d_image, ORT_IMAGE_BINS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (counters)
@@ -1308,6 +1340,7 @@ int ort_attach_buffers(ort_ctx *c, void *d_image, void *d_counters)
     if ((d_image == nullptr) != (d_counters == nullptr))
         return fail(ORT_E_INVALID, "attach both buffers or neither");
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = flush_replicas(c); if (rc) return rc; }     // pending hits belong to the old accumulators
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->d_image = d_image ? (int32_t *)d_image : c->own_image;
     c->d_counters = d_counters ? (unsigned long long *)d_counters : c->own_counters;
@@ -1386,6 +1419,11 @@ int ort_allreduce(ort_ctx **ctxs, int n)
     }
     // one group: image (int32 x 321 602 = 1.29 MB) and counters (uint64 x 8) of every device, each on
     // its context's stream, so the sums are ordered after the traces already queued there
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(hipSetDevice(ctxs[i]->device));
+        const int frc = flush_replicas(ctxs[i]);
+        if (frc) return frc;
+    }
     RCCL_TRY(g_rccl.GroupStart());
     for (int i = 0; i < n; ++i) {
         ort_ctx *c = ctxs[i];
@@ -1399,6 +1437,8 @@ int ort_allreduce(ort_ctx **ctxs, int n)
 int ort_device_image(ort_ctx *c, void **d_image)
 {
     if (!c || !d_image) return fail(ORT_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    { const int rc = flush_replicas(c); if (rc) return rc; }
     *d_image = c->d_image;
     return ORT_OK;
 }
@@ -1414,6 +1454,7 @@ int ort_synchronize(ort_ctx *c)
 {
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = flush_replicas(c); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ORT_OK;
 }

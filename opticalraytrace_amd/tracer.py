@@ -76,7 +76,11 @@ class ShardedRun:
     def _synchronize(self) -> None:
         pass
 
+    def _flush(self) -> None:
+        """Everything traced so far is in `image` / `counters` (stream-ordered)."""
+
     def reset(self) -> None:
+        self._flush()
         self.image.zero_()
         self.counters.zero_()
 
@@ -88,12 +92,14 @@ class ShardedRun:
     def reduce(self, force: bool = False) -> None:
         """Sum image + counters over ranks (RCCL all-reduce over xGMI); no-op for world == 1
         unless `force` (then the collective runs on the single rank: a plumbing check)."""
+        self._flush()
         if self.world > 1 or force:
             import torch.distributed as dist
             dist.all_reduce(self.image, op=dist.ReduceOp.SUM, group=self.group)
             dist.all_reduce(self.counters, op=dist.ReduceOp.SUM, group=self.group)
 
     def result(self, nphotons: int) -> RunResult:
+        self._flush()
         self._synchronize()
         return RunResult(self.image.cpu().numpy().copy(),
                          self.counters.cpu().numpy().astype(np.uint64), nphotons)
@@ -138,6 +144,9 @@ class RayTracer(ShardedRun):
 
     def _trace_shard(self, phase: int, lo: int, cnt: int, seed: int) -> None:
         self.ctx.trace(phase, lo, cnt, seed)
+
+    def _flush(self) -> None:
+        self.ctx.flush()           # per-XCD replicas -> the attached image tensor
 
     def _synchronize(self) -> None:
         self.torch.cuda.synchronize(self.device)
