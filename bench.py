@@ -23,9 +23,9 @@ value = intersections all ranks evaluated (exact int64 device counter) / wall ti
 
 Order of the legs in one process: CPU baseline (child process, before this process touches
 the GPU), set-up (scratch, code objects, 160 untimed launches that bring the clocks out of
-idle — see SETTLE_LAUNCHES), then the informational fp32 and fast-fp64 legs, then the exact
-fp64 leg that `value` reports — last, so that its accumulators are the ones read back and
-checked.  Every leg: W untimed warm-up steps, then exactly K timed steps between two fences.
+idle — see SETTLE_LAUNCHES), then the exact fp64 leg that `value` reports, then the
+informational fp32 and fast-fp64 legs over the same rays.  Every leg: W untimed warm-up steps,
+then exactly K timed steps between two fences.
 """
 import argparse
 import json
@@ -248,18 +248,7 @@ def main() -> int:
         b = sum(int(res.counters[C_BINNED_RING if ph == 1 else C_BINNED_POINT]) for ph in phases)
         return i, b
 
-    # ---- informational legs (outside `value`) ---------------------------------------------------
-    legs = {}
-    for name, prec, skip in (("fp32", 1, args.no_fp32), ("fast_fp64", 2, args.no_fast)):
-        if skip:
-            continue
-        ctx.set_precision(prec)
-        el, kms = timed_run(args.steps, min(args.warmup, 2))
-        r = tracer.result(total_rays * args.steps)
-        legs[name] = (el, kms, r)
-    ctx.set_precision(0)
-
-    # ---- the leg `value` reports: exact fp64 -----------------------------------------------------
+    # ---- the leg `value` reports: exact fp64 — first, straight after the set-up ------------------
     elapsed, kernel_ms = timed_run(args.steps, args.warmup)
     res = tracer.result(total_rays * args.steps)   # counters of the whole timed run, summed over ranks
     isect_total, binned_total = isect_binned(res)
@@ -269,6 +258,17 @@ def main() -> int:
     isect_per_step = isect_total / args.steps
     binned_per_step = binned_total / args.steps
     value = isect_total / elapsed
+
+    # ---- informational legs (outside `value`): the same rays in the other arithmetics -----------
+    legs = {}
+    for name, prec, skip in (("fp32", 1, args.no_fp32), ("fast_fp64", 2, args.no_fast)):
+        if skip:
+            continue
+        ctx.set_precision(prec)
+        el, kms = timed_run(args.steps, args.warmup)
+        r = tracer.result(total_rays * args.steps)
+        legs[name] = (el, kms, r)
+    ctx.set_precision(0)
 
     # ---- roofline of the dominant kernel (the fused trace kernel), per launch = per rank per phase
     # of a step.  kernel_ms holds one entry per ort_trace call (queued kernel + its literal re-run
@@ -381,6 +381,8 @@ def main() -> int:
         out["cpu_baseline"] = cpu
         if cpu.get("value"):
             out["gpu_over_cpu"] = value / cpu["value"]
+    if os.environ.get("ORT_BENCH_DUMP_KERNEL_MS"):               # development: the per-launch series
+        out["kernel_ms_series"] = [round(x, 4) for x in kernel_ms]
     if rank == 0:
         print(json.dumps(out), flush=True)
     tracer.close()
