@@ -74,10 +74,16 @@ struct TraceArgs {
     unsigned long long *counters;
     uint64_t first_ray, n_rays, rng_base;
     int phase, draw_base;
+    // ray ranges of the queued kernel's waves (host: plan_ranges): workgroups [0, head_blocks) cut
+    // rays [0, head_rays) into head_chunk per wave, the rest cut the remainder into tail_chunk per wave
+    uint32_t head_blocks;
+    uint64_t head_rays, head_chunk, tail_chunk;
     // the re-run list of the queued filtered kernel (see trace_queue_kernel): ray indices relative
     // to first_ray; ctl[0] = entries, ctl[1] = workgroups of the re-run kernel that are done
     uint32_t *redo_list;
     unsigned int *redo_ctl;
+    uint64_t defer_base;         // queued kernel: list entry of ray i of this launch = defer_base + i (the entries of all
+                                 // launches of a group are relative to the group's first ray, see close_group)
     int listed;                  // trace_kernel: iterate redo_list instead of [0, n_rays)
     // resident / debug inputs
     uint64_t in_stride;          // component stride of pos_dir_in (the bundle's ray count)
@@ -628,13 +634,14 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     const uint64_t n = a.n_rays;
     const uint64_t ns_in = a.in_stride;
 
-    // contiguous, 64-aligned range of ray indices for this wave
-    const uint64_t nwaves = (uint64_t)gridDim.x * kWavesPerBlock;
-    const uint64_t wid = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
-    uint64_t chunk = (n + nwaves - 1) / nwaves;
-    chunk = (chunk + 63) & ~63ull;
-    uint64_t lo = wid * chunk; if (lo > n) lo = n;
-    uint64_t hi = lo + chunk;  if (hi > n) hi = n;
+    // contiguous, 64-aligned range of ray indices for this wave: long ranges for the workgroups of
+    // the first rounds, short ones for the last workgroups (plan_ranges), so that the chip drains evenly
+    const bool head = blockIdx.x < a.head_blocks;
+    const uint64_t wid = (uint64_t)(head ? blockIdx.x : blockIdx.x - a.head_blocks) * kWavesPerBlock + wave;
+    const uint64_t chunk = head ? a.head_chunk : a.tail_chunk;
+    const uint64_t end = head ? a.head_rays : n;
+    uint64_t lo = (head ? 0 : a.head_rays) + wid * chunk; if (lo > end) lo = end;
+    uint64_t hi = lo + chunk;  if (hi > end) hi = end;
 
     unsigned int lost = 0, isect = 0, binned = 0, help3 = 0;
     auto finish = [&](int st, int nis, int xp, int yp) {
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     // A ray that raised `rare` (ort_device.h: it sat on a decision boundary of a filtered
     // predicate) leaves this kernel without any side effect: its index goes to the re-run list
     // and trace_kernel<literal> traces it from the start afterwards.  ~4e-6 of the rays.
-    auto defer = [&](uint64_t i) { a.redo_list[atomicAdd(&a.redo_ctl[0], 1u)] = (uint32_t)i; };
+    auto defer = [&](uint64_t i) { a.redo_list[atomicAdd(&a.redo_ctl[0], 1u)] = (uint32_t)(a.defer_base + i); };
 
     uint64_t next = lo;
     int qcount = 0, qhead = 0;
@@ -777,6 +784,45 @@ int grid_for(uint64_t n)
     return (int)b;
 }
 
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return (e && atoi(e) > 0) ? atoi(e) : dflt;
+}
+
+// Ray ranges of a queued launch of n rays.  A launch of equal ranges ends with a partly filled last
+// round of workgroups: the chip runs at 2 waves per SIMD instead of 5 for the last ~10 % of the time
+// (measured: two launches overlapped on two streams took 10 % less than back to back).  So the bulk
+// of the rays (kHeadPercent) goes to kHeadBlocks workgroups — two full rounds of the 1280 the chip
+// holds at once — in long ranges, and the rest to many workgroups of kTailBatches 64-ray batches per
+// wave, which the dispatcher hands to whichever CU frees up: the chip drains within one short
+// workgroup.  Small launches keep equal ranges.  Scheduling only: results do not depend on it.
+constexpr int kHeadBlocks = 2560, kHeadPercent = 92, kTailBatches = 4;
+int plan_ranges(TraceArgs &a)
+{
+    static const int head_blocks = env_int("ORT_HEAD_BLOCKS", kHeadBlocks), head_pct = env_int("ORT_HEAD_PERCENT", kHeadPercent),
+                     tail_batches = env_int("ORT_TAIL_BATCHES", kTailBatches);
+    const uint64_t n = a.n_rays, per_block = 64ull * kWavesPerBlock;
+    if (n < (uint64_t)head_blocks * per_block * 4 || head_pct >= 100) {       // equal ranges
+        int grid = grid_for(n);
+        const uint64_t batches = (n + 63) / 64, blocks = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (blocks < (uint64_t)grid) grid = (int)blocks;
+        const uint64_t nwaves = (uint64_t)grid * kWavesPerBlock;
+        a.head_blocks = (uint32_t)grid;
+        a.head_rays = n;
+        a.head_chunk = (((n + nwaves - 1) / nwaves) + 63) & ~63ull;
+        a.tail_chunk = 64;
+        return grid;
+    }
+    const uint64_t hw = (uint64_t)head_blocks * kWavesPerBlock;
+    a.head_blocks = (uint32_t)head_blocks;
+    a.head_chunk = ((n / 100 * (uint64_t)head_pct / hw) + 63) & ~63ull;
+    a.head_rays = a.head_chunk * hw < n ? a.head_chunk * hw : n;
+    a.tail_chunk = 64ull * (uint64_t)tail_batches;
+    const uint64_t rest = n - a.head_rays, tb = a.tail_chunk * kWavesPerBlock;
+    return head_blocks + (int)((rest + tb - 1) / tb);
+}
+
 int redo_blocks()
 {
     static int n = 0;
@@ -816,6 +862,12 @@ struct ort_ctx {
     int32_t *d_image, *own_image;
     int32_t *d_replicas;         // kReplicas x 2 layers x kSlots: hits not yet folded into the image
     bool fold_pending[2];        // per layer: the replicas hold hits (fold_kernel runs when the image is needed)
+    // deferral group: consecutive fused launches of one phase / seed / system whose deferred rays share
+    // the re-run list; the literal re-run is launched when the group closes (close_group)
+    bool group_open;
+    int group_mode;
+    TraceArgs group_args;        // the group's first launch (first_ray = the base the list entries refer to)
+    uint64_t group_rays;         // rays launched in the group so far (bound on the list's fill)
     uint32_t *d_redo_list;       // re-run list of the queued filtered kernel, redo_cap entries
     size_t redo_cap;
     unsigned int *d_redo_ctl;    // [2]: entries, re-run workgroups done; zero between launches
@@ -883,8 +935,28 @@ static int upload_system(ort_ctx *c, const ort_system *sys)
 // Replicas -> image.  The fold is deferred until somebody needs the image (ort_read, ort_reset,
 // ort_allreduce, ort_flush, a change of accumulators): a run of K back-to-back ort_trace calls pays
 // for one fold, not K (each is a launch that reads 8 MB: ~2 % of a 1e7-ray launch).
+static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool queued, bool filt, bool anysrc);
+
+// The rays the queued launches of the open group deferred (ort_device.h: a filtered predicate too
+// close to call) are traced by the literal lockstep kernel — ONE launch per group instead of one
+// behind every queued launch (an empty re-run launch cost ~10 us + a launch gap, 3 % of a 1e7-ray
+// step).  The list can hold every ray of the group (launch_trace closes the group before it
+// could overflow), so nothing is ever dropped.
+static int close_group(ort_ctx *c)
+{
+    if (!c->group_open) return ORT_OK;
+    c->group_open = false;
+    TraceArgs a = c->group_args;
+    a.listed = 1;
+    a.n_rays = c->group_rays;
+    launch_one(c, c->group_mode, a, redo_blocks(), false, false, true);
+    HIP_TRY(hipGetLastError());
+    return ORT_OK;
+}
+
 static int flush_replicas(ort_ctx *c)
 {
+    { const int rc = close_group(c); if (rc) return rc; }
     for (int p = 0; p < 2; ++p) {
         if (!c->fold_pending[p]) continue;
         hipLaunchKernelGGL(fold_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_replicas, p + 1);
@@ -1024,6 +1096,7 @@ int ort_set_system(ort_ctx *c, const ort_system *sys)
     int rc = check_system(sys);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = close_group(c); if (rc) return rc; }     // its re-run must see the system its launches saw
     note_system(c, sys);
     return upload_system(c, sys);
 }
@@ -1035,6 +1108,7 @@ int ort_set_image_source(ort_ctx *c, const int64_t *cdf)
     for (int s = 0; s < ORT_IMAGE_SOURCE_CELLS; ++s)
         if (cdf[s + 1] < cdf[s]) return fail(ORT_E_INVALID, "cdf must be non-decreasing");
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = close_group(c); if (rc) return rc; }     // its re-run emits from the table its launches used
     const size_t bytes = (size_t)(ORT_IMAGE_SOURCE_CELLS + 1) * sizeof(long long);
     if (!c->d_img_cdf) HIP_TRY(hipMalloc(&c->d_img_cdf, bytes));
     HIP_TRY(hipMemcpyAsync(c->d_img_cdf, cdf, bytes, hipMemcpyHostToDevice, c->stream));
@@ -1111,16 +1185,23 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
 #undef ORT_LAUNCH
 }
 
-// the re-run list holds one entry per ray of a launch (launches cover at most kChunkRays)
+// The re-run list holds one entry per ray of a deferral group.  A group must be able to take every
+// ray of a launch (launches cover at most kChunkRays); beyond that the list is sized for several
+// launches, so that a run of back-to-back launches closes a group — one literal re-run launch —
+// only now and then: 8 launches of the largest size seen, at most 2^27 entries (512 MB of the 288 GB).
+constexpr uint64_t kListMax = 1ull << 27;
 static int reserve_list(ort_ctx *c, uint64_t n_rays)
 {
-    const size_t need = (size_t)(n_rays < kChunkRays ? n_rays : kChunkRays);
-    if (need > c->redo_cap) {
+    const uint64_t chunk = n_rays < kChunkRays ? n_rays : kChunkRays;
+    uint64_t want = 8 * chunk < kListMax ? 8 * chunk : kListMax;
+    if (want < chunk) want = chunk;
+    if (want > c->redo_cap) {
+        { const int rc = close_group(c); if (rc) return rc; }
         HIP_TRY(hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_redo_list);
         c->d_redo_list = nullptr; c->redo_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_redo_list, need * sizeof(uint32_t)));
-        c->redo_cap = need;
+        HIP_TRY(hipMalloc(&c->d_redo_list, want * sizeof(uint32_t)));
+        c->redo_cap = want;
     }
     return ORT_OK;
 }
@@ -1160,16 +1241,31 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
         a.n_rays = total - off < step ? total - off : step;
         a.first_ray = a0.first_ray + off;
         if (a.pos_dir_in) a.pos_dir_in += off;              // same component stride (in_stride)
-        int grid = grid_for(a.n_rays);
-        if (queued) {
-            // every wave walks a 64-aligned contiguous range: no more waves than 64-ray batches
-            uint64_t batches = (a.n_rays + 63) / 64;
-            uint64_t blocks = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
-            if (blocks < (uint64_t)grid) grid = (int)blocks;
+        // queued: every wave walks 64-aligned contiguous ranges (plan_ranges); lockstep: grid-stride
+        const int grid = queued ? plan_ranges(a) : grid_for(a.n_rays);
+        if (deferring && mode == MODE_FUSED) {
+            // fused launches share the re-run list of their group; the literal re-run comes when the
+            // group closes (close_group)
+            const TraceArgs &g = c->group_args;
+            const bool fits = c->group_open && c->group_mode == mode && g.phase == a.phase && g.rng_base == a.rng_base &&
+                              a.first_ray >= g.first_ray && (a.first_ray - g.first_ray) + a.n_rays <= (1ull << 32) &&
+                              c->group_rays + a.n_rays <= c->redo_cap;
+            if (!fits) {
+                { const int rc = close_group(c); if (rc) return rc; }
+                c->group_args = a;
+                c->group_mode = mode;
+                c->group_rays = 0;
+                c->group_open = true;
+            }
+            a.defer_base = a.first_ray - c->group_args.first_ray;
+            c->group_rays += a.n_rays;
+        } else {
+            const int rc = close_group(c);                  // anything else runs behind the group's re-run
+            if (rc) return rc;
         }
         launch_one(c, mode, a, grid, queued, filt, anysrc);
         HIP_TRY(hipGetLastError());                         // a failed launch is reported where it happened
-        if (deferring) {
+        if (deferring && mode != MODE_FUSED) {              // resident bundles: re-run at once (the bundle is the caller's)
             a.listed = 1;
             launch_one(c, mode, a, redo_blocks(), false, false, true);
             HIP_TRY(hipGetLastError());
@@ -1463,6 +1559,8 @@ int ort_set_kernel_variant(ort_ctx *c, int variant)
 {
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
     if (variant < 0 || variant > 7) return fail(ORT_E_INVALID, "variant must be in 0..7");
+    HIP_TRY(hipSetDevice(c->device));
+    { const int rc = close_group(c); if (rc) return rc; }
     c->variant = variant;
     return ORT_OK;
 }
@@ -1486,6 +1584,8 @@ int ort_set_precision(ort_ctx *c, int precision)
 {
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
     if (precision < 0 || precision > 2) return fail(ORT_E_INVALID, "precision must be 0 (fp64 exact), 1 (fp32) or 2 (fp64 fast)");
+    HIP_TRY(hipSetDevice(c->device));
+    { const int rc = close_group(c); if (rc) return rc; }     // the re-run uses the arithmetic of its launches
     c->precision = precision;
     return ORT_OK;
 }

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof/<workload>/ (tools/profile_round.sh) -> profiles/rNN/ + profiles/pmc_per_launch.json.
+
+Per workload: kernel_stats.csv (rocprofv3 --kernel-trace --stats of the bench command), the bench
+lines (plain, under rocprof), pmc_summary.json = mean per launch of every counter per kernel, and
+the figures bench.py quotes, stamped with the library's build id and the commit:
+  hbm_bytes_per_launch = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024   (KB units; FETCH doubled per the
+      gfx950 correction of MI355X_MICROARCH.md; separate --pmc passes) of the dominant kernel
+  valu_busy_frac       = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)
+  valu_lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
+usage: python tools/stamp_profiles.py r02 [gpurun_out/prof]"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+DOMINANT = {"point1e7": "trace_queue_kernel<0, true, false, double, 1, false>",
+            "ring1e8": "trace_queue_kernel<0, true, false, double, 2, false>",
+            "full1e9": "trace_queue_kernel<0, true, false, double, 1, false>"}
+
+
+def short(name):
+    m = re.search(r"(trace_queue_kernel|trace_kernel|fold_kernel|emit_kernel)(<[^>]*>)?", name)
+    return (m.group(1) + (m.group(2) or "")) if m else None
+
+
+def main():
+    rnd = sys.argv[1]
+    src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "prof")
+    dst = os.path.join(ROOT, "profiles", rnd)
+    os.makedirs(dst, exist_ok=True)
+    from opticalraytrace_amd import capi
+    build = capi.source_build_id()
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    stamped = {"build_id": build, "commit_at_capture": commit, "round": rnd, "workloads": {},
+               "source": "rocprofv3 --pmc passes of tools/profile_round.sh (separate runs per counter set), means per launch; "
+                         "FETCH_SIZE / WRITE_SIZE in KB, FETCH doubled (gfx950 correction, MI355X_MICROARCH.md)"}
+    for w in sorted(os.listdir(src)):
+        d = os.path.join(src, w)
+        if not os.path.isdir(d) or w not in DOMINANT:
+            continue
+        for f, name in (("bench.json", f"{w}_bench.json"), ("bench_under_rocprof.json", f"{w}_bench_under_rocprof.json")):
+            if os.path.exists(os.path.join(d, f)):
+                lines = [ln for ln in open(os.path.join(d, f)).read().splitlines() if ln.startswith("{")]
+                if lines:
+                    json.dump(json.loads(lines[-1]), open(os.path.join(dst, name), "w"), indent=1)
+        ks = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
+        if ks:
+            shutil.copy(ks[0], os.path.join(dst, f"{w}_kernel_stats.csv"))
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                if k:
+                    agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        summ = {k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in sorted(cs.items())}
+                for k, cs in sorted(agg.items())}
+        json.dump(summ, open(os.path.join(dst, f"{w}_pmc_summary.json"), "w"), indent=1)
+        dom = summ.get(DOMINANT[w])
+        if not dom:
+            print(f"{w}: dominant kernel {DOMINANT[w]} not in the PMC output: {list(summ)}")
+            continue
+        g = lambda c: dom.get(c, {}).get("mean_per_launch")          # noqa: E731
+        bench = json.load(open(os.path.join(dst, f"{w}_bench.json"))) if os.path.exists(os.path.join(dst, f"{w}_bench.json")) else {}
+        cfg = bench.get("config", {})
+        entry = {"kernel": DOMINANT[w], "rays_per_launch_nominal": cfg.get("rays_per_gpu_per_launch")}
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            entry["fetch_bytes_per_launch"] = 2.0 * g("FETCH_SIZE") * 1024.0
+            entry["write_bytes_per_launch"] = g("WRITE_SIZE") * 1024.0
+            entry["hbm_bytes_per_launch"] = entry["fetch_bytes_per_launch"] + entry["write_bytes_per_launch"]
+        if g("SQ_ACTIVE_INST_VALU") and g("GRBM_GUI_ACTIVE"):
+            entry["valu_busy_frac"] = g("SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / (g("GRBM_GUI_ACTIVE") / 8.0)
+        if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+            entry["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
+        for c, key in (("SQ_INSTS_VALU", "valu_instructions_per_launch"), ("SQ_INSTS_SALU", "salu_instructions_per_launch"),
+                       ("SQ_WAVES", "waves_per_launch"), ("TCC_EA0_ATOMIC_sum", "memory_side_atomics_per_launch")):
+            if g(c) is not None:
+                entry[key] = g(c)
+        # intersections per launch of the dominant kernel, from the bench line of the PMC-sized run
+        p1 = os.path.join(d, "pmc1.json")
+        if os.path.exists(p1):
+            lines = [ln for ln in open(p1).read().splitlines() if ln.startswith("{")]
+            if lines:
+                b = json.loads(lines[-1])
+                c2 = b["config"]
+                per_step = c2["intersections_per_step"]
+                if w == "full1e9":       # two phases per step: the point layer holds 6.31 of the 7.87 intersections per ray pair
+                    per_step *= 6.3136 / (6.3136 + 1.5524)
+                launches = max(1, -(-c2["rays_per_gpu_per_launch"] // (1 << 25)))     # ort_trace cuts at 2^25 rays
+                entry["intersections_per_launch"] = per_step / launches
+        stamped["workloads"][w] = entry
+        print(w, json.dumps(entry, indent=1))
+    json.dump(stamped, open(os.path.join(ROOT, "profiles", "pmc_per_launch.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
