@@ -211,7 +211,9 @@ __device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) 
 __device__ unsigned long long ort_dbg_rare[16];
 #define ORT_RARE(site, cond) do { const bool c_ = (cond); rare = rare || c_; if (c_) atomicAdd(&ort_dbg_rare[site], 1ull); } while (0)
 #else
-#define ORT_RARE(site, cond) do { rare = rare || (cond); } while (0)
+// (bitwise, not `||`: a short-circuit makes the compiler branch around the compares of `cond` —
+// two s_and_saveexec / s_cbranch_execz pairs per surface step and a boolean carried through a VGPR)
+#define ORT_RARE(site, cond) do { rare = rare | (bool)(cond); } while (0)
 #endif
 // "does any lane need the literal formula": the guard of every rare path
 #ifdef ORT_ABL_NOFALLBACK
@@ -241,8 +243,8 @@ __device__ inline T sqrt_f(T x, bool need, bool &rare)
         g = __builtin_fma(d, h, g);
         d = __builtin_fma(-g, g, x);
         g = __builtin_fma(d, h, g);
-        const bool plain = fabs(x) > 0x1p-700 && fabs(x) < 0x1p700;      // false for NaN too
-        ORT_RARE(0, need && !plain);
+        const bool plain = (fabs(x) > 0x1p-700) & (fabs(x) < 0x1p700);      // false for NaN too
+        ORT_RARE(0, need & !plain);
         return g;
     }
 #endif
@@ -362,8 +364,8 @@ __device__ inline VecT<T> div3_f(VecT<T> a, T t, bool need, bool &rare, bool x_z
         q.x = __builtin_fma(__builtin_fma(-t, mx, a.x), r, mx);
         q.y = __builtin_fma(__builtin_fma(-t, my, a.y), r, my);
         q.z = __builtin_fma(__builtin_fma(-t, mz, a.z), r, mz);
-        const bool odd = (!x_zero && !(fabs(a.x) > 0x1p-300)) || !(fabs(a.y) > 0x1p-300) || !(fabs(a.z) > 0x1p-300);
-        ORT_RARE(1, need && odd);
+        const bool odd = (!x_zero & !(fabs(a.x) > 0x1p-300)) | !(fabs(a.y) > 0x1p-300) | !(fabs(a.z) > 0x1p-300);
+        ORT_RARE(1, need & odd);
         return q;
     }
 #endif
@@ -379,7 +381,7 @@ __device__ inline VecT<T> vnormalise_f(VecT<T> a, bool need, bool &rare, bool x_
         const double s = a.x * a.x + a.y * a.y + a.z * a.z;
         bool unused = false;
         const double t = sqrt_f<true, double>(s, false, unused);
-        ORT_RARE(0, need && !(s < 0x1p700));
+        ORT_RARE(0, need & !(s < 0x1p700));
         return div3_f<true, double>(a, t, need, rare, x_zero);
     }
     return vnormalise(a);
@@ -417,8 +419,8 @@ __device__ inline VecT<T> vnormalise_est(VecT<T> a, T t0, T h0, T k0, T s_tol, b
         q.x = __builtin_fma(__builtin_fma(-t, mx, a.x), r, mx);
         q.y = __builtin_fma(__builtin_fma(-t, my, a.y), r, my);
         q.z = __builtin_fma(__builtin_fma(-t, mz, a.z), r, mz);
-        const bool odd = (!x_zero && !(fabs(a.x) > 0x1p-300)) || !(fabs(a.y) > 0x1p-300) || !(fabs(a.z) > 0x1p-300);
-        ORT_RARE(1, need && (odd || !(fabs(e) < s_tol)));
+        const bool odd = (!x_zero & !(fabs(a.x) > 0x1p-300)) | !(fabs(a.y) > 0x1p-300) | !(fabs(a.z) > 0x1p-300);
+        ORT_RARE(1, need & (odd | !(fabs(e) < s_tol)));
         return q;
     }
     return vnormalise(a);
@@ -595,7 +597,7 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
         else t = num / den;
 #endif
         hit = (qpos || cneg) && !neg;
-        ORT_RARE(2, live && !ok);                     // tangent, degenerate, on the surface, out of range, or NaN
+        ORT_RARE(2, live & !ok);                     // tangent, degenerate, on the surface, out of range, or NaN
     } else {
         const T b = T(2.0) * hb;
         const T discrim = b * b - T(4.0) * a * c;
@@ -702,7 +704,7 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
         const bool tir = k < T(-1e-6);
         const bool decided = (c1 < T(1.0)) & (tir | ((k > T(1e-6)) & (fabs(diff) > T(1e-10) * P)));
         reflected = tir | (diff < T(0.0));
-        ORT_RARE(3, live && !decided);
+        ORT_RARE(3, live & !decided);
     } else {
         reflected = u <= fresnel(c1, n1, n2, eta);       // :275
     }
@@ -724,7 +726,7 @@ __device__ inline bool outside_aperture(T x, T y, T A, T A2, T A2tol, bool live,
 {
     const T s2 = x * x + y * y;
     if constexpr (FILT) {                               // A2 = A*A, A2tol = 1e-12 A2 (SurfAuxT)
-        ORT_RARE(4, live && !(fabs(s2 - A2) > A2tol));
+        ORT_RARE(4, live & !(fabs(s2 - A2) > A2tol));
         return s2 > A2;
     } else {
         return ORT_SQRT(s2) > A;
@@ -1204,10 +1206,10 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
         fx = floor(qx); fy = floor(qy);
         const T gx = qx - fx, gy = qy - fy;
         const bool na_decided = fabs(xa - T(S.na_cos_min)) > T(1e-10);
-        const bool far = fabs(qx) > T(1e3) || fabs(qy) > T(1e3);
-        const bool bin_decided = far || (gx > T(1e-9) && gx < T(1. - 1e-9) && gy > T(1e-9) && gy < T(1. - 1e-9));   // NaN: undecided
-        ORT_RARE(5, live && !na_decided);
-        ORT_RARE(6, live && !reject && !bin_decided);
+        const bool far = (fabs(qx) > T(1e3)) | (fabs(qy) > T(1e3));
+        const bool bin_decided = far | ((gx > T(1e-9)) & (gx < T(1. - 1e-9)) & (gy > T(1e-9)) & (gy < T(1. - 1e-9)));   // NaN: undecided
+        ORT_RARE(5, live & !na_decided);
+        ORT_RARE(6, live & !reject & !bin_decided);
     } else {
         VecT<T> d = vnormalise(r.dir);
         d = vscale(d, T(-1.));
