@@ -185,22 +185,42 @@ struct ProgDraws {
     __device__ inline void advance(bool) {}
 };
 
-// Development-only ablation switches (tools/ablate.sh): they BREAK the numerics contract
-// and exist to price the IEEE divide / square-root expansions.  Never defined in the build.
-#ifdef ORT_ABL_FASTSQRT
-__device__ inline double abl_sqrt(double x) { return __builtin_amdgcn_sqrt(x); }
-template <class T> __device__ inline T abl_sqrt(T x) { return sqrt(x); }
-#define ORT_SQRT(x) abl_sqrt(x)
-#else
-#define ORT_SQRT(x) sqrt(x)
-#endif
+// Division and square root of the traced arithmetic, by type.
+//   double  the compiler's correctly rounded IEEE operations (the reference's arithmetic)
+//   fastd   ort_fastd.h (its own operator/ and sqrt)
+//   float   the fp32 path of BASELINE configs[4], which has no reference to be bit-exact against
+//           (the reference is fp64 only, src/Makefile:2): hardware reciprocal + one correction step
+//           and hardware square root, each within ~1 ulp (fp32) — a third of the instructions of
+//           the correctly rounded fp32 expansions, which made the fp32 path slower than fp64
+// Development-only ablation switches (ORT_ABL_*) BREAK the numerics contract and exist to price
+// the IEEE expansions.  Never defined in the build.
+__device__ inline double div_t(double a, double b)
+{
 #ifdef ORT_ABL_FASTDIV
-__device__ inline double abl_div(double a, double b) { return a * __builtin_amdgcn_rcp(b); }
-template <class T> __device__ inline T abl_div(T a, T b) { return a / b; }
-#define ORT_DIV(a, b) abl_div(a, b)
+    return a * __builtin_amdgcn_rcp(b);
 #else
-#define ORT_DIV(a, b) ((a) / (b))
+    return a / b;
 #endif
+}
+__device__ inline fastd div_t(fastd a, fastd b) { return a / b; }
+__device__ inline float div_t(float a, float b)
+{
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+__device__ inline double sqrt_t(double x)
+{
+#ifdef ORT_ABL_FASTSQRT
+    return __builtin_amdgcn_sqrt(x);
+#else
+    return sqrt(x);
+#endif
+}
+__device__ inline fastd sqrt_t(fastd x) { return sqrt(x); }
+__device__ inline float sqrt_t(float x) { return __builtin_amdgcn_sqrtf(x); }
+#define ORT_SQRT(x) sqrt_t(x)
+#define ORT_DIV(a, b) div_t(a, b)
 
 // the i1 ballot builtin: an s_and of the compare mask with exec.  (HIP's __ballot(int) first
 // materialises the predicate as 0/1 in a VGPR and compares it again: two VALU instructions.)
@@ -300,7 +320,7 @@ __device__ inline Vec div3_shared(Vec v, double t, bool &shared)
 
 // the three quotients, self-contained (emitters): lanes where the shared form does not apply
 // divide plainly, behind a wave-uniform branch
-__device__ inline VecT<float> div3(VecT<float> v, float t) { return {v.x / t, v.y / t, v.z / t}; }
+__device__ inline VecT<float> div3(VecT<float> v, float t) { return {div_t(v.x, t), div_t(v.y, t), div_t(v.z, t)}; }
 __device__ inline VecT<fastd> div3(VecT<fastd> v, fastd t)
 {
     const double r = rcp_nr2(t.v);
@@ -594,7 +614,7 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
         t = ORT_DIV(num, den);
 #else
         if constexpr (std::is_same<T, double>::value) t = div_plain(num, den);
-        else t = num / den;
+        else t = ORT_DIV(num, den);
 #endif
         hit = (qpos || cneg) && !neg;
         ORT_RARE(2, live & !ok);                     // tangent, degenerate, on the surface, out of range, or NaN
@@ -605,9 +625,9 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
         const T sq = ORT_SQRT(discrim);
         const T q = (b > T(0.0)) ? T(-0.5) * (b + sq) : T(-0.5) * (b - sq);
         const bool dz = discrim == T(0.0);            // :245-247
-        const T xd = T(-0.5) * b / a;
-        const T t0 = dz ? xd : q / a;
-        const T t1 = dz ? xd : c / q;
+        const T xd = ORT_DIV(T(-0.5) * b, a);
+        const T t0 = dz ? xd : ORT_DIV(q, a);
+        const T t1 = dz ? xd : ORT_DIV(c, q);
         const bool sw = t0 > t1;                      // :75-79
         const T lo = sw ? t1 : t0, hi = sw ? t0 : t1;
         const bool lneg = lo < T(0.0);                // :80-83
@@ -639,8 +659,8 @@ template <bool FILT, class T>
 __device__ inline void intersect_ellipse(const RayT<T> &r, T cy, T cz, T semia, T semib, T aux_sa, T aux_sb,
                                          bool live, T &t, bool &hit, bool &rare)
 {
-    T sa = FILT ? aux_sa : T(1.) / (semia * semia);
-    T sb = FILT ? aux_sb : T(1.) / (semib * semib);
+    T sa = FILT ? aux_sa : ORT_DIV(T(1.), semia * semia);
+    T sb = FILT ? aux_sb : ORT_DIV(T(1.), semib * semib);
     T Ly = r.pos.y - cy;
     T Lz = r.pos.z - cz;
     T a = sa * (r.dir.z * r.dir.z) + sb * (r.dir.y * r.dir.y);
@@ -658,8 +678,8 @@ __device__ inline T fresnel(T costt, T n1, T n2, T eta)
     T sintt = ORT_SQRT(T(1.) - costt * costt);
     T sint2 = eta * sintt;
     T cost2 = ORT_SQRT(T(1.) - sint2 * sint2);
-    T r1 = fabs((n1 * costt - n2 * cost2) / (n1 * costt + n2 * cost2));
-    T r2 = fabs((n1 * cost2 - n2 * costt) / (n1 * cost2 + n2 * costt));
+    T r1 = fabs(ORT_DIV(n1 * costt - n2 * cost2, n1 * costt + n2 * cost2));
+    T r2 = fabs(ORT_DIV(n1 * cost2 - n2 * costt, n1 * cost2 + n2 * costt));
     T tir = T(0.5) * (r1 * r1 + r2 * r2);
     tir = (tir != tir || tir > T(1.) || tir < T(0.)) ? T(1.) : tir;     // :366-369
     return (sint2 > T(1.)) ? T(1.0) : ((costt == T(1.)) ? T(0.) : tir);  // :353-358
@@ -763,7 +783,7 @@ __device__ inline void tauint(const RayT<T> &r, T mua, T mus, T cy, T cz, T radi
     nis += on ? 1 : 0;
     const T tauradius = d * mu_tot;
     const bool inside = tau < tauradius;
-    dist = inside ? tau / mu_tot : d;
+    dist = inside ? ORT_DIV(tau, mu_tot) : d;
     at_wall = !inside;
     ok = hit;
 }
@@ -778,8 +798,8 @@ __device__ inline void stokes_hg(VecT<T> &dir, T hgg, T twopi, bool on, D &draws
     const T phip = atan2(dir.y, dir.x);
     const T u1 = draws.template peek_as<T>();
     draws.advance(on);
-    const T w = (T(1.) - g2) / (T(1.) - hgg + T(2.) * hgg * u1);
-    T bmu = ((T(1.) + g2) - w * w) / (T(2.) * hgg);
+    const T w = ORT_DIV(T(1.) - g2, T(1.) - hgg + T(2.) * hgg * u1);
+    T bmu = ORT_DIV((T(1.) + g2) - w * w, T(2.) * hgg);
     T cosb2 = bmu * bmu;
     const bool clamp = fabs(bmu) > T(1.);
     bmu = clamp ? (bmu > T(1.) ? T(1.) : T(-1.)) : bmu;
@@ -798,8 +818,8 @@ __device__ inline void stokes_hg(VecT<T> &dir, T hgg, T twopi, bool on, D &draws
     const T sint_m = fabs(ORT_SQRT(T(1.) - cost * cost));
     const T bott = sint_m * sinbt;
     const T sint = mid ? sint_m : T(0.);
-    const T sini2 = mid ? sa * sintp / sint_m : T(0.);
-    const T cosi2 = mid ? costp / bott - cost * bmu / bott : (cost >= T(1.) ? T(-1.) : T(1.));
+    const T sini2 = mid ? ORT_DIV(sa * sintp, sint_m) : T(0.);
+    const T cosi2 = mid ? ORT_DIV(costp, bott) - ORT_DIV(cost * bmu, bott) : (cost >= T(1.) ? T(-1.) : T(1.));
     T cosdph = -cosi2 * ca + sini2 * sa * bmu;
     cosdph = fabs(cosdph) > T(1.) ? (cosdph > T(1.) ? T(1.) : T(-1.)) : cosdph;
     const T ac = acos(cosdph);
@@ -826,7 +846,7 @@ __device__ inline void scatter_walk(const Surf &s, T twopi, RayT<T> &r, T &t, bo
     t = on ? dist : t;
     bool alive = on && ok;                               // not yet ended inside the walk
     bool walking = alive && !at_wall;
-    const T albedo = s.mus / (s.mus + s.mua);
+    const T albedo = ORT_DIV(T(s.mus), T(s.mus + s.mua));
     while (wave_any(walking)) {
         r.pos = vselect(walking, vadd(r.pos, vscale(r.dir, t)), r.pos);
         const T u = draws.template peek_as<T>();
@@ -960,7 +980,7 @@ __device__ inline void emit_ring(const Sys &S, RayT<T> &r, D &draws, bool &rare)
     T posx = sq * ct;
     T posy = sq * st;
     T Ra = S.ring_bottle_ra;
-    T q = S.ring_ellipse ? posy * Ra / S.ring_bottle_rb : posy;            // :277 vs :279
+    T q = S.ring_ellipse ? ORT_DIV(posy * Ra, T(S.ring_bottle_rb)) : posy;            // :277 vs :279
     T posz = S.ring_bottle_z + sqrt_f<FILT, T>(Ra * Ra - q * q, true, rare);
     rr = T(0.) + draws.template next_as<T>() * (S.ring_lens_r2 - T(0.));           // ranu(0., (radius+10e-3)**2)
     theta = draws.template next_as<T>() * S.twopi;
@@ -1016,7 +1036,7 @@ __device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws)
         s = more ? y * y + x * x : s;
         more = more && (s >= T(1.));
     }
-    T cst = ORT_SQRT(T(-2.) * log(s) / s);
+    T cst = ORT_SQRT(ORT_DIV(T(-2.) * log(s), s));
     T tmp1 = T(0.) + S.crs_sigma * (x * cst);
     T tmp2 = T(0.) + S.crs_sigma * (y * cst);
     RayT<T> drop = {{tmp1, tmp2, T(1.0)}, {T(0.), T(0.), T(-1.)}};
@@ -1047,7 +1067,7 @@ __device__ inline void rang(D &draws, T sigma, T &gx, T &gy)
         s = more ? y * y + x * x : s;
         more = more && (s >= T(1.));
     }
-    T cst = ORT_SQRT(T(-2.) * log(s) / s);
+    T cst = ORT_SQRT(ORT_DIV(T(-2.) * log(s), s));
     gx = T(0.) + sigma * (x * cst);
     gy = T(0.) + sigma * (y * cst);
 }
@@ -1078,13 +1098,13 @@ __device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws)
     bool ok = true;
     {
         const VecT<T> hitp = vadd(pos, vscale(dir, t));
-        VecT<T> N = {T(2.) * (hitp.x - T(0.)) / k, T(2.) * (hitp.y - T(0.)) / k, -(T(2.) * (hitp.z - T(0.))) + T(2.) * height};
+        VecT<T> N = {ORT_DIV(T(2.) * (hitp.x - T(0.)), k), ORT_DIV(T(2.) * (hitp.y - T(0.)), k), -(T(2.) * (hitp.z - T(0.))) + T(2.) * height};
         N = vnormalise(vscale(N, T(-1.)));
         const T u = draws.template peek_as<T>();
         draws.advance(cone);
         VecT<T> d2 = dir;
         (void)reflect_refract<false, true, T>(d2, N, T(1.4), T(1.), T(1.4) / T(1.), T(0.), u, true, unused);
-        const T tt = T(S.isors_base_pos) / d2.z;
+        const T tt = ORT_DIV(T(S.isors_base_pos), d2.z);
         VecT<T> p2 = vadd(hitp, vscale(d2, tt));
         p2.z = T(S.isors_z);
         // bottle inner wall: circular (rad1 = rad2) or elliptical cylinder about x
@@ -1160,12 +1180,12 @@ __device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r
 template <class T, bool ANYSRC, bool FILT = false, class Sys, class D>
 __device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf, bool &rare)
 {
-    const int e = __builtin_amdgcn_readfirstlane(S.emitter[phase - 1]);
     if (!ANYSRC) {
         if (phase == 1) emit_ring<T, FILT>(S, r, draws, rare);
         else emit_point<T, FILT>(S, r, draws, rare);
         return -1;
     }
+    const int e = __builtin_amdgcn_readfirstlane(S.emitter[phase - 1]);
     bool unused = false;                                  // the other emitters are literal throughout
     if (e == ORT_EMIT_RING) emit_ring<T>(S, r, draws, unused);
     else if (e == ORT_EMIT_POINT) emit_point<T>(S, r, draws, unused);
@@ -1215,9 +1235,9 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
         d = vscale(d, T(-1.));
         const T top = (T(0.) * d.x) + (T(0.) * d.y) + (T(-1.) * d.z);
         const T bottom = ORT_SQRT(vdot(d, d)) * T(1.0);
-        reject = (top / bottom) < T(S.na_cos_min);
-        fx = floor(r.pos.x / T(S.bin_width));
-        fy = floor(r.pos.y / T(S.bin_width));
+        reject = ORT_DIV(top, bottom) < T(S.na_cos_min);
+        fx = floor(ORT_DIV(r.pos.x, T(S.bin_width)));
+        fy = floor(ORT_DIV(r.pos.y, T(S.bin_width)));
     }
     const bool off = (r.pos.x > T(1000) || r.pos.y > T(1000)) ||            // :48
                      !(fabs(fx) <= T(200.)) || !(fabs(fy) <= T(200.));       // :52

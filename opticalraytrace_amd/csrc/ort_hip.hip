@@ -250,11 +250,13 @@ struct DevSystem {
 // instructions as scalar operands instead of occupying VGPRs (an LDS read lands in VGPRs), which
 // is what lets the unrolled kernel fit 128 VGPRs without spilling.
 template <class T> struct ConstPtrs {       // fp64 and fast fp64 read the fp64 records
+    typedef const __attribute__((address_space(4))) ort_system *sys_t;
     typedef const __attribute__((address_space(4))) ort_surface *surf_t;
     typedef const __attribute__((address_space(4))) SurfAuxT<double> *aux_t;
     typedef ort_surface Surf;
 };
 template <> struct ConstPtrs<float> {
+    typedef const __attribute__((address_space(4))) SystemT<float> *sys_t;
     typedef const __attribute__((address_space(4))) SurfaceT<float> *surf_t;
     typedef const __attribute__((address_space(4))) SurfAuxT<float> *aux_t;
     typedef SurfaceT<float> Surf;
@@ -599,8 +601,12 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     __shared__ int QN[kWavesPerBlock][SCAT ? kQueueCap : 1];
     __shared__ unsigned int blk[4];
     __shared__ SurfAuxT<T> AUX[PROG == PROG_GENERIC ? ORT_MAX_SURFACES : 1];
-    stage_system(S, a.sys);
-    if (PROG == PROG_GENERIC) stage_aux(AUX, S.surfaces[a.phase - 1], S.n_surfaces[a.phase - 1]);
+    // a program kernel reads everything it needs of the system (surface records, emitter and image
+    // constants) through scalar loads from the device copy: nothing to stage, no barrier at its start
+    if (PROG == PROG_GENERIC) {
+        stage_system(S, a.sys);
+        stage_aux(AUX, S.surfaces[a.phase - 1], S.n_surfaces[a.phase - 1]);
+    }
     if (threadIdx.x < 4) blk[threadIdx.x] = 0;
     __syncthreads();
 
@@ -621,12 +627,15 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     const int ph = phase - 1;
     const typename SysTypes<T>::Surf *surf = S.surfaces[ph];
     // program kernels: scalar loads from the device copy in the kernel's own precision
+    typename ConstPtrs<T>::sys_t csys;
     typename ConstPtrs<T>::surf_t csurf;
     typename ConstPtrs<T>::aux_t caux;
     if constexpr (std::is_same<T, float>::value) {
+        csys = (typename ConstPtrs<T>::sys_t)a.sysf;
         csurf = (typename ConstPtrs<T>::surf_t)a.sysf->surfaces[ph];
         caux = (typename ConstPtrs<T>::aux_t)a.auxf;
     } else {
+        csys = (typename ConstPtrs<T>::sys_t)a.sys;
         csurf = (typename ConstPtrs<T>::surf_t)a.sys->surfaces[ph];
         caux = (typename ConstPtrs<T>::aux_t)a.aux;
     }
@@ -684,7 +693,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             }
             d.unpack(dw, a.rng_base);
             bool rare = false;
-            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n, true>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
+            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n, true>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
             else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
                 if (FILT && rare) defer(d.ray_of_packed(dw, a.rng_base) - a.first_ray);
@@ -707,10 +716,12 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 r.dir = {T(a.pos_dir_in[3 * ns_in + ic]), T(a.pos_dir_in[4 * ns_in + ic]), T(a.pos_dir_in[5 * ns_in + ic])};
             } else {
                 d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                const int est = emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
+                int est;
+                if constexpr (fixed) est = emit<T, ANYSRC, FILT && !ANYSRC>(*csys, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
+                else est = emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
                 st = est < 0 ? st : est;
             }
-            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split, false>(S, csurf, caux, r, d, nis, st, xp, yp, rare);
+            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split, false>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
             else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
             const bool deferred = FILT && rare && act;
             const bool survive = act && st < 0 && !deferred;
