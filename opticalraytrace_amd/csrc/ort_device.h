@@ -889,23 +889,47 @@ __device__ inline double scalar_const(double v)
 }
 #define ORT_SC(v) scalar_const(v)
 
+// the coefficients live in constant memory: a uniform address, so they arrive through scalar loads
+// as 64-bit SGPR pairs that the FMAs read directly (a literal would be parked in a VGPR pair for
+// the whole kernel; an SGPR pair assembled from two s_mov_b32 is first copied to VGPRs — two v_mov
+// per coefficient)
+__device__ __constant__ const double kSinCosTab[16] = {
+    6.36619772367581382433e-01,                      // 0  2/pi
+    1.57079632679489655800e+00, 6.12323399573676603587e-17,      // 1, 2  pi/2 head, tail
+    1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06,     // 3..8  sin: S6 .. S1
+    -1.98412698298579493134e-04, 8.33333333332248946124e-03, -1.66666666666666324348e-01,
+    -1.13596475577881948265e-11, 2.08757232129817482790e-09, -2.75573143513906633035e-07,    // 9..14 cos: C6 .. C1
+    2.48015872894767294178e-05, -1.38888888888741095749e-03, 4.16666666666666019037e-02,
+    0.0};
+// a * b + c with c a scalar (SGPR pair) operand of the instruction itself.  Left to the compiler, a
+// uniform addend is first copied into the destination VGPR pair (two v_mov_b32) so that the
+// two-address v_fmac_f64 can be used.
+__device__ inline double fma_sc(double a, double b, double c_uniform)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+    return r;
+}
+
 __device__ inline SinCosT<double> sincos_small(double x)
 {
-    const double k = __builtin_rint(x * ORT_SC(6.36619772367581382433e-01));        // x * 2/pi
-    double r = __builtin_fma(-k, ORT_SC(1.57079632679489655800e+00), x);
-    r = __builtin_fma(-k, ORT_SC(6.12323399573676603587e-17), r);
+    typedef const __attribute__((address_space(4))) double *ctab_t;
+    const ctab_t C = (ctab_t)kSinCosTab;
+    const double k = __builtin_rint(x * C[0]);        // x * 2/pi
+    double r = __builtin_fma(-k, C[1], x);
+    r = __builtin_fma(-k, C[2], r);
     const double z = r * r;
-    double ps = __builtin_fma(z, ORT_SC(1.58969099521155010221e-10), ORT_SC(-2.50507602534068634195e-08));
-    ps = __builtin_fma(z, ps, ORT_SC(2.75573137070700676789e-06));
-    ps = __builtin_fma(z, ps, ORT_SC(-1.98412698298579493134e-04));
-    ps = __builtin_fma(z, ps, ORT_SC(8.33333333332248946124e-03));
-    ps = __builtin_fma(z, ps, ORT_SC(-1.66666666666666324348e-01));
+    double ps = __builtin_fma(z, C[3], C[4]);
+    ps = fma_sc(z, ps, C[5]);
+    ps = fma_sc(z, ps, C[6]);
+    ps = fma_sc(z, ps, C[7]);
+    ps = fma_sc(z, ps, C[8]);
     const double sr = __builtin_fma(r * z, ps, r);
-    double pc = __builtin_fma(z, ORT_SC(-1.13596475577881948265e-11), ORT_SC(2.08757232129817482790e-09));
-    pc = __builtin_fma(z, pc, ORT_SC(-2.75573143513906633035e-07));
-    pc = __builtin_fma(z, pc, ORT_SC(2.48015872894767294178e-05));
-    pc = __builtin_fma(z, pc, ORT_SC(-1.38888888888741095749e-03));
-    pc = __builtin_fma(z, pc, ORT_SC(4.16666666666666019037e-02));
+    double pc = __builtin_fma(z, C[9], C[10]);
+    pc = fma_sc(z, pc, C[11]);
+    pc = fma_sc(z, pc, C[12]);
+    pc = fma_sc(z, pc, C[13]);
+    pc = fma_sc(z, pc, C[14]);
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double cr = w + (((1.0 - w) - hz) + z * z * pc);                  // k_cos.c's compensated form
