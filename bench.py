@@ -22,8 +22,8 @@ from the key, nothing is read from the host inside the timed region.
 value = intersections all ranks evaluated (exact int64 device counter) / wall time.
 
 Order of the legs in one process: CPU baseline (child process, before this process touches
-the GPU), set-up (scratch, code objects, 160 untimed launches that bring the clocks out of
-idle — see SETTLE_LAUNCHES), then the exact fp64 leg that `value` reports, then the
+the GPU), set-up (scratch, code objects, ~50 ms of untimed launches that bring the clocks out
+of idle — see SETTLE_LAUNCHES), then the exact fp64 leg that `value` reports, then the
 informational fp32 and fast-fp64 legs over the same rays.  Every leg: W untimed warm-up steps,
 then exactly K timed steps between two fences.
 """
@@ -198,12 +198,12 @@ def main() -> int:
     # and in imports) the first ~30 ms of GPU work run at lower clocks (tools/rampbench.py,
     # profiles/r02/ramp.log: 0.446 ms for the first 64 launches, 0.406 from then on).  A production run
     # of this path is >= 40 ms of back-to-back launches per 1e9-ray layer, so steady clocks are the
-    # regime the metric is about: SETTLE_LAUNCHES untimed launches of the workload itself come first,
+    # regime the metric is about: SETTLE_LAUNCHES (160 at 1e7 rays) untimed launches of the step's own size come first,
     # for every leg alike.  They are set-up like the priming launches above — not among the W warm-up
     # steps, not in the timed region — and are reported in config.settle_launches.
-    SETTLE_LAUNCHES = 160
+    SETTLE_LAUNCHES = max(2 * len(phases), min(160, 1_600_000_000 // cnt))   # launches of the step's own size: ~50 ms
     for k in range(SETTLE_LAUNCHES):
-        ctx.trace(phases[k % len(phases)], k * cnt, min(cnt, 10_000_000), DEFAULT_SEED)
+        ctx.trace(phases[k % len(phases)], k * cnt, cnt, DEFAULT_SEED)
     ctx.synchronize()
 
     # step k traces the global ray indices [k*T, (k+1)*T) of each of its phases (T = rays per layer

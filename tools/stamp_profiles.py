@@ -54,12 +54,18 @@ def main():
         ks = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
         if ks:
             shutil.copy(ks[0], os.path.join(dst, f"{w}_kernel_stats.csv"))
-        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        # launches of full size only: bench.py's set-up also runs each kernel once on 64 rays
+        rows = []
         for f in glob.glob(os.path.join(d, "pmc*", "**", "*counter_collection.csv"), recursive=True):
-            for r in csv.DictReader(open(f)):
-                k = short(r["Kernel_Name"])
-                if k:
-                    agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            rows += [r for r in csv.DictReader(open(f)) if short(r["Kernel_Name"])]
+        biggest = collections.defaultdict(int)
+        for r in rows:
+            biggest[short(r["Kernel_Name"])] = max(biggest[short(r["Kernel_Name"])], int(r["Grid_Size"]))
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            if int(r["Grid_Size"]) == biggest[k]:
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         summ = {k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in sorted(cs.items())}
                 for k, cs in sorted(agg.items())}
         json.dump(summ, open(os.path.join(dst, f"{w}_pmc_summary.json"), "w"), indent=1)
