@@ -1299,7 +1299,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
     nis += live ? 1 : 0;
     VecT<T> N;
     bool proceed;                    // lanes that reach the Fresnel decision at this surface
-    int ended = -1;                  // status of lanes that end before it
+    int code = lost;                 // status of a lane that ends at this surface
     if (kind == ORT_SURF_SPHERE || kind == ORT_SURF_CYLINDER || kind == ORT_SURF_ELLIPSE) {
         T t;
         bool hit;
@@ -1319,8 +1319,10 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         const VecT<T> Nraw = {cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z};
         if (kind == ORT_SURF_ELLIPSE) N = vnormalise_f<FILT, T>(Nraw, live && hit, rare, cyl);
         else N = vnormalise_est<FILT, T>(Nraw, T(s.radius), ax.rh, ax.rk, ax.r2_tol, live && hit, rare, cyl);   // |N| = radius
-        ended = !hit ? ((flags & ORT_F_MISS_IS_HELP3) ? ORT_ST_HELP3 : lost) : (out ? lost : -1);
-        ended = walk_end >= 0 ? walk_end : ended;
+        // a lane that ends here: missed (Help3 where the reference aborts), outside the aperture,
+        // reflected (all: `lost`), or ended inside the scattering walk
+        if (flags & ORT_F_MISS_IS_HELP3) code = hit ? lost : ORT_ST_HELP3;
+        if (EXT) code = walk_end >= 0 ? walk_end : code;
         proceed = live && hit && !out;
     } else {
         // plane kinds: d = (z_plane - pos%z) / dir%z ; pos = pos + dir*d
@@ -1341,7 +1343,6 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         }
         r.pos = KEEP ? vselect(live, moved, r.pos) : moved;
         N = {T(0.), T(0.), T(-1.)};                         // flatNormal, lens.f90:165
-        ended = out ? lost : -1;
         proceed = live && !out;
     }
     T u;
@@ -1353,7 +1354,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
     }
     const bool reflected = reflect_refract<FILT, KEEP, T>(r.dir, N, s.n1, s.n2, s.eta, ax.eta2, u, proceed, rare);
     const bool dies = reflected && (flags & ORT_F_SKIP_ON_REFLECT);
-    st = live ? (proceed ? (dies ? lost : -1) : ended) : st;
+    st = live ? ((proceed & !dies) ? -1 : code) : st;
 }
 
 }  // namespace ort
