@@ -4,11 +4,14 @@
     make -C opticalraytrace_amd/csrc isa            # build/isa/ort_hip_mark.s (-DORT_ISA_MARKERS)
     python tools/isa_budget.py build/isa/ort_hip_mark.s 'trace_queue_kernel<0, true, false, double, 1, false>' [OUT.json]
 
-Static counts per region of the listing: the regions are cut by the `; ORT_STEP_BEGIN k` /
-`; ORT_STEP_END k` comment lines the marker build emits around every surface step of a program
-kernel (what lies outside them is emission, queue traffic, bookkeeping).  A step is executed by
-every ray that reaches it, so static count x rays entering the step (SURVEY §6 stage-survival table,
-or the kernel's own counters) is the dynamic budget.  Classes follow what costs differently on
+Static counts per region of the listing.  The marker build emits `; ORT_STEP_END k` comment lines
+behind every surface step of a program kernel; pure arithmetic is free to move across such a
+line, and in practice a step's instructions end up in front of its markers, so region "step k" =
+the lines between the END markers of steps k-1 and k (approximate at the edges: emission and step
+0 share the first region, queue traffic and loop control sit in the regions around the queue
+point).  A step is executed by every ray that reaches it, so static count x rays entering the step
+(SURVEY §6 stage-survival table, or the kernel's own counters) is the dynamic budget; the whole-
+kernel totals are exact.  Classes follow what costs differently on
 gfx950 (profiles/r01/ubench*.log): fp64 fma/mul/add ~1 issue slot, v_rcp/v_rsq_f64 ~3.5 slots,
 compares, selects, 32/64-bit integer (the RNG), everything scalar."""
 import collections
@@ -65,14 +68,13 @@ def main():
     i0 = pick[0][0]
     i1 = next(i for i in range(i0, len(lines)) if lines[i].strip().startswith("s_endpgm"))
     regions = collections.OrderedDict()
-    cur = "outside steps (emission, queue, bookkeeping)"
+    cur = "prologue + emission + step 0"
     for ln in lines[i0:i1 + 1]:
         t = ln.strip()
-        if m := re.match(r"; ORT_STEP_BEGIN (\d+)", t):
-            cur = f"step {m.group(1)}"
+        if re.match(r"; ORT_STEP_BEGIN (\d+)", t):
             continue
-        if re.match(r"; ORT_STEP_END", t):
-            cur = "outside steps (emission, queue, bookkeeping)"
+        if m := re.match(r"; ORT_STEP_END (\d+)", t):
+            cur = f"step {int(m.group(1)) + 1} (+ what follows step {m.group(1)})"
             continue
         if not t or t.startswith((";", ".", "//")) or t.split(";")[0].strip().endswith(":"):
             continue
