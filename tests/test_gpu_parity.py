@@ -495,3 +495,37 @@ def test_program_kernels_equal_the_generic_walk(name, hip_library):
     assert int(cnt0[2]) > 0 and int(cnt0[3]) > 0
     for img, cnt in results[1:]:
         assert np.array_equal(img, img0) and np.array_equal(cnt, cnt0)
+
+
+def test_deferred_rays_of_a_group_of_launches(hip_library):
+    """Fused launches defer rays to ONE list per group of launches; the literal re-run comes when the
+    group closes.  The spot source's first ten rays travel exactly along the axis (costt == 1 at the
+    flat faces: the reference's NaN rule, always deferred), so every launch below leaves entries on
+    the list: several launches per group, groups closed by a read, by a ray range that jumps back,
+    by a change of phase — images and counters must equal the oracle's and the lockstep kernel's."""
+    from opticalraytrace_amd.capi import Context
+    _, osys = make_system("small_spot")
+    orc = _oracle(osys)
+    n = osys.settings.nphotons                            # 100: create_spot's fan
+    want = np.zeros((2, 401, 401), np.int32); wc = np.zeros(8, np.uint64)
+    orc.trace(2, 0, n, SEED, want, wc)
+    orc.trace(1, 0, 2000, SEED, want, wc)
+    with Context(osys) as ctx:
+        out = []
+        for variant in (1, 0):                            # queued + filtered (deferring), lockstep
+            ctx.set_kernel_variant(variant)
+            ctx.reset()
+            ctx.trace(2, 0, 30, SEED)                     # one group: three launches, rising ranges
+            ctx.trace(2, 30, 30, SEED)
+            ctx.trace(2, 60, 20, SEED)
+            ctx.trace(1, 0, 2000, SEED)                   # other phase: closes the group
+            ctx.trace(2, 90, 10, SEED)
+            ctx.trace(2, 80, 10, SEED)                    # jumps back: closes the group
+            out.append(ctx.read())
+        ctx.set_kernel_variant(1)
+        got = ctx.trace_rays(2, n, seed=SEED)
+    assert (got["status"][:9] >= 0).all()
+    for img, cnt in out:
+        assert np.array_equal(img[1], want[1]) and np.abs(img[0].astype(np.int64) - want[0]).sum() <= 2
+        assert np.array_equal(cnt[[1, 3, 5, 7]], wc[[1, 3, 5, 7]])
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

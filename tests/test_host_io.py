@@ -65,3 +65,18 @@ def test_shard_ranges_tile_the_index_range():
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+def test_bench_refuses_more_ranks_than_gpus_before_touching_a_gpu():
+    """`python bench.py --gpus N` as the driver issues it: on a box with fewer GPUs (here: none) a
+    message and exit status 2 — no traceback, no JSON line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("this box has GPUs: covered by tests/test_gpu_distributed.py")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "GPU(s)" in p.stderr and "Traceback" not in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
