@@ -29,6 +29,7 @@
 // No MFMA: there is no contraction anywhere on this path; the kernel is bound by
 // fp64 VALU issue (IEEE divide / sqrt expansions), not by HBM.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -873,6 +874,7 @@ struct ort_ctx {
     int32_t *d_image, *own_image;
     int32_t *d_replicas;         // kReplicas x 2 layers x kSlots: hits not yet folded into the image
     bool fold_pending[2];        // per layer: the replicas hold hits (fold_kernel runs when the image is needed)
+    hipEvent_t launch_ev[2];     // start / stop events the next kernel launch carries itself (null: none)
     // deferral group: consecutive fused launches of one phase / seed / system whose deferred rays share
     // the re-run list; the literal re-run is launched when the group closes (close_group)
     bool group_open;
@@ -982,7 +984,7 @@ static int flush_replicas(ort_ctx *c)
 template <class T, bool FILT = true>
 static void launch_lean(ort_ctx *c, int mode, const TraceArgs &a, int grid)
 {
-#define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
+#define ORT_LAUNCH(K) hipExtLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, c->launch_ev[0], c->launch_ev[1], 0, a)
     // a program's draw indices are compile-time constants: they assume the emitter's own number of
     // draws in front of the first surface (resident bundles may come with another draw_base)
     int prog = c->prog[a.phase - 1];
@@ -1149,7 +1151,7 @@ int ort_flush(ort_ctx *c)
 static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool queued, bool filt, bool anysrc)
 {
     const bool scat = c->scatter[a.phase - 1];
-#define ORT_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, a)
+#define ORT_LAUNCH(K) hipExtLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, c->launch_ev[0], c->launch_ev[1], 0, a)
     if (c->precision == 2) {
         // fast fp64 (ort_fastd.h): FMA contraction, Newton divide / Goldschmidt sqrt; ~1e-13 from exact
         if (mode == MODE_DEBUG) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, fastd, true>));
@@ -1243,10 +1245,14 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
         a0.redo_ctl = c->d_redo_ctl;
     }
     const int slot = (int)(c->ring_count % kTimingRing);
-    // fused traces (evk 0) are timed by the ring's event pair alone: every event record is a
-    // packet the command processor handles between two kernels
+    // fused traces (evk 0) are timed by the ring's event pair.  A trace that is ONE kernel launch
+    // hands the pair to the launch itself (hipExtLaunchKernel: start / stop of that dispatch, no
+    // packet of its own); every separate event record is a packet the command processor handles
+    // between two kernels (~2 us each at 1e7 rays per launch).
+    const bool one_launch = total <= step;
+    const bool ext_timed = c->timing && evk == 0 && one_launch;
     if (c->timing && evk > 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
-    if (c->timing && evk == 0) HIP_TRY(hipEventRecord(c->ring[slot][0], c->stream));
+    if (c->timing && evk == 0 && !ext_timed) HIP_TRY(hipEventRecord(c->ring[slot][0], c->stream));
     for (uint64_t off = 0; off < total; off += step) {
         TraceArgs a = a0;
         a.n_rays = total - off < step ? total - off : step;
@@ -1274,7 +1280,9 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
             const int rc = close_group(c);                  // anything else runs behind the group's re-run
             if (rc) return rc;
         }
+        if (ext_timed) { c->launch_ev[0] = c->ring[slot][0]; c->launch_ev[1] = c->ring[slot][1]; }
         launch_one(c, mode, a, grid, queued, filt, anysrc);
+        c->launch_ev[0] = c->launch_ev[1] = nullptr;
         HIP_TRY(hipGetLastError());                         // a failed launch is reported where it happened
         if (deferring && mode != MODE_FUSED) {              // resident bundles: re-run at once (the bundle is the caller's)
             a.listed = 1;
@@ -1284,7 +1292,11 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     }
     if (use_rep) c->fold_pending[a0.phase - 1] = true;     // folded when the image is next needed (flush_replicas)
     if (c->timing && evk > 0) { HIP_TRY(hipEventRecord(c->ev[evk][1], c->stream)); c->ev_valid[evk] = true; }
-    if (c->timing && evk == 0) { HIP_TRY(hipEventRecord(c->ring[slot][1], c->stream)); c->ring_count++; c->ev_valid[0] = true; }
+    if (c->timing && evk == 0) {
+        if (!ext_timed) HIP_TRY(hipEventRecord(c->ring[slot][1], c->stream));
+        c->ring_count++;
+        c->ev_valid[0] = true;
+    }
     return ORT_OK;
 }
 
