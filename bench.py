@@ -273,9 +273,12 @@ def main() -> int:
     # ---- roofline of the dominant kernel (the fused trace kernel), per launch = per rank per phase
     # of a step.  kernel_ms holds one entry per ort_trace call (queued kernel + its literal re-run
     # launch + fold_kernel, one event bracket); a step of a two-phase workload is two launches.
-    launches_per_step = len(phases)
-    k_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3                  # mean launch, s
-    rays_launch = cnt
+    # ... and an ort_trace call of more than ORT_MAX_RAYS_PER_LAUNCH rays is several kernel launches.
+    kernels_per_call = -(-cnt // capi.MAX_RAYS_PER_LAUNCH)
+    launches_per_step = len(phases) * kernels_per_call
+    call_s = (sum(kernel_ms) / len(kernel_ms)) * 1e-3               # mean ort_trace call, s
+    k_s = call_s / kernels_per_call                                 # mean kernel launch, s
+    rays_launch = cnt / kernels_per_call
     isect_launch = isect_per_step / world / launches_per_step
     binned_launch = binned_per_step / world / launches_per_step
     ring_share = sum(1 for ph in phases if ph == 1) / launches_per_step
@@ -287,13 +290,13 @@ def main() -> int:
     prof = prof or {}
     traffic = prof.get("hbm_bytes_per_launch")
 
-    def fp_roofline(kms, r, peak, bound):
-        ks = (sum(kms) / len(kms)) * 1e-3
+    def fp_roofline(kms, r, peak, bound, kernels):
+        """per CALL here: the fp32 path is not cut into launches of 2^25 rays (nothing is deferred)"""
+        ks = (sum(kms) / len(kms)) * 1e-3 / kernels
         i, _ = isect_binned(r)
-        fl = FLOP_PER_INTERSECTION * i / args.steps / world / launches_per_step \
-            + FLOP_PER_RING_EMISSION * rays_launch * ring_share
+        fl = (FLOP_PER_INTERSECTION * i / args.steps / world / len(phases) + FLOP_PER_RING_EMISSION * cnt * ring_share) / kernels
         return {"bound": bound, "achieved": fl / ks / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": fl / ks / 1e12 / peak, "kernel_ms": ks * 1e3}
+                "frac": fl / ks / 1e12 / peak, "kernel_ms": ks * 1e3, "kernel_launches_per_step": len(phases) * kernels}
 
     out = {
         "metric": "ray-surface intersections/sec",
@@ -324,7 +327,9 @@ def main() -> int:
             "traffic": traffic,                                   # HBM bytes per launch, rocprofv3 PMC (or null)
             "kernel": "trace_queue_kernel<MODE_FUSED, filtered, surface program> (+ the literal re-run launch, "
                       "same event bracket; fold_kernel runs once per run, when the image is read)",
-            "kernel_ms": k_s * 1e3,
+            "kernel_ms": k_s * 1e3,                               # mean duration of ONE kernel launch
+            "kernel_launches_per_step": launches_per_step,        # phases x launches of <= 2^25 rays per ort_trace call
+            "rays_per_kernel_launch": rays_launch,
             "flop_per_intersection": FLOP_PER_INTERSECTION,
             "flop_per_ring_emission": FLOP_PER_RING_EMISSION,
             "algorithmic_flop_per_launch": alg_flop,
@@ -360,7 +365,7 @@ def main() -> int:
         i32, b32 = isect_binned(r)
         out["fp32"] = {
             "value": i32 / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3, "dtype": "f32",
-            "roofline": fp_roofline(kms, r, FP32_VEC_PEAK_TFLOPS, "valu_fp32"),
+            "roofline": fp_roofline(kms, r, FP32_VEC_PEAK_TFLOPS, "valu_fp32", 1),
             "image_l1_vs_exact": int(abs(r.image.astype("int64") - res.image.astype("int64")).sum()),
             "image_l1_vs_exact_frac_of_binned": float(abs(r.image.astype("int64") - res.image.astype("int64")).sum()) / max(binned_total, 1),
             "binned": b32, "binned_exact": binned_total, "intersections": i32, "intersections_exact": isect_total,
@@ -372,7 +377,7 @@ def main() -> int:
         i2, _ = isect_binned(r)
         out["fast_fp64"] = {
             "value": i2 / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3,
-            "roofline": fp_roofline(kms, r, FP64_VEC_PEAK_TFLOPS, "valu_fp64"),
+            "roofline": fp_roofline(kms, r, FP64_VEC_PEAK_TFLOPS, "valu_fp64", kernels_per_call),
             "image_l1_vs_exact": int(abs(r.image.astype("int64") - res.image.astype("int64")).sum()),
             "note": "ort_set_precision(2): FMA contraction + Newton reciprocal/rsqrt; ~1e-15 relative from the "
                     "exact path, not bit-identical (tests/test_gpu_fastd.py)",

@@ -32,6 +32,8 @@ extern "C" {
 #define ORT_IMAGE_N 401
 #define ORT_IMAGE_BINS (2 * 401 * 401)
 #define ORT_NUM_COUNTERS 8
+#define ORT_MAX_RAYS_PER_LAUNCH (1u << 25)  /* ort_trace / ort_trace_resident cut a call into kernel launches of at
+                                               most this many rays (fp64 paths; bounds the re-run list) */
 
 /* error codes */
 #define ORT_OK 0

@@ -60,7 +60,7 @@ static_assert(ORT_IMAGE_N * ORT_IMAGE_N <= (int)kSlots, "a layer must fit the sl
 constexpr size_t kReplicaInts = 2 * (size_t)kSlots;   // both layers of one replica
 constexpr int kMaxBlocks = 256 * 12;    // 256 CUs x 12 workgroups = 3 rounds at 4 resident per CU: the static ranges'
                                         // cost spread (~10 %) then idles the chip for 1/3 less than with 2 rounds
-constexpr uint64_t kChunkRays = 1ull << 25;   // rays per launch of the queued kernel (bounds the re-run list: 4 B per ray)
+constexpr uint64_t kChunkRays = ORT_MAX_RAYS_PER_LAUNCH;   // rays per launch of the queued kernel (bounds the re-run list: 4 B per ray)
 constexpr int kRedoBlocks = 128;        // grid of the literal re-run kernel (it normally finds an empty list and returns)
 
 enum { MODE_FUSED = 0, MODE_RESIDENT = 1, MODE_DEBUG = 2 };
