@@ -281,7 +281,7 @@ def main() -> int:
     rays_launch = cnt / kernels_per_call
     isect_launch = isect_per_step / world / launches_per_step
     binned_launch = binned_per_step / world / launches_per_step
-    ring_share = sum(1 for ph in phases if ph == 1) / launches_per_step
+    ring_share = sum(1 for ph in phases if ph == 1) / len(phases)     # share of the launches that emit ring rays
     alg_flop = FLOP_PER_INTERSECTION * isect_launch + FLOP_PER_RING_EMISSION * rays_launch * ring_share
     contract_bytes = BYTES_PER_RAY * rays_launch + BYTES_PER_BINNED * binned_launch
     ach_tf = alg_flop / k_s / 1e12
