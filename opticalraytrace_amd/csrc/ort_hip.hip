@@ -805,11 +805,13 @@ int env_int(const char *name, int dflt)
 // Ray ranges of a queued launch of n rays.  A launch of equal ranges ends with a partly filled last
 // round of workgroups: the chip runs at 2 waves per SIMD instead of 5 for the last ~10 % of the time
 // (measured: two launches overlapped on two streams took 10 % less than back to back).  So the bulk
-// of the rays (kHeadPercent) goes to kHeadBlocks workgroups — two full rounds of the 1280 the chip
-// holds at once — in long ranges, and the rest to many workgroups of kTailBatches 64-ray batches per
-// wave, which the dispatcher hands to whichever CU frees up: the chip drains within one short
-// workgroup.  Small launches keep equal ranges.  Scheduling only: results do not depend on it.
-constexpr int kHeadBlocks = 2560, kHeadPercent = 92, kTailBatches = 4;
+// of the rays (kHeadPercent) goes to kHeadBlocks workgroups — one full round of the 1280 the chip
+// holds at once (256 CUs x 5) — in long ranges, and the rest to many workgroups of kTailBatches
+// 64-ray batches per wave, which the dispatcher hands to whichever CU frees up: the chip drains
+// within one short workgroup.  (Swept on the GPU, 1e7 rays per launch: 1280 / 86 % / 6 batches;
+// 2560 / 92 % / 4 is 2 % slower, equal ranges 5 %.)  Small launches keep equal ranges.
+// Scheduling only: results do not depend on it.
+constexpr int kHeadBlocks = 1280, kHeadPercent = 86, kTailBatches = 6;
 int plan_ranges(TraceArgs &a)
 {
     static const int head_blocks = env_int("ORT_HEAD_BLOCKS", kHeadBlocks), head_pct = env_int("ORT_HEAD_PERCENT", kHeadPercent),

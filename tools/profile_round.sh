@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile (GPU box): for each bench workload, `rocprofv3 --kernel-trace --stats` of the bench
 # command itself and the PMC passes (each in its own run: --pmc never together with other trace
-# domains than --kernel-trace), into gpurun_out/prof/<workload>/.  tools/stamp_profiles.py turns the
+# domains than --kernel-trace), then the plain bench line, into gpurun_out/prof/<workload>/.  tools/stamp_profiles.py turns the
 # CSVs into profiles/rNN/*.json and profiles/pmc_per_launch.json (stamped with ort_build_id()).
 #   usage: bash tools/profile_round.sh [workloads...]      (default: point1e7 ring1e8 full1e9)
 set -u
@@ -16,8 +16,6 @@ for w in $WL; do
     full1e9)  STEPS="--steps 4 --warmup 1";    PSTEPS="--steps 1 --warmup 0";;
   esac
   D=$OUT/$w; mkdir -p $D
-  echo "== $w: plain bench"
-  python3 $R/bench.py --workload $w $STEPS > $D/bench.json 2> $D/bench.err || exit 1
   echo "== $w: kernel trace"
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -o t -- python3 $R/bench.py --workload $w $STEPS --no-cpu-baseline > $D/bench_under_rocprof.json 2> $D/trace.err || exit 1
   i=0
@@ -29,5 +27,18 @@ for w in $WL; do
     echo "== $w: pmc pass $i: $set"
     rocprofv3 --pmc $set --kernel-trace --output-format csv -d $D/pmc$i -o p -- python3 $R/bench.py --workload $w $PSTEPS --no-cpu-baseline --no-fp32 --no-fast > $D/pmc$i.json 2> $D/pmc$i.err || echo "pass $i failed (see pmc$i.err)"
   done
+done
+# the plain bench lines last, quoting the counters just collected (bench.py reads
+# profiles/pmc_per_launch.json only when its build id is the library's)
+python3 $R/tools/stamp_profiles.py _box $OUT > $OUT/stamp_on_box.log 2>&1 || exit 1
+rm -rf $R/profiles/_box
+for w in $WL; do
+  case $w in
+    point1e7) STEPS="--steps 200 --warmup 20";;
+    ring1e8)  STEPS="--steps 40 --warmup 4";;
+    full1e9)  STEPS="--steps 4 --warmup 1";;
+  esac
+  echo "== $w: plain bench"
+  python3 $R/bench.py --workload $w $STEPS > $OUT/$w/bench.json 2> $OUT/$w/bench.err || exit 1
 done
 echo done
