@@ -572,7 +572,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
 // over a contiguous range of global ray indices.  The surface list is cut into two
 // segments at S.split (host-chosen: just after the aperture stop that removes most
 // rays).  Segment 1 runs in lockstep on 64 fresh rays; the survivors are appended to
-// a wave-private ray queue in LDS (SoA: pos, dir, RNG counter; 128 slots).  As soon
+// a wave-private ray queue in LDS (SoA: pos, dir in the kernel's precision, draw state; 128 slots).  As soon
 // as 64 rays are queued the wave runs segment 2 on a FULL wavefront.  Dead lanes of
 // segment 1 therefore never ride along through segment 2 — the lanes stay busy
 // although rays die at different surfaces.  No workgroup barrier is involved: a
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
 // ---------------------------------------------------------------------------
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kQueueCap = 128;      // >= 63 leftover + 64 new survivors
-constexpr int kQueueFields = 7;     // px py pz dx dy dz + RNG counter bits
+constexpr int kQueueFields = 6;     // px py pz dx dy dz (+ the draw state: its own array)
 
 __device__ inline int lane_prefix(unsigned long long mask)
 {
@@ -596,7 +596,12 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                   "programs exist for the lean kernels only: filtered (fp64, fast fp64) or fp32");
     static_assert(!FILT || !std::is_same<T, float>::value, "the fp32 path evaluates every predicate literally");
     __shared__ typename SysTypes<T>::Sys S;
-    __shared__ double Q[kWavesPerBlock][kQueueFields][kQueueCap];
+    // 26.6 KB per workgroup of a program kernel in fp64 (6 workgroups per CU's 160 KB), 14 KB in fp32
+    constexpr bool fixed = PROG != PROG_GENERIC;        // surface program known at compile time
+    using QT = typename std::conditional<std::is_same<T, float>::value, float, double>::type;
+    using QD = typename std::conditional<fixed, uint32_t, uint64_t>::type;   // program: the ray's index in the launch
+    __shared__ QT Q[kWavesPerBlock][kQueueFields][kQueueCap];
+    __shared__ QD QDRAW[kWavesPerBlock][kQueueCap];
     // intersections evaluated before the queue point: `split` for every survivor unless a surface
     // scatters (extended instantiation), so only that one carries the count through the queue
     __shared__ int QN[kWavesPerBlock][SCAT ? kQueueCap : 1];
@@ -613,9 +618,9 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    double (*q)[kQueueCap] = Q[wave];
+    QT (*q)[kQueueCap] = Q[wave];
+    QD *qd = QDRAW[wave];
     int *qn = QN[wave];
-    constexpr bool fixed = PROG != PROG_GENERIC;        // surface program known at compile time
     using DrawsT = typename std::conditional<fixed, ProgDraws, KeyedDraws>::type;
     int phase = a.phase, ns, split;
     if constexpr (fixed) {
@@ -684,20 +689,21 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             qcount -= m;
             RayT<T> r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}};
             DrawsT d;
-            uint64_t dw = 0;                             // the queued image of the draw state
+            QD dw = 0;                                   // the queued image of the draw state
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
             if (act) {
                 r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
                 r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
-                dw = (uint64_t)__double_as_longlong(q[6][slot]);
+                dw = qd[slot];
                 nis = SCAT ? qn[slot] : split;
             }
-            d.unpack(dw, a.rng_base);
+            if constexpr (fixed) d.init_keyed(a.rng_base, a.first_ray + dw, 0);
+            else d.unpack(dw, a.rng_base);
             bool rare = false;
             if constexpr (fixed) walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n, true>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
             else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
-                if (FILT && rare) defer(d.ray_of_packed(dw, a.rng_base) - a.first_ray);
+                if (FILT && rare) defer(fixed ? (uint64_t)dw : d.ray_of_packed(dw, a.rng_base) - a.first_ray);
                 else finish(st, nis, xp, yp);
             }
             __builtin_amdgcn_wave_barrier();
@@ -729,9 +735,10 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(survive);
             if (survive) {
                 const int slot = (qhead + qcount + lane_prefix(mask)) & (kQueueCap - 1);
-                q[0][slot] = (double)r.pos.x; q[1][slot] = (double)r.pos.y; q[2][slot] = (double)r.pos.z;
-                q[3][slot] = (double)r.dir.x; q[4][slot] = (double)r.dir.y; q[5][slot] = (double)r.dir.z;
-                q[6][slot] = __longlong_as_double((long long)d.pack());
+                q[0][slot] = (QT)r.pos.x; q[1][slot] = (QT)r.pos.y; q[2][slot] = (QT)r.pos.z;
+                q[3][slot] = (QT)r.dir.x; q[4][slot] = (QT)r.dir.y; q[5][slot] = (QT)r.dir.z;
+                if constexpr (fixed) qd[slot] = (uint32_t)i;
+                else qd[slot] = d.pack();
                 if (SCAT) qn[slot] = nis;
             } else if (deferred) {
                 defer(i);
@@ -803,14 +810,15 @@ int env_int(const char *name, int dflt)
 }
 
 // Ray ranges of a queued launch of n rays.  A launch of equal ranges ends with a partly filled last
-// round of workgroups: the chip runs at 2 waves per SIMD instead of 5 for the last ~10 % of the time
-// (measured: two launches overlapped on two streams took 10 % less than back to back).  So the bulk
-// of the rays (kHeadPercent) goes to kHeadBlocks workgroups — one full round of the 1280 the chip
-// holds at once (256 CUs x 5) — in long ranges, and the rest to many workgroups of kTailBatches
-// 64-ray batches per wave, which the dispatcher hands to whichever CU frees up: the chip drains
-// within one short workgroup.  (Swept on the GPU, 1e7 rays per launch: 1280 / 86 % / 6 batches;
-// 2560 / 92 % / 4 is 2 % slower, equal ranges 5 %.)  Small launches keep equal ranges.
-// Scheduling only: results do not depend on it.
+// round of workgroups: the chip runs at 2 waves per SIMD instead of 5-6 for the last ~10 % of the
+// time (measured: two launches overlapped on two streams took 10 % less than back to back).  So the
+// bulk of the rays (kHeadPercent) goes to kHeadBlocks = 256 CUs x 5 workgroups in long ranges, and
+// the rest to many workgroups of kTailBatches 64-ray batches per wave, which the dispatcher hands
+// to whichever CU has room (the fp64 program kernels fit 6 per CU, so the first of them start
+// beside the long ones): the chip drains within one short workgroup.  Swept on the GPU at 1e7 rays
+// per launch (profiles/r02/range_plan_sweep.log): 1280 / 86 % / 6; 1024 or 1536 long workgroups
+// +2 %, 2560 / 92 % / 4 +3 %, equal ranges +5 %; at 2^25 rays per launch the choice is within
+// 0.5 %.  Small launches keep equal ranges.  Scheduling only: results do not depend on it.
 constexpr int kHeadBlocks = 1280, kHeadPercent = 86, kTailBatches = 6;
 int plan_ranges(TraceArgs &a)
 {
