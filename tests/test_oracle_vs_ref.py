@@ -8,6 +8,7 @@ import pytest
 
 from conftest import CONFIGS, isors_safe_uniforms, make_system, needs_extended_res, res_dir_with_image
 from parity import emit_draws, merge_status
+from random_systems import SEEDS as RANDOM_SEEDS
 from oracle.binding import Oracle, Reference, reference_available
 from opticalraytrace_amd.params import resource_dir
 
@@ -90,3 +91,30 @@ def test_reference_constants_match_host_model():
     assert osys.cos_theta_max == c[33] and osys.r1 == c[34] and osys.r2 == c[35]
     assert osys.img_plane == c[36] and osys.na_angle == c[39] and osys.bin_width == c[40]
     assert osys.L3[1].n3 == c[22] and osys.bottle.ncontents == c[1]
+
+
+@pytest.mark.parametrize("seed", RANDOM_SEEDS)
+def test_oracle_equals_reference_on_random_systems(seed):
+    """Perturbed lens and bottle files, random wavelength / iris / fibre offset / image diameter
+    (tests/random_systems.py): the restatement follows the reference bit for bit there too."""
+    from random_systems import random_system
+    from opticalraytrace_amd.system import OpticalSystem
+    settings, res = random_system(seed)
+    osys = OpticalSystem.from_settings(settings, res)
+    ref = Reference(settings, res)
+    orc = Oracle(osys)
+    c = ref.constants()               # the host model derives the same run constants from these files
+    assert osys.cos_theta_max == c[33] and osys.r1 == c[34] and osys.r2 == c[35]
+    assert osys.img_plane == c[36] and osys.na_angle == c[39] and osys.bin_width == c[40]
+    n = 20000
+    u = np.random.default_rng(seed).random((9, n))
+    for phase in (1, 2):
+        a = orc.trace_rays(phase, n, u=u)
+        b = ref.trace_rays(phase, n, u=u)
+        assert np.array_equal(merge_status(a["status"]), b["status"]), (seed, phase)
+        assert np.array_equal(a["emitted"], b["emitted"]), (seed, phase)
+        assert np.array_equal(a["n_draws"], b["n_draws"]), (seed, phase)
+        reach = b["status"] <= 1
+        assert np.array_equal(a["pos_dir"][:, reach], b["pos_dir"][:, reach]), (seed, phase)
+        binned = b["status"] == 0
+        assert np.array_equal(a["bin_xy"][:, binned], b["bin_xy"][:, binned]), (seed, phase)
