@@ -34,6 +34,8 @@ extern "C" {
 #define ORT_NUM_COUNTERS 8
 #define ORT_MAX_RAYS_PER_LAUNCH (1u << 25)  /* ort_trace / ort_trace_resident cut a call into kernel launches of at
                                                most this many rays (fp64 paths; bounds the re-run list) */
+#define ORT_MAX_RAY_INDEX (1ull << 40)      /* global ray indices are below this (the keyed draw counter is
+                                               (ray << 24) + draw); a call reaching beyond it is ORT_E_INVALID */
 
 /* error codes */
 #define ORT_OK 0

@@ -1238,6 +1238,8 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     a0.replicas = use_rep ? c->d_replicas : nullptr;
     a0.img_cdf = c->d_img_cdf;
     a0.in_stride = a0.n_rays;
+    if (a0.first_ray > ORT_MAX_RAY_INDEX || a0.n_rays > ORT_MAX_RAY_INDEX - a0.first_ray)
+        return fail(ORT_E_INVALID, "ray indices reach beyond 2^40 (ORT_MAX_RAY_INDEX): the keyed draw counter holds 40 bits of ray index");
     if (a0.n_rays == 0) return ORT_OK;
     const bool queued = (c->variant & 1) && mode != MODE_DEBUG;
     const bool filt = (c->variant & 2) == 0 && c->precision != 1;      // fp32: literal predicates, nothing is deferred
@@ -1349,6 +1351,8 @@ int ort_emit(ort_ctx *c, int phase, uint64_t first_ray, uint64_t n_rays, uint64_
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
     if (phase != 1 && phase != 2) return fail(ORT_E_INVALID, "phase must be 1 (ring) or 2 (point)");
     if (!d_pos_dir && n_rays) return fail(ORT_E_INVALID, "d_pos_dir is NULL");
+    if (first_ray > ORT_MAX_RAY_INDEX || n_rays > ORT_MAX_RAY_INDEX - first_ray)
+        return fail(ORT_E_INVALID, "ray indices reach beyond 2^40 (ORT_MAX_RAY_INDEX): the keyed draw counter holds 40 bits of ray index");
     if (n_rays == 0) return ORT_OK;
     HIP_TRY(hipSetDevice(c->device));
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2][0], c->stream));

@@ -229,6 +229,10 @@ def test_errors_do_not_abort(hip_library):
     with Context(osys) as ctx:
         with pytest.raises(OrtError):
             ctx.trace(3, 0, 10, 1)
+        with pytest.raises(OrtError, match="2\\^40"):          # ORT_MAX_RAY_INDEX
+            ctx.trace(2, (1 << 40) - 5, 10, 1)
+        ctx.trace(2, (1 << 40) - 10, 10, 1)                      # the last ten indices are fine
+        assert int(ctx.read()[1][3]) > 0
 
 
 @pytest.mark.parametrize("name", ["large", "small_iris_after", "small_f60_nobottle", "ellipse"])
