@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU box): parity soak over many random optical systems (tests/random_systems.py).
+Per system: explicit-input rays HIP vs oracle bit for bit (status, bins, intersection and draw
+counts, final state), and the queued filtered kernel's image == the literal lockstep kernel's.
+usage: python tools/parity_soak.py [--systems 300] [--rays 100000] [--first 100]   -> one line per
+system + a summary (kept as profiles/rNN/parity_soak.log)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401,E402
+from opticalraytrace_amd import capi  # noqa: E402
+from opticalraytrace_amd.system import OpticalSystem  # noqa: E402
+from oracle.binding import Oracle  # noqa: E402  (the checker; this is a test tool)
+from parity import SEED, emit_draws  # noqa: E402
+from random_systems import random_system  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--systems", type=int, default=300)
+    ap.add_argument("--first", type=int, default=100)
+    ap.add_argument("--rays", type=int, default=100_000)
+    args = ap.parse_args()
+    bad = 0
+    rays = 0
+    t0 = time.time()
+    print(f"# library build {capi.build_id()}, {args.systems} systems from seed {args.first}, {args.rays} rays per phase")
+    for seed in range(args.first, args.first + args.systems):
+        settings, res = random_system(seed)
+        osys = OpticalSystem.from_settings(settings, res)
+        orc = Oracle(osys)
+        with capi.Context(osys, device=0) as ctx:
+            notes = []
+            n = args.rays + seed % 64
+            for phase in (1, 2):
+                u = np.random.default_rng(seed * 2 + phase).random((9, n))
+                em = orc.trace_rays(phase, n, u=u)["emitted"]
+                base = emit_draws(settings, phase)
+                want = orc.trace_rays(phase, n, pos_dir_in=em, u=u, draw_base=base)
+                got = ctx.trace_rays(phase, n, pos_dir_in=em, u=u, draw_base=base)
+                for key in ("status", "bin_xy", "n_isect", "n_draws", "pos_dir"):
+                    if not np.array_equal(got[key], want[key]):
+                        notes.append(f"phase {phase} {key} differs")
+                rays += n
+            imgs = []
+            for variant in (0, 1):
+                ctx.set_kernel_variant(variant)
+                ctx.reset()
+                ctx.trace(1, 0, 2 * n, SEED)
+                ctx.trace(2, 0, 2 * n, SEED)
+                imgs.append(ctx.read())
+            if not (np.array_equal(imgs[0][0], imgs[1][0]) and np.array_equal(imgs[0][1], imgs[1][1])):
+                notes.append("queued filtered image != lockstep literal image")
+            binned = int(imgs[1][1][4]) + int(imgs[1][1][5])
+        bad += bool(notes)
+        print(f"seed {seed:4d} iris {settings.iris:6s} bottle {int(settings.use_bottle)} binned {binned:7d} "
+              f"{'OK' if not notes else 'MISMATCH: ' + '; '.join(notes)}", flush=True)
+    print(f"# {args.systems} systems, {rays} explicit rays, {bad} systems with a mismatch, {time.time() - t0:.0f} s")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
