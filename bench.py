@@ -334,7 +334,11 @@ def main() -> int:
             "flop_per_ring_emission": FLOP_PER_RING_EMISSION,
             "algorithmic_flop_per_launch": alg_flop,
             "note": "algorithmic flop = an assumed 100 per surface solve (SURVEY §8d; + 61 per emitted ring "
-                    "ray in the ring loop) / mean launch duration (HIP events on the context's stream)",
+                    "ray in the ring loop) / mean launch duration (HIP events on the context's stream)"
+                    + ("; ring loop: the rays whose lens-disc draw already puts them outside the first aperture "
+                       "(69 % for this lens) are counted there — one surface solve, lost — without being emitted "
+                       "(DESIGN §3.8); the algorithmic figure prices them as the reference executes them, so this "
+                       "fraction includes work avoided, not only work done faster" if 1 in phases else ""),
             # executed work, from the committed PMC passes of this very build (null otherwise)
             "valu_busy": prof.get("valu_busy_frac"),
             "valu_lane_utilisation": prof.get("valu_lane_utilisation"),

@@ -276,7 +276,9 @@ int ort_set_precision(ort_ctx *ctx, int precision);
  * segments), clear = plain lockstep kernel; bit 1 set = every predicate evaluated literally
  * (no filtered predicates, see csrc/ort_device.h), clear (default) = filtered; bit 2 set =
  * bin straight into the image, clear (default) = bin into 8 private replicas folded into the
- * image after the launch.  All combinations produce bit-identical rays, images and
+ * image after the launch; bit 3 set = the ring loop emits every ray, clear (default) = ring rays
+ * whose third draw already puts them outside the first aperture are counted without being emitted
+ * (queued surface-program kernels).  All combinations produce bit-identical rays, images and
  * counters.  Default 1. */
 int ort_set_kernel_variant(ort_ctx *ctx, int variant);
 

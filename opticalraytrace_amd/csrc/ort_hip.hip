@@ -83,6 +83,11 @@ struct TraceArgs {
     // to first_ray; ctl[0] = entries, ctl[1] = workgroups of the re-run kernel that are done
     uint32_t *redo_list;
     unsigned int *redo_ctl;
+    // ring programs (trace_queue_kernel, segment 0): a ring ray whose lens-disc sample rr (its third draw x
+    // ring_lens_r2) exceeds `cull` misses the plano-convex aperture for certain and is counted without
+    // being emitted; +inf: nothing is culled (host: ring_cull_threshold)
+    double cull;
+    float cullf;
     uint64_t defer_base;         // queued kernel: list entry of ray i of this launch = defer_base + i (the entries of all
                                  // launches of a group are relative to the group's first ray, see close_group)
     int listed;                  // trace_kernel: iterate redo_list instead of [0, n_rays)
@@ -358,6 +363,12 @@ template <> struct Prog<PROG_POINT_ELLIPSE> {
     static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 0};
 };
 
+template <int P> constexpr bool prog_is_ring()
+{
+    if constexpr (P == PROG_GENERIC) return false;
+    else return Prog<P>::phase == 1;
+}
+
 // draws a ray has consumed before step K of program P: the emitter's (point 2, ring 4:
 // src/sourceMod.f90:31-37, :266-286) plus one per refracting surface passed (an iris and the image
 // plane draw nothing)
@@ -602,6 +613,10 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     using QD = typename std::conditional<fixed, uint32_t, uint64_t>::type;   // program: the ray's index in the launch
     __shared__ QT Q[kWavesPerBlock][kQueueFields][kQueueCap];
     __shared__ QD QDRAW[kWavesPerBlock][kQueueCap];
+    // ring programs, fused: segment 0 (below) culls the rays that are certain to miss the first aperture
+    // before anything is emitted; the others wait here (ray index in the launch) for a full wave
+    constexpr bool PRE = prog_is_ring<PROG>() && MODE == MODE_FUSED;
+    __shared__ uint32_t CQ[kWavesPerBlock][PRE ? kQueueCap : 1];
     // intersections evaluated before the queue point: `split` for every survivor unless a surface
     // scatters (extended instantiation), so only that one carries the count through the queue
     __shared__ int QN[kWavesPerBlock][SCAT ? kQueueCap : 1];
@@ -620,6 +635,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     const int wave = threadIdx.x >> 6;
     QT (*q)[kQueueCap] = Q[wave];
     QD *qd = QDRAW[wave];
+    uint32_t *cq = CQ[wave];
     int *qn = QN[wave];
     using DrawsT = typename std::conditional<fixed, ProgDraws, KeyedDraws>::type;
     int phase = a.phase, ns, split;
@@ -678,9 +694,11 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
 
     uint64_t next = lo;
     int qcount = 0, qhead = 0;
+    int ccount = 0, chead = 0;
     for (;;) {
         const bool have_new = next < hi;
-        if (qcount >= 64 || (!have_new && qcount > 0)) {
+        const bool cand_ready = PRE && (ccount >= 64 || (!have_new && ccount > 0));
+        if (qcount >= 64 || (!have_new && !cand_ready && qcount > 0)) {
             // ---- segment 2 on up to 64 queued rays
             const int m = qcount < 64 ? qcount : 64;
             const bool act = lane < m;
@@ -707,12 +725,22 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 else finish(st, nis, xp, yp);
             }
             __builtin_amdgcn_wave_barrier();
-        } else if (have_new) {
-            // ---- segment 1 on 64 fresh rays
-            const uint64_t i = next + (uint64_t)lane;
-            const bool act = i < hi;
-            next += 64;
-            const uint64_t ic = act ? i : hi - 1;        // clamped: idle lanes recompute the last ray, unused
+        } else if (cand_ready || (!PRE && have_new)) {
+            // ---- segment 1 on 64 fresh rays (ring programs: on up to 64 rays that passed segment 0)
+            uint64_t i;
+            bool act;
+            if constexpr (PRE) {
+                const int m = ccount < 64 ? ccount : 64;
+                act = lane < m;
+                i = act ? (uint64_t)cq[(chead + lane) & (kQueueCap - 1)] : lo;
+                chead = (chead + m) & (kQueueCap - 1);
+                ccount -= m;
+            } else {
+                i = next + (uint64_t)lane;
+                act = i < hi;
+                next += 64;
+            }
+            const uint64_t ic = act ? i : (PRE ? lo : hi - 1);   // idle lanes recompute a ray of this wave, unused
             RayT<T> r;
             DrawsT d;
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
@@ -746,6 +774,35 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 finish(st, nis, xp, yp);
             }
             qcount += __popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+        } else if (PRE && have_new) {
+            // ---- segment 0 (ring programs) on 64 fresh ray indices.  `ring` aims every ray at a point of
+            // the plane z = L2%fb with squared radius rr = ranu(0., (radius + 10e-3)**2), its third draw
+            // (src/sourceMod.f90:283-286), and that plane IS the plano-convex lens's flat face
+            // (centre%z + curve_radius - thickness = fb, src/lens.f90:163, :448): the ray crosses the
+            // face at its aim point up to rounding (host: ring_cull_threshold bounds it by 1e-8 of rr),
+            // so rr > radius^2 (1 + 1e-6) means r > this%radius at lens.f90:451 whatever the other
+            // three draws are: the ray ends there after ONE surface solve.  69 % of the ring rays; they
+            // are counted (lost, one intersection) and never emitted.  Results are unchanged
+            // (tests: with culling == without it, bit for bit, on every system of the parity suite).
+            const uint64_t i = next + (uint64_t)lane;
+            const bool act = i < hi;
+            next += 64;
+            const uint64_t ic = act ? i : hi - 1;
+            if constexpr (PRE) {
+                ProgDraws d;
+                d.init_keyed(a.rng_base, a.first_ray + ic, 0);
+                const T u3 = d.template at<T, 2, true>();
+                const T rr = T(0.) + u3 * (T(csys->ring_lens_r2) - T(0.));       // as emit_ring forms it
+                bool dies;
+                if constexpr (std::is_same<T, float>::value) dies = rr > a.cullf;
+                else dies = rr > T(a.cull);
+                const bool cand = act && !dies;
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
+                if (cand) cq[(chead + ccount + lane_prefix(mask)) & (kQueueCap - 1)] = (uint32_t)i;
+                else if (act) finish(ORT_ST_LOST_TELESCOPE, 1, 0, 0);
+                ccount += __popcll(mask);
+            }
             __builtin_amdgcn_wave_barrier();
         } else {
             break;
@@ -902,6 +959,8 @@ struct ort_ctx {
     int emitter[2];              // host copy of ort_system.emitter
     bool scatter[2];             // per phase: some surface of its list carries ORT_F_SCATTER
     int prog[2];                 // per phase: PROG_* the staged system matches (match_program)
+    double ring_cull;            // TraceArgs.cull of the staged system (ring_cull_threshold), +inf: no culling
+    float ring_cullf;
     hipEvent_t ev[3][2];
     hipEvent_t ring[kTimingRing][2];   // fused-trace launches, most recent kTimingRing
     unsigned long long ring_count;
@@ -925,6 +984,30 @@ static bool matches(const ort_system *sys)
     return true;
 }
 
+// TraceArgs.cull for the ring programs' segment 0: radius^2 (1 + margin) of the plano-convex aperture if
+// the geometry the argument needs holds for this system, else +inf.  With the aim point T on the plane
+// z = zt (ring_lens_z), the start point P (|P.xy| <= sqrt(r2), P.z in [zmin, zmax] on the bottle) and
+// the flat face at zp, the ray crosses the face at P + (T - P) s, s = (zp - P.z) / (zt - P.z):
+// |s - 1| <= |zp - zt| / (zt - zmax).  Required: zp within 1e-12 |zt| of zt and zt - zmax >= 1e-3 |zt|
+// (so |s - 1| <= 1e-9), the start points inside the aperture (|P.xy| < radius), a real bottle point
+// under every start point.  The crossing point's squared radius then differs from rr by less than
+// 3e-9 rr + rounding (1e-14 in fp64, 1e-5 in fp32, which also moves zp by an ulp): margins 1e-6 / 1e-3.
+static void ring_cull_threshold(const ort_system *sys, bool is_ring_program, double *cull, float *cullf)
+{
+    *cull = HUGE_VAL; *cullf = HUGE_VALF;
+    if (!is_ring_program || getenv("ORT_NO_RING_CULL")) return;
+    const ort_surface &s0 = sys->surfaces[0][0];
+    if (s0.kind != ORT_SURF_PLANE || !(s0.aperture > 0.0)) return;
+    const double zt = sys->ring_lens_z, zp = s0.cz, ra = sys->ring_bottle_ra, rb = sys->ring_bottle_rb;
+    const double rmax = sqrt(sys->ring_r1 > sys->ring_r2 ? sys->ring_r1 : sys->ring_r2);     // |P.xy| <= rmax
+    const double q = sys->ring_ellipse ? rmax * ra / rb : rmax;
+    if (!(fabs(zp - zt) <= 1e-12 * fabs(zt)) || !(ra > 0.0) || !(ra * ra > q * q * 1.000001)) return;
+    const double zmax = sys->ring_bottle_z + ra;
+    if (!(zt - zmax >= 1e-3 * fabs(zt)) || !(rmax < s0.aperture) || !(sys->ring_lens_r2 > 0.0)) return;
+    *cull = s0.aperture * s0.aperture * (1.0 + 1e-6);
+    *cullf = (float)(s0.aperture * s0.aperture * (1.0 + 1e-3));
+}
+
 static void note_system(ort_ctx *c, const ort_system *sys)
 {
     c->emitter[0] = sys->emitter[0]; c->emitter[1] = sys->emitter[1];
@@ -938,6 +1021,7 @@ static void note_system(ort_ctx *c, const ort_system *sys)
     ORT_PROGRAMS(ORT_MATCH)
 #undef ORT_MATCH
     if (getenv("ORT_NO_PROGRAMS")) c->prog[0] = c->prog[1] = PROG_GENERIC;      // development knob (A/B)
+    ring_cull_threshold(sys, c->prog[0] != PROG_GENERIC, &c->ring_cull, &c->ring_cullf);
 }
 
 // system + derived per-surface constants -> device (synchronises: the staging copy is a local)
@@ -1238,6 +1322,9 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     a0.replicas = use_rep ? c->d_replicas : nullptr;
     a0.img_cdf = c->d_img_cdf;
     a0.in_stride = a0.n_rays;
+    const bool culling = (c->variant & 8) == 0;                 // bit 3: A/B knob, ring rays are all emitted
+    a0.cull = culling ? c->ring_cull : HUGE_VAL;
+    a0.cullf = culling ? c->ring_cullf : HUGE_VALF;
     if (a0.first_ray > ORT_MAX_RAY_INDEX || a0.n_rays > ORT_MAX_RAY_INDEX - a0.first_ray)
         return fail(ORT_E_INVALID, "ray indices reach beyond 2^40 (ORT_MAX_RAY_INDEX): the keyed draw counter holds 40 bits of ray index");
     if (a0.n_rays == 0) return ORT_OK;
@@ -1595,7 +1682,7 @@ int ort_synchronize(ort_ctx *c)
 int ort_set_kernel_variant(ort_ctx *c, int variant)
 {
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
-    if (variant < 0 || variant > 7) return fail(ORT_E_INVALID, "variant must be in 0..7");
+    if (variant < 0 || variant > 15) return fail(ORT_E_INVALID, "variant must be in 0..15");
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = close_group(c); if (rc) return rc; }
     c->variant = variant;

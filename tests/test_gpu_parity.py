@@ -242,7 +242,7 @@ def test_queued_kernel_equals_lockstep_kernel(ctxs, name):
     osys, ctx = ctxs(name)
     for n in (1, 63, 64, 65, 4097, 250_003):
         out = []
-        for variant in (0, 1, 2, 3, 5, 6):   # lockstep/queued x filtered/literal x replicas/direct
+        for variant in (0, 1, 2, 3, 5, 6, 9, 11):   # lockstep/queued x filtered/literal x replicas/direct x ring cull on/off
             ctx.set_kernel_variant(variant)
             ctx.reset()
             ctx.trace(1, 5, n, SEED)
