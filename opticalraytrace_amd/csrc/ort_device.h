@@ -1286,16 +1286,42 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
 // st/xp/yp/nis of such lanes); KEEP = true freezes r where the ray ended (debug / tracker output).
 // DK >= 0 (surface programs): this step's draw index is the compile-time constant DK for every live
 // lane (ProgDraws::at); DK < 0: the draw source counts per lane.
+// PART (surface programs, the step at the queue point of trace_queue_kernel): 0 = the whole step;
+// 1 = up to the point where the reference knows whether the ray goes on at this surface (moved to
+// the surface, hit, inside the aperture): a lane that ends takes its status, the others keep st < 0
+// with pos on the surface; 2 = the rest for those lanes (normal, Fresnel draw, new direction).  The
+// rays that miss the aperture stop — a third of the point rays at the doublet's first face — then
+// leave the wavefront BEFORE the normalisation and the Fresnel arithmetic, not after.  1 then 2 is
+// the whole step, operation for operation.
 template <bool FILT, class T, bool EXT, bool KEEP = true, int KIND = -1, int FLAGS = -1, int HASAP = -1, int DK = -1, bool FRESH = false,
-          class Sys, class Surf, class D>
+          int PART = 0, class Sys, class Surf, class D>
 __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<T> &ax, RayT<T> &r, D &draws,
                                     int &nis, int &st, int &xp, int &yp, bool &rare)
 {
+    static_assert(PART == 0 || (!EXT && !KEEP && KIND >= 0 && KIND != ORT_SURF_IMAGE && KIND != ORT_SURF_IRIS),
+                  "half steps exist for the refracting steps of the surface programs");
     const bool live = st < 0;
     const int kind = KIND >= 0 ? KIND : __builtin_amdgcn_readfirstlane(s.kind);
     const unsigned flags = FLAGS >= 0 ? (unsigned)FLAGS : (unsigned)__builtin_amdgcn_readfirstlane((int)s.flags);
     const bool has_ap = HASAP >= 0 ? (HASAP != 0) : aperture_present<T>(s.aperture);   // aperture >= 0
     const int lost = (flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE;
+    if constexpr (PART == 2) {
+        // second half: every lane with st < 0 is on the surface (pos = the crossing point) and goes on
+        VecT<T> N2;
+        const bool cyl = kind != ORT_SURF_SPHERE;
+        if (kind == ORT_SURF_SPHERE || kind == ORT_SURF_CYLINDER || kind == ORT_SURF_ELLIPSE) {
+            const VecT<T> Nraw = {cyl ? T(0.0) : s.cx - r.pos.x, s.cy - r.pos.y, s.cz - r.pos.z};
+            if (kind == ORT_SURF_ELLIPSE) N2 = vnormalise_f<FILT, T>(Nraw, live, rare, cyl);
+            else N2 = vnormalise_est<FILT, T>(Nraw, T(s.radius), ax.rh, ax.rk, ax.r2_tol, live, rare, cyl);
+        } else {
+            N2 = {T(0.), T(0.), T(-1.)};
+        }
+        const T u2 = draws.template at<T, DK, FRESH>();
+        const bool reflected2 = reflect_refract<FILT, KEEP, T>(r.dir, N2, s.n1, s.n2, s.eta, ax.eta2, u2, live, rare);
+        const bool dies2 = reflected2 && (flags & ORT_F_SKIP_ON_REFLECT);
+        st = (live & dies2) ? lost : st;
+        return;
+    }
     nis += live ? 1 : 0;
     VecT<T> N;
     bool proceed;                    // lanes that reach the Fresnel decision at this surface
@@ -1316,9 +1342,11 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         bool out = false;
         if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, ax.ap2, ax.ap_tol, live && hit, rare);
         // normal = centre - pos, with orig%x = centre%x for the bottle (lens.f90:288-290)
-        const VecT<T> Nraw = {cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z};
-        if (kind == ORT_SURF_ELLIPSE) N = vnormalise_f<FILT, T>(Nraw, live && hit, rare, cyl);
-        else N = vnormalise_est<FILT, T>(Nraw, T(s.radius), ax.rh, ax.rk, ax.r2_tol, live && hit, rare, cyl);   // |N| = radius
+        if constexpr (PART != 1) {
+            const VecT<T> Nraw = {cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z};
+            if (kind == ORT_SURF_ELLIPSE) N = vnormalise_f<FILT, T>(Nraw, live && hit, rare, cyl);
+            else N = vnormalise_est<FILT, T>(Nraw, T(s.radius), ax.rh, ax.rk, ax.r2_tol, live && hit, rare, cyl);   // |N| = radius
+        }
         // a lane that ends here: missed (Help3 where the reference aborts), outside the aperture,
         // reflected (all: `lost`), or ended inside the scattering walk
         if (flags & ORT_F_MISS_IS_HELP3) code = hit ? lost : ORT_ST_HELP3;
@@ -1344,6 +1372,10 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         r.pos = KEEP ? vselect(live, moved, r.pos) : moved;
         N = {T(0.), T(0.), T(-1.)};                         // flatNormal, lens.f90:165
         proceed = live && !out;
+    }
+    if constexpr (PART == 1) {
+        st = live ? (proceed ? -1 : code) : st;
+        return;
     }
     T u;
     if constexpr (DK >= 0) {

@@ -3,27 +3,29 @@
 // Kernels (device functions: ort_device.h; the arithmetic type T is double = the reference's
 // arithmetic, bit-exact; float = fp32 study path; fastd = opt-in fast fp64, ort_fastd.h)
 //   trace_queue_kernel<MODE, FILT, EXT, T, PROG>   the production kernel.  One wavefront = one ray
-//       bundle over a contiguous range of global ray indices; the 2.7 KB ort_system (surface
-//       lists + emitter + image constants) is staged into LDS once per workgroup; a ray lives
-//       in VGPRs from emission to binning; survivors of the first surface segment are
-//       compacted through a wave-private LDS queue so that the second segment runs on full
-//       wavefronts; hits are binned with global int32 atomics into one of 8 image replicas
-//       (fold_kernel adds them into the image afterwards); counters are reduced per workgroup.
+//       bundle over contiguous ranges of global ray indices (plan_ranges); a ray lives in VGPRs
+//       from emission to binning; survivors of the first surface segment are compacted through a
+//       wave-private LDS queue so that the second segment runs on full wavefronts; hits are
+//       binned with global int32 atomics into one of 8 image replicas (fold_kernel adds them
+//       into the image when it is next needed); counters are reduced per workgroup.
 //         MODE_FUSED     emit in-kernel (src/main.f90:90-109 / :127-162 whole loop body)
 //         MODE_RESIDENT  ray bundle read from HBM, SoA fp64 [6][n], coalesced
 //         FILT           filtered predicates (decisions from bounded approximations); a ray that
 //                        lands inside a margin is not decided here: its index goes to the
 //                        re-run list and it leaves the kernel without side effect
-//         EXT (ANYSRC)   also compiles the rarely used emitters (spot, crs, image); SCAT the
+//         EXT (ANYSRC)   also compiles the rarely used emitters (spot, crs, image, isors); SCAT the
 //                        in-bottle scattering walk (213+ VGPRs); the default instantiation
 //                        leaves both out, and a phase is given only what its own list needs
 //         PROG           the surface list as template constants (Prog<P>: the default point /
-//                        ring systems and their iris variants), steps unrolled, surface records
-//                        through scalar loads; PROG_GENERIC walks any staged list
+//                        ring systems, their iris variants, no bottle, elliptical bottle), steps
+//                        unrolled, the system read through scalar loads from its device copy;
+//                        the ring programs put a segment 0 in front (rays that are certain to
+//                        miss the first aperture are counted, not emitted).  PROG_GENERIC stages
+//                        the 3 KB ort_system into LDS once per workgroup and walks any list
 //   trace_kernel<MODE, FILT, T, EXT>         plain lockstep thread-per-ray walk: the literal
-//       re-run of the listed rays right after the queued kernel (normally an empty list), the
-//       parity / debug entry (MODE_DEBUG: per-ray outputs, tracker paths, no side effect), the
-//       fp32 path and the A/B baseline of the queued kernel
+//       re-run of the listed rays when a group of queued launches closes (normally an empty
+//       list), the parity / debug entry (MODE_DEBUG: per-ray outputs, tracker paths, no side
+//       effect) and the A/B baseline of the queued kernel
 //   fold_kernel, emit_kernel
 //
 // No MFMA: there is no contraction anywhere on this path; the kernel is bound by
@@ -58,8 +60,7 @@ constexpr uint32_t kSlotMul = 0x379B1u, kSlotMulInv = 0x32F51u;
 static_assert(((kSlotMul * kSlotMulInv) & (kSlots - 1)) == 1u, "kSlotMulInv must invert kSlotMul modulo 2^18");
 static_assert(ORT_IMAGE_N * ORT_IMAGE_N <= (int)kSlots, "a layer must fit the slot table");
 constexpr size_t kReplicaInts = 2 * (size_t)kSlots;   // both layers of one replica
-constexpr int kMaxBlocks = 256 * 12;    // 256 CUs x 12 workgroups = 3 rounds at 4 resident per CU: the static ranges'
-                                        // cost spread (~10 %) then idles the chip for 1/3 less than with 2 rounds
+constexpr int kMaxBlocks = 256 * 12;    // grid cap of the lockstep kernels and of small queued launches (equal ranges)
 constexpr uint64_t kChunkRays = ORT_MAX_RAYS_PER_LAUNCH;   // rays per launch of the queued kernel (bounds the re-run list: 4 B per ray)
 constexpr int kRedoBlocks = 128;        // grid of the literal re-run kernel (it normally finds an empty list and returns)
 
@@ -404,6 +405,26 @@ __device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t su
     }
 }
 
+// one half (PART 1 / 2, ort_device.h: surface_step) of step K of program P: the step the queue point
+// of trace_queue_kernel sits in
+template <bool FILT, class T, int P, int K, int PART, class Sys, class D>
+__device__ inline void step_part(const Sys &S, typename ConstPtrs<T>::surf_t surf, typename ConstPtrs<T>::aux_t aux, RayT<T> &r, D &draws,
+                                 int &nis, int &st, int &xp, int &yp, bool &rare)
+{
+    if (wave_any(st < 0)) {
+        const typename ConstPtrs<T>::Surf s = load_surface<T>(surf + K);
+        const SurfAuxT<T> ax = load_aux<T>(aux + K);
+#ifdef ORT_ISA_MARKERS
+        if (PART == 1) asm volatile("; ORT_STEP_BEGIN %0" ::"n"(K));
+#endif
+        surface_step<FILT, T, false, false, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), PART == 2, PART>(
+            S, s, ax, r, draws, nis, st, xp, yp, rare);
+#ifdef ORT_ISA_MARKERS
+        if (PART == 2) asm volatile("; ORT_STEP_END %0" ::"n"(K));
+#endif
+    }
+}
+
 // The segment [k0, k1) with the reference's outcome for every lane.  FILT: one pass with the
 // filtered predicates; if any lane raised `rare` (ort_device.h) the wave runs the segment again
 // from its initial state — `restore(r, draws, st)` re-creates it: reloaded or re-emitted, so no
@@ -718,8 +739,11 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             if constexpr (fixed) d.init_keyed(a.rng_base, a.first_ray + dw, 0);
             else d.unpack(dw, a.rng_base);
             bool rare = false;
-            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n, true>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-            else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
+            if constexpr (fixed) {
+                // the queue point lies INSIDE step split - 1, behind its aperture test (step_part)
+                step_part<FILT, T, PROG, Prog<PROG>::split - 1, 2>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n, false>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+            } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
                 if (FILT && rare) defer(fixed ? (uint64_t)dw : d.ray_of_packed(dw, a.rng_base) - a.first_ray);
                 else finish(st, nis, xp, yp);
@@ -756,8 +780,10 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 else est = emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
                 st = est < 0 ? st : est;
             }
-            if constexpr (fixed) walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split, false>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-            else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
+            if constexpr (fixed) {
+                walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split - 1, false>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                step_part<FILT, T, PROG, Prog<PROG>::split - 1, 1>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+            } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
             const bool deferred = FILT && rare && act;
             const bool survive = act && st < 0 && !deferred;
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(survive);
