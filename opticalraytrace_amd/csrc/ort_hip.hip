@@ -395,8 +395,19 @@ __device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t su
             asm volatile("; ORT_STEP_BEGIN %0" ::"n"(K));
 #endif
             constexpr bool draws_here = Prog<P>::kind[K] != ORT_SURF_IRIS && Prog<P>::kind[K] != ORT_SURF_IMAGE;
-            surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH>(
-                S, s, ax, r, draws, nis, st, xp, yp, rare);
+            if constexpr (draws_here && Prog<P>::ap[K] != 0 && !KEEP) {
+                // a refracting step with an aperture stop, in halves (surface_step PART): when the stop
+                // ends every ray of the wavefront — the doublet's first face does that to 9 of 10
+                // wavefronts of the ring loop — the normalisation and the Fresnel arithmetic are skipped
+                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 1>(
+                    S, s, ax, r, draws, nis, st, xp, yp, rare);
+                if (wave_any(st < 0))
+                    surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 2>(
+                        S, s, ax, r, draws, nis, st, xp, yp, rare);
+            } else {
+                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH>(
+                    S, s, ax, r, draws, nis, st, xp, yp, rare);
+            }
 #ifdef ORT_ISA_MARKERS
             asm volatile("; ORT_STEP_END %0" ::"n"(K));
 #endif

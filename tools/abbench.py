@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Dev tool (GPU box): A/B several builds of libort_hip.so in ONE process, interleaved, at steady
-clocks.  Each measurement = mean kernel time of 64 back-to-back 1e7-ray launches (HIP events).
+"""Dev tool (GPU box): A/B several builds of libort_hip.so in ONE process, interleaved (order rotated
+per round, one discarded measurement in front of every group), at steady clocks.  Each measurement = mean kernel time of 64 back-to-back 1e7-ray launches (HIP events).
 usage: python tools/abbench.py --libs build/a.so,build/b.so [--phases 2,1] [--precisions 0,2] [--rounds 5]"""
 import argparse
 import ctypes as C
@@ -45,17 +45,27 @@ def main():
         c.reserve(args.rays)
         ctxs.append((os.path.basename(p), c))
     res = {}
+
+    def measure(c, phase, prec):
+        c.set_precision(prec)
+        c.reset()
+        for k in range(64):
+            c.trace(phase, k * args.rays, args.rays, 123456789)
+        ms = c.kernel_times(64)
+        return sum(ms) / len(ms)
+
+    # The first measurement behind a change of kernel (phase / precision) reads 2-4 % high whichever
+    # library it is (identical copies of one library, first in the list: 0.3352 vs 0.3284 / 0.3280 ms):
+    # every group starts with a discarded measurement, and the order rotates from round to round.
     for rnd in range(args.rounds + 1):
+        order = ctxs[rnd % len(ctxs):] + ctxs[:rnd % len(ctxs)]
         for phase in [int(p) for p in args.phases.split(",")]:
             for prec in [int(p) for p in args.precisions.split(",")]:
-                for name, c in ctxs:
-                    c.set_precision(prec)
-                    c.reset()
-                    for k in range(64):
-                        c.trace(phase, k * args.rays, args.rays, 123456789)
-                    ms = c.kernel_times(64)
+                measure(order[-1][1], phase, prec)
+                for name, c in order:
+                    ms = measure(c, phase, prec)
                     if rnd:
-                        res.setdefault((phase, prec, name), []).append(sum(ms) / len(ms))
+                        res.setdefault((phase, prec, name), []).append(ms)
     for (phase, prec, name), v in sorted(res.items()):
         v = np.array(v)
         print(f"phase {phase} precision {prec} {name:28s}: mean {v.mean():.4f} ms  min {v.min():.4f}  max {v.max():.4f}")
