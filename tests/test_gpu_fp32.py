@@ -97,15 +97,24 @@ def test_fp32_queued_kernel_equals_fp32_lockstep_kernel(hip_library, name):
     with Context(osys) as c:
         c.set_precision(1)
         out = []
-        for variant in (1, 0):
+        for variant in (1, 0, 9):            # queued; lockstep; queued without the ring cull
             c.set_kernel_variant(variant)
             c.reset()
             c.trace(1, 0, n, SEED)
             c.trace(2, 5, n, SEED)
             out.append(c.read())
-    (iq, cq), (il, cl) = out
+        for m in (1, 63, 64, 65, 129, 4097):              # ragged sizes: partial batches, queue flush at the tail
+            res = []
+            for variant in (1, 0):
+                c.set_kernel_variant(variant)
+                c.reset(); c.trace(1, 3, m, SEED); c.trace(2, 7, m, SEED)
+                res.append(c.read())
+            assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), (name, m)
+        c.set_kernel_variant(1)
+    (iq, cq), (il, cl) = out[0], out[1]
     assert int(cq[2]) > n and int(cq[3]) > n
     assert np.array_equal(iq, il) and np.array_equal(cq, cl)
+    assert np.array_equal(iq, out[2][0]) and np.array_equal(cq, out[2][1])
 
 
 def test_config4_fp32_full_size(ctx):
