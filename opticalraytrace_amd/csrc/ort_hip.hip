@@ -369,6 +369,19 @@ template <int P> constexpr bool prog_is_ring()
     if constexpr (P == PROG_GENERIC) return false;
     else return Prog<P>::phase == 1;
 }
+// the step the queue point of trace_queue_kernel lies in, + 1.  Prog<P>::split (the host's choice for
+// the list: behind the stop that removes most rays) — except in the fused ring programs: their
+// segment 0 has already removed the rays the first stop would, every ray that reaches segment 1
+// passes it, and the next stop (the doublet's first face, step 2) ends nearly all of them
+template <int P, int MODE> constexpr int queue_step()
+{
+    if constexpr (P == PROG_GENERIC) return 0;
+    else if constexpr (prog_is_ring<P>() && MODE == MODE_FUSED) {
+        for (int k = 1; k < Prog<P>::n; ++k)
+            if (Prog<P>::ap[k] != 0 && Prog<P>::kind[k] != ORT_SURF_IRIS && Prog<P>::kind[k] != ORT_SURF_IMAGE) return k + 1;
+        return Prog<P>::split;
+    } else return Prog<P>::split;
+}
 
 // draws a ray has consumed before step K of program P: the emitter's (point 2, ring 4:
 // src/sourceMod.f90:31-37, :266-286) plus one per refracting surface passed (an iris and the image
@@ -672,7 +685,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     using DrawsT = typename std::conditional<fixed, ProgDraws, KeyedDraws>::type;
     int phase = a.phase, ns, split;
     if constexpr (fixed) {
-        phase = Prog<PROG>::phase; ns = Prog<PROG>::n; split = Prog<PROG>::split;   // host: match_program
+        phase = Prog<PROG>::phase; ns = Prog<PROG>::n; split = queue_step<PROG, MODE>();   // host: match_program
     } else {
         ns = S.n_surfaces[phase - 1];
         split = S.split[phase - 1];
@@ -752,8 +765,8 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             bool rare = false;
             if constexpr (fixed) {
                 // the queue point lies INSIDE step split - 1, behind its aperture test (step_part)
-                step_part<FILT, T, PROG, Prog<PROG>::split - 1, 2>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-                walk_fixed<FILT, T, false, PROG, Prog<PROG>::split, Prog<PROG>::n, false>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 2>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                walk_fixed<FILT, T, false, PROG, queue_step<PROG, MODE>(), Prog<PROG>::n, false>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
             } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
                 if (FILT && rare) defer(fixed ? (uint64_t)dw : d.ray_of_packed(dw, a.rng_base) - a.first_ray);
@@ -792,8 +805,8 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 st = est < 0 ? st : est;
             }
             if constexpr (fixed) {
-                walk_fixed<FILT, T, false, PROG, 0, Prog<PROG>::split - 1, false>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-                step_part<FILT, T, PROG, Prog<PROG>::split - 1, 1>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                walk_fixed<FILT, T, false, PROG, 0, queue_step<PROG, MODE>() - 1, false>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 1>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
             } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
             const bool deferred = FILT && rare && act;
             const bool survive = act && st < 0 && !deferred;
