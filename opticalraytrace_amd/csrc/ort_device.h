@@ -161,6 +161,15 @@ struct ProgDraws {
         h = 0;
         k = first_draw;
     }
+    // ray `idx` of a launch whose first ray has zray z0 (= zray_of(base, first_ray), wave-uniform):
+    // zray_of(base, first_ray + idx) = z0 + (GOLDEN << 23) idx modulo 2^64 — a 64 x 32-bit product
+    // per lane instead of a 64-bit add, a shift and a 64 x 64-bit product
+    __device__ inline void init_index(uint64_t z0, uint32_t idx, int first_draw)
+    {
+        zray = z0 + (kGolden << 23) * (uint64_t)idx;
+        h = 0;
+        k = first_draw;
+    }
     template <class T, int K, bool FRESH> __device__ inline T at()
     {
 #ifdef ORT_ABL_NORNG

@@ -740,6 +740,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     uint64_t next = lo;
     int qcount = 0, qhead = 0;
     int ccount = 0, chead = 0;
+    const uint64_t z0 = zray_of(a.rng_base, a.first_ray);      // ProgDraws::init_index (a launch holds < 2^32 rays)
     for (;;) {
         const bool have_new = next < hi;
         const bool cand_ready = PRE && (ccount >= 64 || (!have_new && ccount > 0));
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 dw = qd[slot];
                 nis = SCAT ? qn[slot] : split;
             }
-            if constexpr (fixed) d.init_keyed(a.rng_base, a.first_ray + dw, 0);
+            if constexpr (fixed) d.init_index(z0, dw, 0);
             else d.unpack(dw, a.rng_base);
             bool rare = false;
             if constexpr (fixed) {
@@ -794,11 +795,13 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
             bool rare = false;
             if (MODE == MODE_RESIDENT) {
-                d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
+                if constexpr (fixed) d.init_index(z0, (uint32_t)ic, a.draw_base);
+                else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
                 r.pos = {T(a.pos_dir_in[0 * ns_in + ic]), T(a.pos_dir_in[1 * ns_in + ic]), T(a.pos_dir_in[2 * ns_in + ic])};
                 r.dir = {T(a.pos_dir_in[3 * ns_in + ic]), T(a.pos_dir_in[4 * ns_in + ic]), T(a.pos_dir_in[5 * ns_in + ic])};
             } else {
-                d.init_keyed(a.rng_base, a.first_ray + ic, 0);
+                if constexpr (fixed) d.init_index(z0, (uint32_t)ic, 0);
+                else d.init_keyed(a.rng_base, a.first_ray + ic, 0);
                 int est;
                 if constexpr (fixed) est = emit<T, ANYSRC, FILT && !ANYSRC>(*csys, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
                 else est = emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
@@ -841,7 +844,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             const uint64_t ic = act ? i : hi - 1;
             if constexpr (PRE) {
                 ProgDraws d;
-                d.init_keyed(a.rng_base, a.first_ray + ic, 0);
+                d.init_index(z0, (uint32_t)ic, 0);
                 const T u3 = d.template at<T, 2, true>();
                 const T rr = T(0.) + u3 * (T(csys->ring_lens_r2) - T(0.));       // as emit_ring forms it
                 bool dies;
