@@ -677,7 +677,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: the wave's range and loop control stay scalar
     QT (*q)[kQueueCap] = Q[wave];
     QD *qd = QDRAW[wave];
     uint32_t *cq = CQ[wave];
