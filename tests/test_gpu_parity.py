@@ -164,6 +164,33 @@ def test_image_vs_oracle(ctxs, name):
     assert abs(int(cnt[0]) - int(g["img1_lost"])) <= 4 and abs(int(cnt[1]) - int(g["img2_lost"])) <= 4
 
 
+def test_bulk_kernels_far_into_the_ray_index_range(ctxs):
+    """Ray indices beyond 2^32 (a late shard of a very long run): the program kernels form a ray's
+    RNG key from a wave-uniform base + its 32-bit index in the launch; the lockstep kernel and the
+    oracle form it from the 64-bit index.  Same image (exactly between the kernels, up to the
+    emission budget against the oracle)."""
+    osys, ctx = ctxs("large")
+    orc = _oracle(osys)
+    n = 200_000
+    first = (1 << 35) + 12345
+    out = []
+    for variant in (1, 0):
+        ctx.set_kernel_variant(variant)
+        ctx.reset()
+        ctx.trace(1, first, n, SEED)
+        ctx.trace(2, first, n, SEED)
+        out.append(ctx.read())
+    ctx.set_kernel_variant(1)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    want = np.zeros((2, 401, 401), np.int32)
+    wc = np.zeros(8, np.uint64)
+    for phase in (1, 2):
+        orc.trace(phase, first, n, SEED, want, wc)
+    assert np.abs(out[0][0].astype(np.int64) - want).sum() <= 2 * _image_budget(2 * n)
+    assert np.abs(out[0][1].astype(np.int64) - wc.astype(np.int64)).max() <= _image_budget(2 * n)
+    assert int(out[0][1][5]) > 50_000
+
+
 def test_partition_invariance_and_resident_path(ctxs):
     """(a) any split of the ray range gives the same image bit for bit (integer adds commute),
     (b) emit -> HBM bundle -> resident trace == fused trace bit for bit."""
