@@ -14,7 +14,8 @@ number of rays and prints one JSON object.
 
 Only the loop is timed (no parsing, no file output), as for the GPU.  Each timing runs in a
 fresh process with OMP_NUM_THREADS = the physical cores, then every hardware thread; the best is
-reported with both counts stated (`cores`, `threads`).
+reported with both counts stated (`cores`, `threads`); every figure is the median of `--repeats` (3)
+timings of the loop.
 """
 import argparse
 import json
@@ -43,19 +44,20 @@ def physical_cores(cpus):
     return len(cores) or len(cpus)
 
 
-def run_once(kind: str, rays: int, phase: int, threads: int):
-    """One timing in a fresh process (the OpenMP team size is fixed at first use)."""
+def run_once(kind: str, rays: int, phase: int, threads: int, repeats: int):
+    """The timings of one thread count in a fresh process (the OpenMP team size is fixed at first use)."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", kind, "--rays", str(rays),
-                          "--phase", str(phase)], env=env, capture_output=True, text=True, timeout=600)
+                          "--phase", str(phase), "--repeats", str(repeats)], env=env, capture_output=True, text=True,
+                         timeout=900)
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     if out.returncode != 0 or not line:
         raise RuntimeError(f"{kind} worker failed: {out.stderr[-400:]}")
     return json.loads(line[-1])
 
 
-def worker(kind: str, rays: int, phase: int):
+def worker(kind: str, rays: int, phase: int, repeats: int):
     import numpy as np  # noqa: F401
     from opticalraytrace_amd.params import Settings, resource_dir
     from opticalraytrace_amd.system import OpticalSystem
@@ -70,16 +72,21 @@ def worker(kind: str, rays: int, phase: int):
     if kind == "reference":
         ref = Reference(s, resource_dir())
         ref.trace(phase, 0, warm, seed)
-        t0 = time.perf_counter()
-        ref.trace(phase, 0, rays, seed)
-        dt = time.perf_counter() - t0
+        times = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            ref.trace(phase, 0, rays, seed)
+            times.append(time.perf_counter() - t0)
         _, c = orc.trace(phase, 0, rays, seed)              # untimed: the oracle counts the intersections
     else:
         orc.trace(phase, 0, warm, seed)
-        t0 = time.perf_counter()
-        _, c = orc.trace(phase, 0, rays, seed)
-        dt = time.perf_counter() - t0
-    print(json.dumps({"seconds": dt, "intersections": int(c[2 + phase - 1])}))
+        times = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            _, c = orc.trace(phase, 0, rays, seed)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    print(json.dumps({"seconds": times[len(times) // 2], "all_seconds": times, "intersections": int(c[2 + phase - 1])}))
 
 
 def main():
@@ -87,10 +94,11 @@ def main():
     ap.add_argument("--rays", type=int, default=50_000_000)
     ap.add_argument("--phase", type=int, default=2)
     ap.add_argument("--kind", choices=["auto", "reference", "port"], default="auto")
-    ap.add_argument("--worker", choices=["reference", "port"], default=None, help="internal: one timing")
+    ap.add_argument("--repeats", type=int, default=3, help="timings per thread count; the median is reported")
+    ap.add_argument("--worker", choices=["reference", "port"], default=None, help="internal: one thread count")
     args = ap.parse_args()
     if args.worker:
-        return worker(args.worker, args.rays, args.phase)
+        return worker(args.worker, args.rays, args.phase, args.repeats)
 
     from oracle.binding import reference_available
     cpus = os.sched_getaffinity(0)
@@ -111,9 +119,9 @@ def main():
     sweep = {}
     for k in ([kind] if kind == "port" else ["reference", "port"]):
         for t in tried:
-            r = run_once(k, args.rays, args.phase, t)
-            sweep[f"{k}@{t}"] = {"threads": t, "seconds": r["seconds"], "value": r["intersections"] / r["seconds"],
-                                 "rays_per_s": args.rays / r["seconds"]}
+            r = run_once(k, args.rays, args.phase, t, args.repeats)
+            sweep[f"{k}@{t}"] = {"threads": t, "seconds": r["seconds"], "all_seconds": r["all_seconds"],
+                                 "value": r["intersections"] / r["seconds"], "rays_per_s": args.rays / r["seconds"]}
             isect = r["intersections"]
     best_t = max(tried, key=lambda t: sweep[f"{kind}@{t}"]["value"])
     best = sweep[f"{kind}@{best_t}"]
@@ -130,7 +138,7 @@ def main():
         "threads": best_t, "physical_cores_available": n_cores, "hardware_threads_available": n_threads,
         "kind": kind,
         "sample": f"{args.rays} rays of phase {args.phase} (BASELINE configs[1] system, seed 123456789), "
-                  f"{isect} intersections in {best['seconds']:.3f} s wall on {best_t} threads "
+                  f"{isect} intersections in {best['seconds']:.3f} s wall (median of {args.repeats}) on {best_t} threads "
                   f"(best of threads = {tried}); {what}",
         "rays_per_s": best["rays_per_s"], "seconds": best["seconds"], "cpu": cpu_model,
         "thread_sweep": sweep, **extra}))
