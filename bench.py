@@ -325,8 +325,9 @@ def main() -> int:
             "bound": "valu_fp64", "achieved": ach_tf, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach_tf / FP64_VEC_PEAK_TFLOPS,
             "traffic": traffic,                                   # HBM bytes per launch, rocprofv3 PMC (or null)
-            "kernel": "trace_queue_kernel<MODE_FUSED, filtered, surface program> (+ the literal re-run launch, "
-                      "same event bracket; fold_kernel runs once per run, when the image is read)",
+            "kernel": "trace_queue_kernel<MODE_FUSED, filtered, surface program> (one launch per <= 2^25 rays, timed by the "
+                      "event pair the launch itself carries; the literal re-run of deferred rays — normally none — runs "
+                      "once per group of launches, fold_kernel once per run when the image is read)",
             "kernel_ms": k_s * 1e3,                               # mean duration of ONE kernel launch
             "kernel_launches_per_step": launches_per_step,        # phases x launches of <= 2^25 rays per ort_trace call
             "rays_per_kernel_launch": rays_launch,
