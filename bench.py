@@ -101,6 +101,15 @@ def cpu_baseline(rays: int):
                 "sample": f"failed: {e!r}"}
 
 
+def ring_cull_fraction(system) -> float:
+    """Share of the ring rays whose lens-disc sample lies outside the plano-convex aperture (what the ring
+    programs' segment 0 culls when the geometry allows it: csrc/ort_hip.hip ring_cull_threshold)."""
+    from opticalraytrace_amd import capi
+    c = capi.pack_system(system)
+    ap = c.surfaces[0][0].aperture
+    return max(0.0, 1.0 - ap * ap * (1.0 + 1e-6) / c.ring_lens_r2) if ap > 0 and c.ring_lens_r2 > 0 else 0.0
+
+
 def profiled_counters(workload: str, build_id: str):
     """Counters of the committed rocprofv3 --pmc passes (profiles/pmc_per_launch.json, written by
     tools/stamp_profiles.py) — only when they were taken on THIS build of the kernels."""
@@ -333,6 +342,9 @@ def main() -> int:
             "rays_per_kernel_launch": rays_launch,
             "flop_per_intersection": FLOP_PER_INTERSECTION,
             "flop_per_ring_emission": FLOP_PER_RING_EMISSION,
+            # ring loop only: the share of its rays that end at the first aperture by their third draw alone and
+            # are counted (lost, one surface solve) without being emitted — DESIGN §3.8; radius^2 / (radius + 10 mm)^2
+            "ring_rays_culled_fraction": ring_cull_fraction(system) if 1 in phases else None,
             "algorithmic_flop_per_launch": alg_flop,
             "note": "algorithmic flop = an assumed 100 per surface solve (SURVEY §8d; + 61 per emitted ring "
                     "ray in the ring loop) / mean launch duration (HIP events on the context's stream)"
