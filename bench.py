@@ -85,6 +85,97 @@ def launch_ranks(args, argv) -> int:
     return p.returncode
 
 
+def single_process(args, phases, rays_gpu, text) -> int:
+    """`--gpus N --single-process`: ONE process drives N contexts (one per device) and sums image + counters
+    with ort_allreduce (RCCL inside the library) — the layout of a Fortran host that owns all GPUs of a node
+    (src/main.f90:88 + src/imageMod.f90:55-56 across devices).  Same steps, same rays,
+    same JSON line as the one-process-per-GPU layout; only the exact fp64 leg is run."""
+    import torch                                    # first: libort_hip.so must bind to torch's HIP runtime
+    from opticalraytrace_amd import capi
+    from opticalraytrace_amd.capi import C_BINNED_POINT, C_BINNED_RING, C_ISECT_POINT, C_ISECT_RING, Context
+    from opticalraytrace_amd.params import Settings
+    from opticalraytrace_amd.system import OpticalSystem
+    from opticalraytrace_amd.tracer import DEFAULT_SEED, shard_range
+    world = args.gpus
+    have = capi.device_count()
+    if have < world:
+        sys.stderr.write(f"bench.py: --gpus {world} --single-process but this node shows {have} GPU(s); "
+                         "one context per GPU is the only supported layout\n")
+        return 2
+    strong = rays_gpu is None
+    total_rays = 1_000_000_000 if strong else rays_gpu * world
+    system = OpticalSystem.from_settings(Settings(nphotons=min(total_rays, 2**31 - 1), make_images=True,
+                                                  bottle_file="clearBottle-large.params", L2_file="planoConvex-f39.9mm.params",
+                                                  L3_file="achromaticDoublet-f50.0mm.params"))
+    streams = [torch.cuda.Stream(device=g) for g in range(world)]
+    ctxs = [Context(system, device=g, stream=streams[g].cuda_stream) for g in range(world)]
+    shards = [shard_range(total_rays, g, world) for g in range(world)]
+    for c, (lo, cnt) in zip(ctxs, shards):
+        c.set_timing(True)
+        c.reserve(cnt)
+        for ph in phases:
+            c.trace(ph, 0, 64, DEFAULT_SEED)
+    settle = max(2 * len(phases), min(160, 1_600_000_000 // shards[0][1]))
+    for k in range(settle):
+        for c, (lo, cnt) in zip(ctxs, shards):
+            c.trace(phases[k % len(phases)], k * cnt, cnt, DEFAULT_SEED)
+
+    def run(steps, first):
+        for c in ctxs:
+            c.reset()
+        for c in ctxs:
+            c.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            for c, (lo, cnt) in zip(ctxs, shards):
+                for ph in phases:
+                    c.trace(ph, (first + k) * total_rays + lo, cnt, DEFAULT_SEED)
+        for c in ctxs:
+            c.flush()
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        with torch.cuda.device(0):
+            ev[0].record(streams[0])
+        if world > 1 or args.force_dist:
+            capi.allreduce(ctxs)
+        with torch.cuda.device(0):
+            ev[1].record(streams[0])
+        for c in ctxs:
+            c.synchronize()
+        return time.perf_counter() - t0, ev[0].elapsed_time(ev[1])
+
+    run(args.warmup, 0)
+    elapsed, reduce_ms = run(args.steps, args.warmup)
+    img, cnt8 = ctxs[0].read()                                  # the global sums (every context holds them)
+    isect = sum(int(cnt8[C_ISECT_RING if ph == 1 else C_ISECT_POINT]) for ph in phases)
+    for ph in phases:
+        assert int(img[ph - 1].sum()) == int(cnt8[C_BINNED_RING if ph == 1 else C_BINNED_POINT]), "image and counter disagree"
+    culled = sum(c.work_counters()[0] for c in ctxs)
+    kms = ctxs[0].kernel_times(min(args.steps * len(phases), 64))
+    cnt0 = shards[0][1]
+    kernels_per_call = -(-cnt0 // capi.MAX_RAYS_PER_LAUNCH)
+    k_s = (sum(kms) / len(kms)) * 1e-3 / kernels_per_call
+    launches = args.steps * world * len(phases) * kernels_per_call
+    ring_share = sum(1 for ph in phases if ph == 1) / len(phases)
+    alg = FLOP_PER_INTERSECTION * isect / launches + FLOP_PER_RING_EMISSION * (cnt0 / kernels_per_call) * ring_share
+    exe = alg - (FLOP_PER_INTERSECTION + FLOP_PER_RING_EMISSION) * culled / launches
+    print(json.dumps({
+        "metric": "ray-surface intersections/sec", "value": isect / elapsed, "unit": "intersections/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "value_executed": (isect - culled) / elapsed, "reduce_ms": reduce_ms,
+        "config": {"workload": text, "name": args.workload, "host": "single-process: one context per device, ort_allreduce",
+                   "rays_per_layer_per_step": total_rays, "rays_per_gpu_per_launch": cnt0, "phases": list(phases),
+                   "seed": DEFAULT_SEED, "intersections_per_step": isect / args.steps, "settle_launches": settle,
+                   "build_id": capi.build_id()},
+        "roofline": {"bound": "valu_fp64", "achieved": alg / k_s / 1e12, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": alg / k_s / 1e12 / FP64_VEC_PEAK_TFLOPS, "frac_executed": exe / k_s / 1e12 / FP64_VEC_PEAK_TFLOPS,
+                     "traffic": None, "kernel_ms": k_s * 1e3, "note": "device 0's launches; see the default layout's line for counters"},
+    }), flush=True)
+    for c in ctxs:
+        c.close()
+    return 0
+
+
 def cpu_baseline(rays: int):
     """Time the CPU checker on a bounded sample of the same workload (rank 0, N=1 only).
 
@@ -136,12 +227,17 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast", action="store_true", help="skip the informational fast-fp64 leg")
     ap.add_argument("--no-fp32", action="store_true", help="skip the informational fp32 leg (configs[4])")
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process, one context per GPU, ort_allreduce (the Fortran host's layout, INTEGRATION.md §C)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and all-reduce even with one rank (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         ap.error("--gpus >= 1, --steps >= 1, --warmup >= 0")
 
+    if args.single_process:
+        phases, rays_gpu, text = WORKLOADS[args.workload]
+        return single_process(args, (args.phase,) if args.phase else phases, args.rays or rays_gpu, text)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -203,17 +299,6 @@ def main() -> int:
         for ph in phases:
             ctx.trace(ph, 0, 64, DEFAULT_SEED)
     ctx.set_precision(0)
-    # ... and the clocks: after an idle period (this process has just spent seconds in the CPU baseline
-    # and in imports) the first ~30 ms of GPU work run at lower clocks (tools/rampbench.py,
-    # profiles/r02/ramp.log: 0.446 ms for the first 64 launches, 0.406 from then on).  A production run
-    # of this path is >= 40 ms of back-to-back launches per 1e9-ray layer, so steady clocks are the
-    # regime the metric is about: SETTLE_LAUNCHES (160 at 1e7 rays) untimed launches of the step's own size come first,
-    # for every leg alike.  They are set-up like the priming launches above — not among the W warm-up
-    # steps, not in the timed region — and are reported in config.settle_launches.
-    SETTLE_LAUNCHES = max(2 * len(phases), min(160, 1_600_000_000 // cnt))   # launches of the step's own size: ~50 ms
-    for k in range(SETTLE_LAUNCHES):
-        ctx.trace(phases[k % len(phases)], k * cnt, cnt, DEFAULT_SEED)
-    ctx.synchronize()
 
     # step k traces the global ray indices [k*T, (k+1)*T) of each of its phases (T = rays per layer
     # per step over all ranks), this rank its contiguous shard of them
@@ -238,12 +323,25 @@ def main() -> int:
         fence()
         tracer.reset()
         fence()
+        w0 = ctx.work_counters()
         t0 = time.perf_counter()
         for k in range(steps):
             step(args.warmup + k)
+        tracer.flush()                              # the group's literal re-run + the fold, then the reduce
+        if use_dist:                                # reduce_ms: an event pair around the all-reduce alone
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         tracer.reduce(force=use_dist)
+        if use_dist:
+            ev[1].record()
         fence()
         el = time.perf_counter() - t0
+        timed_run.reduce_ms = ev[0].elapsed_time(ev[1]) if use_dist else 0.0
+        w1 = ctx.work_counters()
+        work = torch.tensor([w1[0] - w0[0], w1[1] - w0[1]], dtype=torch.int64, device="cuda")
+        if use_dist:
+            dist.all_reduce(work)
+        timed_run.culled, timed_run.deferred = (int(x) for x in work.tolist())
         if use_dist:
             tmax = torch.tensor([el], dtype=torch.float64, device="cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -252,6 +350,26 @@ def main() -> int:
         kms = ctx.kernel_times(min(steps * len(phases), 64))
         return el, kms
 
+    # ---- the COLD figure: exactly what `--warmup W --steps K` give straight after the priming launches,
+    # i.e. without the settle launches below.  The process has just spent seconds on the CPU (baseline,
+    # imports): the GPU clocks are still ramping through these steps.  Reported as ms_per_step_cold /
+    # value_cold next to the steady-clock figure `value`.
+    cold_elapsed, _ = timed_run(args.steps, args.warmup)
+    cold_res = tracer.result(total_rays * args.steps)
+    cold_isect = sum(int(cold_res.counters[C_ISECT_RING if ph == 1 else C_ISECT_POINT]) for ph in phases)
+
+    # ... and the clocks: after an idle period (this process has just spent seconds in the CPU baseline
+    # and in imports) the first ~30 ms of GPU work run at lower clocks (tools/rampbench.py,
+    # profiles/r02/ramp.log: 0.446 ms for the first 64 launches, 0.406 from then on).  A production run
+    # of this path is >= 40 ms of back-to-back launches per 1e9-ray layer, so steady clocks are the
+    # regime the metric is about: SETTLE_LAUNCHES (160 at 1e7 rays) untimed launches of the step's own size come first,
+    # for every leg alike.  They are set-up like the priming launches above — not among the W warm-up
+    # steps, not in the timed region — and are reported in config.settle_launches.
+    SETTLE_LAUNCHES = max(2 * len(phases), min(160, 1_600_000_000 // cnt))   # launches of the step's own size: ~50 ms
+    for k in range(SETTLE_LAUNCHES):
+        ctx.trace(phases[k % len(phases)], k * cnt, cnt, DEFAULT_SEED)
+    ctx.synchronize()
+
     def isect_binned(res):
         i = sum(int(res.counters[C_ISECT_RING if ph == 1 else C_ISECT_POINT]) for ph in phases)
         b = sum(int(res.counters[C_BINNED_RING if ph == 1 else C_BINNED_POINT]) for ph in phases)
@@ -259,6 +377,7 @@ def main() -> int:
 
     # ---- the leg `value` reports: exact fp64 — first, straight after the set-up ------------------
     elapsed, kernel_ms = timed_run(args.steps, args.warmup)
+    reduce_ms, culled_total, deferred_total = timed_run.reduce_ms, timed_run.culled, timed_run.deferred
     res = tracer.result(total_rays * args.steps)   # counters of the whole timed run, summed over ranks
     isect_total, binned_total = isect_binned(res)
     for ph in phases:
@@ -276,7 +395,7 @@ def main() -> int:
         ctx.set_precision(prec)
         el, kms = timed_run(args.steps, args.warmup)
         r = tracer.result(total_rays * args.steps)
-        legs[name] = (el, kms, r)
+        legs[name] = (el, kms, r, timed_run.culled)
     ctx.set_precision(0)
 
     # ---- roofline of the dominant kernel (the fused trace kernel), per launch = per rank per phase
@@ -294,18 +413,28 @@ def main() -> int:
     alg_flop = FLOP_PER_INTERSECTION * isect_launch + FLOP_PER_RING_EMISSION * rays_launch * ring_share
     contract_bytes = BYTES_PER_RAY * rays_launch + BYTES_PER_BINNED * binned_launch
     ach_tf = alg_flop / k_s / 1e12
+    # EXECUTED work (ring loop): a ray that segment 0 counts at the first aperture costs one hash and one
+    # compare — no surface solve, no emission — so it is priced at zero flop and leaves both counts
+    culled_launch = culled_total / args.steps / world / launches_per_step
+    isect_exec_per_step = isect_per_step - culled_total / args.steps
+    exec_flop = (FLOP_PER_INTERSECTION * (isect_launch - culled_launch)
+                 + FLOP_PER_RING_EMISSION * (rays_launch * ring_share - culled_launch))
+    exec_tf = exec_flop / k_s / 1e12
     build = capi.build_id()
     prof, prof_note = profiled_counters(args.workload if not custom else "custom", build)
     prof = prof or {}
     traffic = prof.get("hbm_bytes_per_launch")
 
-    def fp_roofline(kms, r, peak, bound, kernels):
+    def fp_roofline(kms, r, culled, peak, bound, kernels):
         """per CALL here: the fp32 path is not cut into launches of 2^25 rays (nothing is deferred)"""
         ks = (sum(kms) / len(kms)) * 1e-3 / kernels
         i, _ = isect_binned(r)
-        fl = (FLOP_PER_INTERSECTION * i / args.steps / world / len(phases) + FLOP_PER_RING_EMISSION * cnt * ring_share) / kernels
+        per_call = 1.0 / args.steps / world / len(phases)
+        fl = (FLOP_PER_INTERSECTION * i * per_call + FLOP_PER_RING_EMISSION * cnt * ring_share) / kernels
+        fx = (FLOP_PER_INTERSECTION * (i - culled) * per_call + FLOP_PER_RING_EMISSION * (cnt * ring_share - culled * per_call)) / kernels
         return {"bound": bound, "achieved": fl / ks / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": fl / ks / 1e12 / peak, "kernel_ms": ks * 1e3, "kernel_launches_per_step": len(phases) * kernels}
+                "frac": fl / ks / 1e12 / peak, "achieved_executed": fx / ks / 1e12, "frac_executed": fx / ks / 1e12 / peak,
+                "kernel_ms": ks * 1e3, "kernel_launches_per_step": len(phases) * kernels}
 
     out = {
         "metric": "ray-surface intersections/sec",
@@ -315,6 +444,13 @@ def main() -> int:
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        # the same K steps behind the same W warm-up steps WITHOUT the settle launches (clocks still ramping)
+        "ms_per_step_cold": cold_elapsed / args.steps * 1e3,
+        "value_cold": cold_isect / cold_elapsed,
+        # what was executed: intersections minus the ring rays counted at the first aperture without a surface
+        # solve (segment 0 of the ring programs; 0 for the point loop), and the all-reduce on its own
+        "value_executed": isect_exec_per_step * args.steps / elapsed,
+        "reduce_ms": reduce_ms,
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
@@ -326,6 +462,9 @@ def main() -> int:
                    "sharding": f"contiguous global ray ranges over {world} rank(s); one RCCL sum of "
                                "image+counters per run of K steps, inside the timed region",
                    "intersections_per_step": isect_per_step, "binned_per_step": binned_per_step,
+                   "intersections_executed_per_step": isect_exec_per_step,
+                   "ring_rays_culled_per_step": culled_total / args.steps,
+                   "rays_deferred_to_literal_rerun_per_step": deferred_total / args.steps,
                    "rays_per_s": total_rays * len(phases) * args.steps / elapsed,
                    "settle_launches": SETTLE_LAUNCHES,
                    "build_id": build},
@@ -333,6 +472,9 @@ def main() -> int:
         "roofline": {
             "bound": "valu_fp64", "achieved": ach_tf, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": ach_tf / FP64_VEC_PEAK_TFLOPS,
+            # the same with executed work only (culled ring rays priced at zero): equals `frac` for the point loop
+            "achieved_executed": exec_tf, "frac_executed": exec_tf / FP64_VEC_PEAK_TFLOPS,
+            "executed_flop_per_launch": exec_flop,
             "traffic": traffic,                                   # HBM bytes per launch, rocprofv3 PMC (or null)
             "kernel": "trace_queue_kernel<MODE_FUSED, filtered, surface program> (one launch per <= 2^25 rays, timed by the "
                       "event pair the launch itself carries; the literal re-run of deferred rays — normally none — runs "
@@ -378,11 +520,11 @@ def main() -> int:
         } if traffic else None),
     }
     if "fp32" in legs:
-        el, kms, r = legs["fp32"]
+        el, kms, r, cul = legs["fp32"]
         i32, b32 = isect_binned(r)
         out["fp32"] = {
             "value": i32 / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3, "dtype": "f32",
-            "roofline": fp_roofline(kms, r, FP32_VEC_PEAK_TFLOPS, "valu_fp32", 1),
+            "roofline": fp_roofline(kms, r, cul, FP32_VEC_PEAK_TFLOPS, "valu_fp32", 1),
             "image_l1_vs_exact": int(abs(r.image.astype("int64") - res.image.astype("int64")).sum()),
             "image_l1_vs_exact_frac_of_binned": float(abs(r.image.astype("int64") - res.image.astype("int64")).sum()) / max(binned_total, 1),
             "binned": b32, "binned_exact": binned_total, "intersections": i32, "intersections_exact": isect_total,
@@ -390,11 +532,11 @@ def main() -> int:
                     "predicates, uniforms = top 24 bits of the same draws; tests/test_gpu_fp32.py holds the tolerance study",
         }
     if "fast_fp64" in legs:
-        el, kms, r = legs["fast_fp64"]
+        el, kms, r, cul = legs["fast_fp64"]
         i2, _ = isect_binned(r)
         out["fast_fp64"] = {
             "value": i2 / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3,
-            "roofline": fp_roofline(kms, r, FP64_VEC_PEAK_TFLOPS, "valu_fp64", kernels_per_call),
+            "roofline": fp_roofline(kms, r, cul, FP64_VEC_PEAK_TFLOPS, "valu_fp64", kernels_per_call),
             "image_l1_vs_exact": int(abs(r.image.astype("int64") - res.image.astype("int64")).sum()),
             "note": "ort_set_precision(2): FMA contraction + Newton reciprocal/rsqrt; ~1e-15 relative from the "
                     "exact path, not bit-identical (tests/test_gpu_fastd.py)",

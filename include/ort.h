@@ -170,6 +170,10 @@ int ort_device_count(int *count);
  * passed as void*; NULL = the device's default (null) stream.  Every launch, copy and
  * memset of the context is issued on that stream, in call order. */
 int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out);
+/* Waits for the context's stream and releases everything the context owns.  Attached buffers
+ * (ort_attach_buffers) are the caller's and are left as they are — in particular NOT completed: hits
+ * still held in the per-XCD copies, and rays a group of launches deferred to its literal re-run, are
+ * dropped.  A host that wants them calls ort_flush (or any of the calls listed there) first. */
 int ort_destroy(ort_ctx *ctx);
 int ort_set_system(ort_ctx *ctx, const ort_system *sys);
 /* Histogram of the `image` light source (reference imgin, src/sourceMod.f90:363-408) as its
@@ -179,8 +183,9 @@ int ort_set_system(ort_ctx *ctx, const ort_system *sys);
 int ort_set_image_source(ort_ctx *ctx, const int64_t *cdf);
 int ort_reset(ort_ctx *ctx);                       /* image = 0, counters = 0 (src/main.f90:39-41) */
 /* ort_trace bins into per-XCD private copies of the image and adds them into the image when the
- * image is next needed (ort_read, ort_reset, ort_allreduce, ort_synchronize, ort_device_image,
- * ort_attach_buffers do it themselves).  A host that reads ATTACHED device buffers on its own
+ * image is next needed, and the few rays a group of launches deferred to the literal re-run are counted
+ * (image AND counters) when the group closes (ort_read, ort_reset, ort_allreduce, ort_synchronize,
+ * ort_device_image, ort_device_counters, ort_attach_buffers do both themselves).  A host that reads ATTACHED device buffers on its own
  * (torch tensors, its own RCCL communicator) calls ort_flush first; asynchronous, on the context's
  * stream. */
 int ort_flush(ort_ctx *ctx);
@@ -250,6 +255,17 @@ int ort_allreduce(ort_ctx **ctxs, int n);
 int ort_device_image(ort_ctx *ctx, void **d_image);
 int ort_device_counters(ort_ctx *ctx, void **d_counters);
 int ort_synchronize(ort_ctx *ctx);
+/* Executed-work counters since the last ort_reset — bookkeeping for measurements, NOT part of the
+ * result (the image and counters above are what the reference computes, however the work was done):
+ *   [ORT_W_CULLED]   ring rays that segment 0 of the ring programs counted as lost at the first aperture
+ *                    (one intersection each in ORT_C_ISECT_RING, as the reference executes them) WITHOUT
+ *                    emitting them or solving a surface — see ort_set_kernel_variant bit 3
+ *   [ORT_W_DEFERRED] rays the filtered kernels handed to the literal re-run (traced twice in part)
+ * Synchronous. */
+#define ORT_NUM_WORK 2
+#define ORT_W_CULLED 0
+#define ORT_W_DEFERRED 1
+int ort_work_counters(ort_ctx *ctx, uint64_t *work);
 /* Optional: allocate now the per-launch scratch a trace of up to n_rays rays needs (otherwise the
  * first such ort_trace allocates it, synchronising the stream once).  The reference allocates its
  * image up front as well (src/main.f90:35). */

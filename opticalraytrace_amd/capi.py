@@ -195,6 +195,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ort_device_image": (C.c_int, [vp, C.POINTER(vp)]),
         "ort_device_counters": (C.c_int, [vp, C.POINTER(vp)]),
         "ort_synchronize": (C.c_int, [vp]),
+        "ort_work_counters": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "ort_reserve": (C.c_int, [vp, u64]),
         "ort_last_kernel_ms": (C.c_int, [vp, i32, C.POINTER(C.c_float)]),
         "ort_set_timing": (C.c_int, [vp, i32]),
@@ -216,7 +217,7 @@ EXPORTED_SYMBOLS = ["ort_abi_version", "ort_build_id", "ort_allreduce", "ort_las
                     "ort_destroy", "ort_set_system", "ort_set_image_source", "ort_reset", "ort_flush", "ort_trace", "ort_emit",
                     "ort_trace_resident", "ort_trace_rays", "ort_trace_paths", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
-                    "ort_device_counters", "ort_synchronize", "ort_reserve", "ort_last_kernel_ms",
+                    "ort_device_counters", "ort_synchronize", "ort_work_counters", "ort_reserve", "ort_last_kernel_ms",
                     "ort_set_timing", "ort_kernel_times", "ort_set_kernel_variant", "ort_set_precision"]
 
 
@@ -305,6 +306,13 @@ class Context:
 
     def synchronize(self) -> None:
         _check(self.lib, self.lib.ort_synchronize(self._h), "ort_synchronize")
+
+    def work_counters(self):
+        """(ring rays culled by segment 0 without being emitted, rays deferred to the literal re-run)
+        since the last reset: executed-work bookkeeping, not part of the result."""
+        w = np.zeros(2, dtype=np.uint64)
+        _check(self.lib, self.lib.ort_work_counters(self._h, w.ctypes.data_as(C.POINTER(C.c_uint64))), "ort_work_counters")
+        return int(w[0]), int(w[1])
 
     def reserve(self, n_rays: int) -> None:
         """Allocate the per-launch scratch of traces of up to n_rays rays now (optional)."""

@@ -74,6 +74,7 @@ struct TraceArgs {
     int32_t *image;              // [2][401][401]
     int32_t *replicas;           // [kReplicas][2][kSlots] or null: see bin_hit, fold_kernel
     unsigned long long *counters;
+    unsigned long long *work;    // [ORT_NUM_WORK]: executed-work counters (ort_work_counters), not part of the result
     uint64_t first_ray, n_rays, rng_base;
     int phase, draw_base;
     // ray ranges of the queued kernel's waves (host: plan_ranges): workgroups [0, head_blocks) cut
@@ -617,6 +618,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
         // the last workgroup to finish leaves the list empty for the next launch (every workgroup
         // has read ctl[0] before it counts itself done)
         if (listed && threadIdx.x == 0 && atomicAdd(&a.redo_ctl[1], 1u) == gridDim.x - 1) {
+            atomicAdd(&a.work[ORT_W_DEFERRED], (unsigned long long)a.redo_ctl[0]);
             a.redo_ctl[0] = 0;
             a.redo_ctl[1] = 0;
         }
@@ -665,7 +667,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     // intersections evaluated before the queue point: `split` for every survivor unless a surface
     // scatters (extended instantiation), so only that one carries the count through the queue
     __shared__ int QN[kWavesPerBlock][SCAT ? kQueueCap : 1];
-    __shared__ unsigned int blk[4];
+    __shared__ unsigned int blk[5];       // lost, isect, binned, help3, culled
     __shared__ SurfAuxT<T> AUX[PROG == PROG_GENERIC ? ORT_MAX_SURFACES : 1];
     // a program kernel reads everything it needs of the system (surface records, emitter and image
     // constants) through scalar loads from the device copy: nothing to stage, no barrier at its start
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
         stage_system(S, a.sys);
         stage_aux(AUX, S.surfaces[a.phase - 1], S.n_surfaces[a.phase - 1]);
     }
-    if (threadIdx.x < 4) blk[threadIdx.x] = 0;
+    if (threadIdx.x < 5) blk[threadIdx.x] = 0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     uint64_t lo = (head ? 0 : a.head_rays) + wid * chunk; if (lo > end) lo = end;
     uint64_t hi = lo + chunk;  if (hi > end) hi = end;
 
-    unsigned int lost = 0, isect = 0, binned = 0, help3 = 0;
+    unsigned int lost = 0, isect = 0, binned = 0, help3 = 0, culled = 0;
     auto finish = [&](int st, int nis, int xp, int yp) {
         isect += (unsigned)nis;
         if (st == ORT_ST_BINNED) {
@@ -853,7 +855,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 const bool cand = act && !dies;
                 const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
                 if (cand) cq[(chead + ccount + lane_prefix(mask)) & (kQueueCap - 1)] = (uint32_t)i;
-                else if (act) finish(ORT_ST_LOST_TELESCOPE, 1, 0, 0);
+                else if (act) { finish(ORT_ST_LOST_TELESCOPE, 1, 0, 0); culled++; }
                 ccount += __popcll(mask);
             }
             __builtin_amdgcn_wave_barrier();
@@ -863,9 +865,11 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     }
     atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect);
     atomicAdd(&blk[2], binned); atomicAdd(&blk[3], help3);
+    if constexpr (PRE) atomicAdd(&blk[4], culled);
     __syncthreads();
     if (threadIdx.x < 4 && blk[threadIdx.x])
         atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
+    if (PRE && threadIdx.x == 4 && blk[4]) atomicAdd(&a.work[ORT_W_CULLED], (unsigned long long)blk[4]);
 }
 
 __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int phase,
@@ -1006,6 +1010,7 @@ struct ort_ctx {
     unsigned int *d_redo_ctl;    // [2]: entries, re-run workgroups done; zero between launches
     long long *d_img_cdf;        // image-source table (ORT_IMAGE_SOURCE_CELLS + 1) or null
     unsigned long long *d_counters, *own_counters;
+    unsigned long long *d_work;  // [ORT_NUM_WORK], see ort_work_counters
     bool timing;
     int variant;                 // bit mask, see ort_set_kernel_variant
     int precision;               // 0 fp64 (reference arithmetic), 1 fp32 (study path)
@@ -1180,6 +1185,8 @@ static int create_on_device(ort_ctx *c, const ort_system *sys)
     HIP_TRY(hipMalloc(&c->own_counters, ORT_NUM_COUNTERS * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&c->d_replicas, kReplicas * kReplicaInts * sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(c->d_replicas, 0, kReplicas * kReplicaInts * sizeof(int32_t), c->stream));
+    HIP_TRY(hipMalloc(&c->d_work, ORT_NUM_WORK * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->d_work, 0, ORT_NUM_WORK * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipMalloc(&c->d_redo_ctl, 2 * sizeof(unsigned int)));
     HIP_TRY(hipMemsetAsync(c->d_redo_ctl, 0, 2 * sizeof(unsigned int), c->stream));
     c->d_image = c->own_image;
@@ -1244,7 +1251,7 @@ int ort_destroy(ort_ctx *c)
     for (int k = 0; k < kTimingRing; ++k)
         for (int j = 0; j < 2; ++j) if (c->ring[k][j]) (void)hipEventDestroy(c->ring[k][j]);
     (void)hipFree(c->d_sys); (void)hipFree(c->own_image); (void)hipFree(c->own_counters); (void)hipFree(c->d_replicas); (void)hipFree(c->d_img_cdf);
-    (void)hipFree(c->d_redo_list); (void)hipFree(c->d_redo_ctl);
+    (void)hipFree(c->d_redo_list); (void)hipFree(c->d_redo_ctl); (void)hipFree(c->d_work);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ORT_OK;
@@ -1284,6 +1291,7 @@ int ort_reset(ort_ctx *c)
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->d_image, 0, ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, ORT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_work, 0, ORT_NUM_WORK * sizeof(unsigned long long), c->stream));
     return ORT_OK;
 }
 
@@ -1370,7 +1378,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
 {
     a0.sys = &c->d_sys->sys; a0.aux = c->d_sys->aux[a0.phase - 1];
     a0.sysf = &c->d_sys->sysf; a0.auxf = c->d_sys->auxf[a0.phase - 1];
-    a0.image = c->d_image; a0.counters = c->d_counters;
+    a0.image = c->d_image; a0.counters = c->d_counters; a0.work = c->d_work;
     const bool use_rep = (c->variant & 4) == 0 && mode != MODE_DEBUG;
     a0.replicas = use_rep ? c->d_replicas : nullptr;
     a0.img_cdf = c->d_img_cdf;
@@ -1719,7 +1727,19 @@ int ort_device_image(ort_ctx *c, void **d_image)
 int ort_device_counters(ort_ctx *c, void **d_counters)
 {
     if (!c || !d_counters) return fail(ORT_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    { const int rc = flush_replicas(c); if (rc) return rc; }     // the deferred rays of an open group are counted by its re-run
     *d_counters = c->d_counters;
+    return ORT_OK;
+}
+
+int ort_work_counters(ort_ctx *c, uint64_t *work)
+{
+    if (!c || !work) return fail(ORT_E_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    { const int rc = close_group(c); if (rc) return rc; }
+    HIP_TRY(hipMemcpyAsync(work, c->d_work, ORT_NUM_WORK * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return ORT_OK;
 }
 

@@ -79,6 +79,10 @@ class ShardedRun:
     def _flush(self) -> None:
         """Everything traced so far is in `image` / `counters` (stream-ordered)."""
 
+    def flush(self) -> None:
+        """Complete `image` / `counters` with everything traced so far (asynchronous)."""
+        self._flush()
+
     def reset(self) -> None:
         self._flush()
         self.image.zero_()

@@ -13,9 +13,13 @@ number of rays and prints one JSON object.
   kind "port": oracle/libort_oracle.so — the plain-C restatement, same loop.
 
 Only the loop is timed (no parsing, no file output), as for the GPU.  Each timing runs in a
-fresh process with OMP_NUM_THREADS = the physical cores, then every hardware thread; the best is
-reported with both counts stated (`cores`, `threads`); every figure is the median of `--repeats` (3)
-timings of the loop.
+fresh process with OMP_NUM_THREADS = the physical cores, then every hardware thread, each unbound
+(OMP_PROC_BIND=false) and bound (OMP_PROC_BIND=close, OMP_PLACES=cores); the best is reported with
+both counts stated (`cores`, `threads`) and its binding; every figure is the median of `--repeats`
+(3) timings of the loop.  A ONE-thread point (a proportionally smaller sample of the same rays) puts
+the figure in context: `parallel_efficiency` = best / (cores occupied x the one-thread figure).
+Nothing in the reference's loop (src/main.f90:83-89) is changed for any of this: the thread count
+and the binding are the OpenMP runtime's environment, as install.sh's -n is.
 """
 import argparse
 import json
@@ -44,10 +48,14 @@ def physical_cores(cpus):
     return len(cores) or len(cpus)
 
 
-def run_once(kind: str, rays: int, phase: int, threads: int, repeats: int):
+def run_once(kind: str, rays: int, phase: int, threads: int, repeats: int, bind: bool = False):
     """The timings of one thread count in a fresh process (the OpenMP team size is fixed at first use)."""
     import subprocess
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close" if bind else "false")
+    if bind:
+        env["OMP_PLACES"] = "cores"
+    else:
+        env.pop("OMP_PLACES", None)
     out = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", kind, "--rays", str(rays),
                           "--phase", str(phase), "--repeats", str(repeats)], env=env, capture_output=True, text=True,
                          timeout=900)
@@ -68,7 +76,7 @@ def worker(kind: str, rays: int, phase: int, repeats: int):
     osys = OpticalSystem.from_settings(s)
     orc = Oracle(osys)
     seed = 123456789
-    warm = 1_000_000                                        # first large call pays thread/arena start-up
+    warm = min(1_000_000, rays)                             # first large call pays thread/arena start-up
     if kind == "reference":
         ref = Reference(s, resource_dir())
         ref.trace(phase, 0, warm, seed)
@@ -114,32 +122,63 @@ def main():
                 break
     except OSError:
         pass
-    # thread counts tried: one per physical core, and every hardware thread; the best is reported
+    # thread counts tried: one per physical core, and every hardware thread, each unbound and bound to
+    # cores; the best is reported.  Plus one thread on a sample scaled down by the core count.
     tried = sorted({n_cores, n_threads})
+    one_rays = max(200_000, args.rays // max(n_cores, 1))
     sweep = {}
-    for k in ([kind] if kind == "port" else ["reference", "port"]):
+    kinds = [kind] if kind == "port" else ["reference", "port"]
+
+    def entry(r, t, rays, bind):
+        return {"threads": t, "bind": "close/cores" if bind else "none", "rays": rays, "seconds": r["seconds"],
+                "all_seconds": r["all_seconds"], "value": r["intersections"] / r["seconds"], "rays_per_s": rays / r["seconds"]}
+
+    for k in kinds:
+        r = run_once(k, one_rays, args.phase, 1, 1)
+        sweep[f"{k}@1"] = entry(r, 1, one_rays, False)
         for t in tried:
-            r = run_once(k, args.rays, args.phase, t, args.repeats)
-            sweep[f"{k}@{t}"] = {"threads": t, "seconds": r["seconds"], "all_seconds": r["all_seconds"],
-                                 "value": r["intersections"] / r["seconds"], "rays_per_s": args.rays / r["seconds"]}
-            isect = r["intersections"]
-    best_t = max(tried, key=lambda t: sweep[f"{kind}@{t}"]["value"])
-    best = sweep[f"{kind}@{best_t}"]
+            for bind in (False, True):
+                try:
+                    r = run_once(k, args.rays, args.phase, t, args.repeats, bind)
+                except RuntimeError:
+                    if bind:                                # a runtime that cannot bind (cgroup cpuset): unbound only
+                        continue
+                    raise
+                sweep[f"{k}@{t}" + ("b" if bind else "")] = entry(r, t, args.rays, bind)
+                isect = r["intersections"]
+
+    def best_of(k):
+        keys = [x for x in sweep if x.startswith(k + "@") and x != f"{k}@1"]
+        return max(keys, key=lambda x: sweep[x]["value"])
+
+    best_key = best_of(kind)
+    best = sweep[best_key]
+    best_t = best["threads"]
+
+    def efficiency(k, key):
+        occupied = min(n_cores, sweep[key]["threads"])
+        return sweep[key]["value"] / (occupied * sweep[f"{k}@1"]["value"])
+
     extra = {}
     if kind == "reference":                                 # also report the C restatement
-        bp = max(tried, key=lambda t: sweep[f"port@{t}"]["value"])
-        extra = {"port_value": sweep[f"port@{bp}"]["value"], "port_threads": bp,
+        bp = best_of("port")
+        extra = {"port_value": sweep[bp]["value"], "port_threads": sweep[bp]["threads"], "port_bind": sweep[bp]["bind"],
+                 "port_one_thread_value": sweep["port@1"]["value"], "port_parallel_efficiency": efficiency("port", bp),
                  "port_sample": "oracle/libort_oracle.so (C restatement, gcc -O2 + OpenMP)"}
     what = ("oracle/_ref: the reference's own Fortran path sources compiled with flang -O2, OpenMP over rays"
             if kind == "reference" else "oracle/libort_oracle.so: C restatement, gcc -O2, OpenMP over rays")
     print(json.dumps({
         "value": best["value"], "unit": "intersections/s",
         "cores": min(n_cores, best_t),                      # physical cores the best run occupied
-        "threads": best_t, "physical_cores_available": n_cores, "hardware_threads_available": n_threads,
+        "threads": best_t, "bind": best["bind"], "physical_cores_available": n_cores, "hardware_threads_available": n_threads,
         "kind": kind,
+        "one_thread_value": sweep[f"{kind}@1"]["value"],
+        # best / (physical cores occupied x the one-thread figure): what the OpenMP loop of src/main.f90:83-89 with its
+        # atomic image update (src/imageMod.f90:55) keeps of one core's rate at this thread count
+        "parallel_efficiency": efficiency(kind, best_key),
         "sample": f"{args.rays} rays of phase {args.phase} (BASELINE configs[1] system, seed 123456789), "
                   f"{isect} intersections in {best['seconds']:.3f} s wall (median of {args.repeats}) on {best_t} threads "
-                  f"(best of threads = {tried}); {what}",
+                  f"(best of threads = {tried} x binding none / close-to-cores; one-thread point on {one_rays} rays); {what}",
         "rays_per_s": best["rays_per_s"], "seconds": best["seconds"], "cpu": cpu_model,
         "thread_sweep": sweep, **extra}))
 

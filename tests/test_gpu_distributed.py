@@ -156,3 +156,42 @@ def test_bench_one_rank_through_rccl():
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 1e9
     assert abs(line["config"]["intersections_per_step"] / 1e6 - 6.31) < 0.05      # 6.31 per point ray
     assert line["roofline"]["bound"] == "valu_fp64" and 0 < line["roofline"]["frac"] < 1
+
+
+def test_bench_single_process_layout():
+    """`bench.py --single-process`: one process, one context per GPU, ort_allreduce.  One GPU: the line of a
+    one-context run with the reduce forced (a one-rank RCCL communicator inside the library); asking for
+    more GPUs than the box has fails cleanly, as the torchrun layout does."""
+    p = _bench("--gpus", "1", "--single-process", "--force-dist", "--steps", "3", "--warmup", "1", "--rays", "1000000")
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 1e9 and "single-process" in line["config"]["host"]
+    assert abs(line["config"]["intersections_per_step"] / 1e6 - 6.31) < 0.05
+    assert line["reduce_ms"] > 0 and 0 < line["roofline"]["frac"] < 1
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = _bench("--gpus", str(n), "--single-process", "--steps", "3", "--warmup", "1")
+    assert p.returncode != 0 and "GPU(s)" in p.stderr and "Traceback" not in p.stderr
+
+
+def test_c_abi_allreduce_over_two_devices(plain):
+    """ort_allreduce over TWO contexts on two devices (skipped on a one-GPU box; the driver's 8-GPU node
+    runs it): shard 0 on device 0, shard 1 on device 1, one ort_allreduce — both contexts then hold the
+    single run's image and counters, bit for bit.  Two collectives (image, counters) per communicator in
+    one RCCL group."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: UNVERIFIED on hardware until an 8-GPU lease runs it")
+    from opticalraytrace_amd import capi
+    from opticalraytrace_amd.tracer import shard_range
+    osys, want = plain
+    with capi.Context(osys, device=0) as a, capi.Context(osys, device=1) as b:
+        for r, c in enumerate((a, b)):
+            lo, cnt = shard_range(N, r, 2)
+            c.reset()
+            for phase in (1, 2):
+                c.trace(phase, lo, cnt, SEED)
+        capi.allreduce([a, b])
+        for c in (a, b):
+            img, cnt = c.read()
+            assert np.array_equal(img, want.image) and np.array_equal(cnt, want.counters)

@@ -135,8 +135,10 @@ def test_edge_sizes(ctxs):
 
 
 def _image_budget(n_rays):
-    # rays whose emitted direction differs by an ulp and flips a discrete outcome: ~1e-6 of rays
-    return max(4, int(n_rays * 4e-6))
+    # rays whose emitted direction differs by an ulp (device sin / cos vs glibc) AND sit within that ulp of
+    # a decision boundary: expected ~1e-15 of the rays, observed 0 at every size up to 1e9
+    # (tests/test_gpu_fullsize_parity.py).  Two rays are allowed, whatever the size.
+    return 2
 
 
 @pytest.mark.parametrize("name", ["small", "large"])
@@ -335,7 +337,8 @@ def test_boundary_rays_bit_exact_in_both_predicate_modes(ctxs, name, phase):
 def test_config3_ring_1e8_and_config4_shape_1e9(ctxs):
     """BASELINE configs[2] (ring source, 1e8 rays) and the per-GPU shape of configs[3]
     (ring + point through the full stack, 1e9 rays per layer) at FULL size on one GPU:
-    size-independent properties (the oracle would need hours)."""
+    size-independent properties (the images and counters are compared with the oracle's, bin for
+    bin, in tests/test_gpu_fullsize_parity.py)."""
     osys, ctx = ctxs("large")
     ctx.reset()
     n3 = 100_000_000
@@ -424,7 +427,7 @@ def test_scattering_bottle_vs_oracle(ctxs, name):
     err = (np.abs(a - b) / scale).max(axis=0)
     assert np.mean(err > REL_TOL) < 1e-4, np.mean(err > REL_TOL)     # north_star's 1e-10: observed 2e-5 of the rays beyond it
     assert np.mean(err > 1e-12) < 5e-3
-    assert err.max() < 1e-8                                          # observed 2.9e-10
+    assert err.max() < 6e-10                                         # observed 2.9e-10 (2 x margin)
     ctx.reset()
     ctx.trace(2, 0, n, SEED)
     img, cnt = ctx.read()
