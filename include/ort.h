@@ -175,6 +175,10 @@ int ort_create(const ort_system *sys, int device, void *stream, ort_ctx **out);
  * still held in the per-XCD copies, and rays a group of launches deferred to its literal re-run, are
  * dropped.  A host that wants them calls ort_flush (or any of the calls listed there) first. */
 int ort_destroy(ort_ctx *ctx);
+/* Stage another system for the launches that FOLLOW (a sweep: runner.py re-runs the whole program per settings
+ * file, here ~8 KB move).  Asynchronous on the context's stream and without waiting for it: traces already
+ * queued keep the system they were launched with (a ring of 16 staged systems), so a host can queue
+ * set_system / attach_buffers / trace for simulation after simulation and synchronise once at the end. */
 int ort_set_system(ort_ctx *ctx, const ort_system *sys);
 /* Histogram of the `image` light source (reference imgin, src/sourceMod.f90:363-408) as its
  * cumulative sum in the order emit_image scans the cells (:313-321): cdf[0] = 0,
@@ -241,7 +245,9 @@ int ort_trace_paths(ort_ctx *ctx, int phase, int64_t n, uint64_t seed, uint64_t 
 int ort_read(ort_ctx *ctx, int32_t *image, uint64_t *counters);
 /* Use caller-owned DEVICE buffers (e.g. torch tensors: int32[ORT_IMAGE_BINS],
  * int64[ORT_NUM_COUNTERS]) as the accumulators from now on; they are not zeroed
- * and not freed by the context.  NULL, NULL returns to the context's own. */
+ * and not freed by the context.  NULL, NULL returns to the context's own.  Asynchronous: what was traced before
+ * the call is completed in the OLD buffers by work queued on the stream (they must stay valid until the stream
+ * has passed this point); what is traced afterwards lands in the new ones. */
 int ort_attach_buffers(ort_ctx *ctx, void *d_image, void *d_counters);
 /* Sum image and counters over the n contexts of ONE process (one context per device) in place,
  * over RCCL / xGMI: afterwards every context holds the global sums.  The multi-GPU equivalent

@@ -472,6 +472,26 @@ __device__ inline double div_plain(double x, double y)
 template <class T> struct RayT { VecT<T> pos, dir; };
 using Ray = RayT<double>;
 
+// What a surface step may ASSUME (OPT bit mask; 0 = nothing, the generic walk and every entry that takes
+// rays from the caller).  Each bit removes instructions whose result is known in advance; none changes a
+// result (tests: every kernel variant against the lockstep kernel and the oracle, bit for bit).
+//   OPT_UNIT_DIR   the direction is a unit vector up to rounding: it was emitted by `point` / `ring`
+//                  (normalised there) and every surface passed since left I alpha + N beta with
+//                  |I| = |N| = 1 and alpha^2 (1 - c1^2) + ... = 1 (refract: eta^2 (1 - c1^2) + c2^2 = 1 by
+//                  c2^2 = k; reflect: 1 - 4 c1^2 + 4 c1^2), each to a few ulps — true for the fused
+//                  program kernels, whose rays never come from outside.  Then a = dir.dir needs no range
+//                  guard in solve_and_pick, and the NA test of make_image may take dir.z for dir.z / |dir|.
+//   OPT_ON_AXIS    the surface's centre has cx = cy = +0.0 exactly (host: match_program): pos.x - cx and
+//                  pos.y - cy are pos.x and pos.y, bit for bit (x - (+0) = x for every x, -0 included).
+// ORT_DIET (development, A/B builds): mask of the optimisations compiled in; the build uses all of them.
+#ifndef ORT_DIET
+#define ORT_DIET 0xff
+#endif
+constexpr int OPT_UNIT_DIR = (ORT_DIET & 1) ? 1 : 0, OPT_ON_AXIS = (ORT_DIET & 2) ? 2 : 0;
+constexpr bool kDietStatusCarriesStep = (ORT_DIET & 4) != 0;   // program kernels: see surface_step NISK
+constexpr bool kDietDiesOnReflect = (ORT_DIET & 8) != 0;       // reflect_refract DIES
+constexpr bool kDietApertureBounds = (ORT_DIET & 16) != 0;     // outside_aperture on precomputed bounds
+
 // ----------------------------------------------------------------------------
 // Filtered predicates (FILT = true, the production setting).
 //
@@ -541,7 +561,7 @@ template <> struct SysTypes<fastd> { using Sys = ort_system; using Surf = ort_su
 // but fp64 arithmetic lives in the vector unit): formed once per workgroup next to the staged
 // system, by the very operations the per-ray code would use, so nothing changes bit-wise.  Only
 // the filtered path reads them; the literal path recomputes from the surface record.
-template <class T> struct SurfAuxT { T r2, ap2, ap_tol, eta2, ell_sa, ell_sb, rh, rk, r2_tol; };
+template <class T> struct SurfAuxT { T r2, ap2, ap_tol, eta2, ell_sa, ell_sb, rh, rk, r2_tol, ap_lo, ap_hi; };
 template <class T, class Surf>
 __host__ __device__ inline SurfAuxT<T> make_aux(const Surf &s)
 {
@@ -550,6 +570,8 @@ __host__ __device__ inline SurfAuxT<T> make_aux(const Surf &s)
     a.r2 = r * r;                          // intersect_sphere / _cylinder: radius**2
     a.ap2 = A * A;                         // aperture test on the squares
     a.ap_tol = T(1e-12) * a.ap2;
+    a.ap_lo = a.ap2 - a.ap_tol;            // outside_aperture: decided when s2 < ap_lo or s2 > ap_hi
+    a.ap_hi = a.ap2 + a.ap_tol;
     a.eta2 = e * e;                        // refract: eta**2
     a.ell_sa = T(1.) / (r * r);            // intersect_ellipse: 1/semia**2, 1/semib**2 (inf for other kinds: unused)
     a.ell_sb = T(1.) / (rb * rb);
@@ -590,7 +612,7 @@ template <> __device__ inline bool aperture_present<float>(float a)
 //   q < 0 : q/a < 0 ; hit <=> c/q >= 0 <=> c <= 0 -> t = c/q
 // Range guards: on the two operands of the quotient, see `ok`.
 // ----------------------------------------------------------------------------
-template <bool FILT, class T>
+template <bool FILT, class T, bool UNIT = false>
 __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit, bool &rare)
 {
     static_assert(!FILT || sizeof(T) == 8, "filtered predicates are derived for fp64 only");
@@ -616,8 +638,9 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
         // path).  For a lane with real roots also |q| = |hb| + sqrt(D) in (2^-300, 2^300): sqrt(D) <=
         // |q| and D > 2^-640 are inside sqrt_f's range, |c| < 2^701, every quotient in (2^-1000, 2^1000).
         // (tools/check_quadratic.py replays these guards on the CPU over all exponents.)
-        const bool common = (fabs(D) > T(1e-10) * hh) & (fabs(D) < T(0x1p900)) & (a > T(0x1p-100)) & (a < T(0x1p100)) &
-                            (fabs(c) > T(0x1p-300));
+        // UNIT: a = dir.dir = 1 to a few ulps (OPT_UNIT_DIR): its two range tests are vacuous
+        const bool a_ok = UNIT ? true : ((a > T(0x1p-100)) & (a < T(0x1p100)));
+        const bool common = (fabs(D) > T(1e-10) * hh) & (fabs(D) < T(0x1p900)) & a_ok & (fabs(c) > T(0x1p-300));
         const bool ok = common & (neg | ((fabs(q) > T(0x1p-300)) & (fabs(q) < T(0x1p300))));
 #if defined(ORT_ABL_FASTDIV)
         t = ORT_DIV(num, den);
@@ -649,22 +672,23 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
 // one body: the x-axis cylinder is the sphere with the x terms removed
 // (a = dz^2+dy^2 etc. — fp addition commutes, so the sums are bit-identical).
 // r2 = radius**2 (SurfAuxT); the literal path forms it itself.
-template <bool FILT, class T>
+template <bool FILT, class T, int OPT = 0>
 __device__ inline void intersect_quadric(const RayT<T> &r, T cx, T cy, T cz, T radius, T r2,
                                          bool cylinder, bool live, T &t, bool &hit, bool &rare)
 {
-    T Lx = cylinder ? T(0.0) : r.pos.x - cx;
-    T Ly = r.pos.y - cy;
+    constexpr bool axis = (OPT & 2) != 0;                // OPT_ON_AXIS: cx = cy = +0.0
+    T Lx = cylinder ? T(0.0) : (axis ? r.pos.x : r.pos.x - cx);
+    T Ly = axis ? r.pos.y : r.pos.y - cy;
     T Lz = r.pos.z - cz;
     T dx = cylinder ? T(0.0) : r.dir.x;
     T a = (dx * dx) + (r.dir.y * r.dir.y) + (r.dir.z * r.dir.z);
     T hb = (dx * Lx) + (r.dir.y * Ly) + (r.dir.z * Lz);
     T c = ((Lx * Lx) + (Ly * Ly) + (Lz * Lz)) - (FILT ? r2 : radius * radius);
-    solve_and_pick<FILT>(a, hb, c, live, t, hit, rare);
+    solve_and_pick<FILT, T, (OPT & 1) != 0>(a, hb, c, live, t, hit, rare);
 }
 
 // intersect_ellipse, src/surfaces.f90:133-176 (sa, sb = 1/semia**2, 1/semib**2: SurfAuxT)
-template <bool FILT, class T>
+template <bool FILT, class T, int OPT = 0>
 __device__ inline void intersect_ellipse(const RayT<T> &r, T cy, T cz, T semia, T semib, T aux_sa, T aux_sb,
                                          bool live, T &t, bool &hit, bool &rare)
 {
@@ -675,7 +699,7 @@ __device__ inline void intersect_ellipse(const RayT<T> &r, T cy, T cz, T semia, 
     T a = sa * (r.dir.z * r.dir.z) + sb * (r.dir.y * r.dir.y);
     T hb = sa * r.dir.z * Lz + sb * r.dir.y * Ly;
     T c = sa * (Lz * Lz) + sb * (Ly * Ly) - T(1);
-    solve_and_pick<FILT>(a, hb, c, live, t, hit, rare);
+    solve_and_pick<FILT>(a, hb, c, live, t, hit, rare);      // a = sa dz^2 + sb dy^2 is not |dir|^2: guards stay
 }
 
 // fresnel, src/surfaces.f90:336-372, as one expression (eta = n1/n2 rounded once on
@@ -701,9 +725,13 @@ __device__ inline T fresnel(T costt, T n1, T n2, T eta)
 // reciprocals, with refract's own c2 standing in for fresnel's cost2 (the same
 // quantity, rounded along another path; they differ by < 1e-13 once k > 1e-6) and with
 // refract's eta c1 - c2 as the first numerator.  |R' - R| < 1e-12, the margin is 1e-10.
-template <bool FILT, bool KEEP, class T>
+// DIES: a reflected ray ends at this surface (ORT_F_SKIP_ON_REFLECT) and the caller reads nothing of an
+// ended ray's state (KEEP = false): only the refracted direction is formed — alpha = eta as it stands, beta
+// one sign select — and a reflecting lane leaves with garbage in I.
+template <bool FILT, bool KEEP, class T, bool DIES = false>
 __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta, T eta2, T u, bool live, bool &rare)
 {
+    static_assert(!DIES || !KEEP, "DIES leaves garbage in reflecting lanes");
     const T c1s = vdot(N, I);                            // == vdot(I, N): the products commute
     const T c1 = fabs(c1s);                              // costt (fresnel) and |c1| (refract)
     // refract's radicand, refract's order (:327); eta2 = eta**2 (SurfAuxT)
@@ -741,8 +769,9 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
     //   reflect (:297)      I - (2 c1s) N         = I*1   + N*(-(2 c1s))     (x*1 and a + (-b) are exact)
     //   refract (:320-329)  eta I + (eta c1 - c2) Nt,  Nt = N or -N  = I*eta + N*(+-(eta c1 - c2))
     // so the two scalars are selected, not the six components.
-    const T alpha = reflected ? T(1.) : eta;
-    const T beta = reflected ? -(T(2.) * c1s) : ((c1s < T(0.)) ? m : -m);
+    const T mm = (c1s < T(0.)) ? m : -m;
+    const T alpha = DIES ? eta : (reflected ? T(1.) : eta);
+    const T beta = DIES ? mm : (reflected ? -(T(2.) * c1s) : mm);
     const VecT<T> out = vadd(vscale(I, alpha), vscale(N, beta));
     I = KEEP ? vselect(live, out, I) : out;
     return reflected;
@@ -751,10 +780,17 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
 // aperture test `sqrt(x^2+y^2) > A` (lens.f90:450-454, :576-580, :559-563): decided on
 // the squares unless they agree to 1e-12 (then the reference's square root is taken)
 template <bool FILT, class T>
-__device__ inline bool outside_aperture(T x, T y, T A, T A2, T A2tol, bool live, bool &rare)
+__device__ inline bool outside_aperture(T x, T y, T A, T A2, T A2tol, T A2lo, T A2hi, bool live, bool &rare)
 {
     const T s2 = x * x + y * y;
     if constexpr (FILT) {                               // A2 = A*A, A2tol = 1e-12 A2 (SurfAuxT)
+        if constexpr (kDietApertureBounds) {
+            // the same margin as two bounds formed once per surface: A2lo = A2 - A2tol, A2hi = A2 + A2tol
+            // (SurfAuxT); inside [A2lo, A2hi], or NaN: the reference's square root decides
+            const bool out = s2 > A2hi;
+            ORT_RARE(4, live & !out & !(s2 < A2lo));
+            return out;
+        }
         ORT_RARE(4, live & !(fabs(s2 - A2) > A2tol));
         return s2 > A2;
     } else {
@@ -1243,14 +1279,17 @@ __device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64
 // reference's).  NaN / x > 1 fall through as accepted, exactly as
 // `if(angle > na) return` does with a NaN angle.  Returns the ORT_ST_* status.
 // ----------------------------------------------------------------------------
-template <bool FILT, class T, class Sys>
+template <bool FILT, class T, bool UNIT = false, class Sys>
 __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int &xp, int &yp, bool &rare)
 {
     bool reject;
     T fx, fy;
     if constexpr (FILT) {
-        // x = dir_z / |dir| up to 1e-13; the literal form below rounds it five more times
-        const T xa = r.dir.z * rsq_approx(vdot(r.dir, r.dir));
+        // x = dir_z / |dir| up to 1e-13; the literal form below rounds it five more times.
+        // UNIT (OPT_UNIT_DIR): |dir| = 1 to a few ulps, so dir_z itself is x to 1e-14 (margin 1e-10)
+        T xa;
+        if constexpr (UNIT) xa = r.dir.z;
+        else xa = r.dir.z * rsq_approx(vdot(r.dir, r.dir));
         reject = xa < T(S.na_cos_min);
         // floor(x / binwid) from one multiply.  |q| > 1e3: off the +-200 grid whatever the rounding.
         // Otherwise the product and the quotient differ by < 1e3 * 4.4e-16, so floor agrees unless q
@@ -1280,6 +1319,10 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
     return reject ? ORT_ST_NA_REJECT : (off ? ORT_ST_OFF_GRID : ORT_ST_BINNED);
 }
 
+// status word of the program kernels (surface_step NISK): ORT_ST_* in the low byte, intersections above
+__device__ inline int status_code(int st) { return st & 0xff; }
+__device__ inline int status_isect(int st) { return st >> 8; }
+
 // ----------------------------------------------------------------------------
 // One surface of the staged list for every lane of the wave.  `st` < 0 marks a
 // live ray; a ray that ends here gets its final ORT_ST_* status.  nis counts
@@ -1302,18 +1345,24 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
 // rays that miss the aperture stop — a third of the point rays at the doublet's first face — then
 // leave the wavefront BEFORE the normalisation and the Fresnel arithmetic, not after.  1 then 2 is
 // the whole step, operation for operation.
+// NISK >= 0 (surface programs): this is step NISK - 1 of the program, so a ray that ends here has evaluated
+// exactly NISK intersections: instead of counting per lane and step (`nis` is left alone), the status of a
+// ray that ends carries the count, st = ORT_ST_* | NISK << 8 (status_code / status_isect split it).
+// OPT: what the step may assume (OPT_*).
 template <bool FILT, class T, bool EXT, bool KEEP = true, int KIND = -1, int FLAGS = -1, int HASAP = -1, int DK = -1, bool FRESH = false,
-          int PART = 0, class Sys, class Surf, class D>
+          int PART = 0, int NISK = -1, int OPT = 0, class Sys, class Surf, class D>
 __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<T> &ax, RayT<T> &r, D &draws,
                                     int &nis, int &st, int &xp, int &yp, bool &rare)
 {
+    constexpr int tag = NISK >= 0 ? (NISK << 8) : 0;
+    constexpr bool DIES = kDietDiesOnReflect && !KEEP && FLAGS >= 0 && (FLAGS & ORT_F_SKIP_ON_REFLECT) != 0;
     static_assert(PART == 0 || (!EXT && !KEEP && KIND >= 0 && KIND != ORT_SURF_IMAGE && KIND != ORT_SURF_IRIS),
                   "half steps exist for the refracting steps of the surface programs");
     const bool live = st < 0;
     const int kind = KIND >= 0 ? KIND : __builtin_amdgcn_readfirstlane(s.kind);
     const unsigned flags = FLAGS >= 0 ? (unsigned)FLAGS : (unsigned)__builtin_amdgcn_readfirstlane((int)s.flags);
     const bool has_ap = HASAP >= 0 ? (HASAP != 0) : aperture_present<T>(s.aperture);   // aperture >= 0
-    const int lost = (flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE;
+    const int lost = ((flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE) | tag;
     if constexpr (PART == 2) {
         // second half: every lane with st < 0 is on the surface (pos = the crossing point) and goes on
         VecT<T> N2;
@@ -1326,12 +1375,12 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
             N2 = {T(0.), T(0.), T(-1.)};
         }
         const T u2 = draws.template at<T, DK, FRESH>();
-        const bool reflected2 = reflect_refract<FILT, KEEP, T>(r.dir, N2, s.n1, s.n2, s.eta, ax.eta2, u2, live, rare);
+        const bool reflected2 = reflect_refract<FILT, KEEP, T, DIES>(r.dir, N2, s.n1, s.n2, s.eta, ax.eta2, u2, live, rare);
         const bool dies2 = reflected2 && (flags & ORT_F_SKIP_ON_REFLECT);
         st = (live & dies2) ? lost : st;
         return;
     }
-    nis += live ? 1 : 0;
+    if constexpr (NISK < 0) nis += live ? 1 : 0;
     VecT<T> N;
     bool proceed;                    // lanes that reach the Fresnel decision at this surface
     int code = lost;                 // status of a lane that ends at this surface
@@ -1340,7 +1389,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         bool hit;
         const bool cyl = kind != ORT_SURF_SPHERE;
         if (kind == ORT_SURF_ELLIPSE) intersect_ellipse<FILT, T>(r, s.cy, s.cz, s.radius, s.radius_b, ax.ell_sa, ax.ell_sb, live, t, hit, rare);
-        else intersect_quadric<FILT, T>(r, s.cx, s.cy, s.cz, s.radius, ax.r2, cyl, live, t, hit, rare);
+        else intersect_quadric<FILT, T, (KIND == ORT_SURF_SPHERE ? OPT : (OPT & ~2))>(r, s.cx, s.cy, s.cz, s.radius, ax.r2, cyl, live, t, hit, rare);
         int walk_end = -1;
         if (EXT && (flags & ORT_F_SCATTER)) {               // wave-uniform
             scatter_walk<T>(s, S.twopi, r, t, live && hit && !rare, draws, nis, walk_end);
@@ -1349,7 +1398,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         const VecT<T> moved = vadd(r.pos, vscale(r.dir, t));
         r.pos = KEEP ? vselect(live && hit, moved, r.pos) : moved;
         bool out = false;
-        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, ax.ap2, ax.ap_tol, live && hit, rare);
+        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, ax.ap2, ax.ap_tol, ax.ap_lo, ax.ap_hi, live && hit, rare);
         // normal = centre - pos, with orig%x = centre%x for the bottle (lens.f90:288-290)
         if constexpr (PART != 1) {
             const VecT<T> Nraw = {cyl ? T(0.0) : s.cx - moved.x, s.cy - moved.y, s.cz - moved.z};
@@ -1358,7 +1407,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         }
         // a lane that ends here: missed (Help3 where the reference aborts), outside the aperture,
         // reflected (all: `lost`), or ended inside the scattering walk
-        if (flags & ORT_F_MISS_IS_HELP3) code = hit ? lost : ORT_ST_HELP3;
+        if (flags & ORT_F_MISS_IS_HELP3) code = hit ? lost : (ORT_ST_HELP3 | tag);
         if (EXT) code = walk_end >= 0 ? walk_end : code;
         proceed = live && hit && !out;
     } else {
@@ -1367,12 +1416,12 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         const VecT<T> moved = vadd(r.pos, vscale(r.dir, d));
         if (kind == ORT_SURF_IMAGE) {
             r.pos = KEEP ? vselect(live, moved, r.pos) : moved;
-            const int ist = make_image<FILT, T>(S, r, live, xp, yp, rare);
+            const int ist = make_image<FILT, T, (OPT & OPT_UNIT_DIR) != 0>(S, r, live, xp, yp, rare) | tag;
             st = live ? ist : st;
             return;
         }
         bool out = false;
-        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, ax.ap2, ax.ap_tol, live, rare);
+        if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, ax.ap2, ax.ap_tol, ax.ap_lo, ax.ap_hi, live, rare);
         if (kind == ORT_SURF_IRIS) {
             if (KEEP) r.pos = vselect(live && out, moved, r.pos);   // pos = origpos unless lost (lens.f90:564, :643)
             st = (live && out) ? lost : st;
@@ -1393,7 +1442,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         u = draws.template peek_as<T>();
         draws.advance(proceed);
     }
-    const bool reflected = reflect_refract<FILT, KEEP, T>(r.dir, N, s.n1, s.n2, s.eta, ax.eta2, u, proceed, rare);
+    const bool reflected = reflect_refract<FILT, KEEP, T, DIES>(r.dir, N, s.n1, s.n2, s.eta, ax.eta2, u, proceed, rare);
     const bool dies = reflected && (flags & ORT_F_SKIP_ON_REFLECT);
     st = live ? ((proceed & !dies) ? -1 : code) : st;
 }

@@ -288,6 +288,7 @@ __device__ inline SurfAuxT<T> load_aux(typename ConstPtrs<T>::aux_t p)
     a.r2 = T(p->r2); a.ap2 = T(p->ap2); a.ap_tol = T(p->ap_tol); a.eta2 = T(p->eta2);
     a.ell_sa = T(p->ell_sa); a.ell_sb = T(p->ell_sb);
     a.rh = T(p->rh); a.rk = T(p->rk); a.r2_tol = T(p->r2_tol);
+    a.ap_lo = T(p->ap_lo); a.ap_hi = T(p->ap_hi);
     return a;
 }
 
@@ -397,7 +398,11 @@ template <int P> constexpr int draw_index(int K)
 
 // steps [K, K1) of program P, each entered only while some lane of the wave is alive.  FRESH: no
 // hash is at hand for the next odd draw (the walk starts behind the queue)
-template <bool FILT, class T, bool KEEP, int P, int K, int K1, bool FRESH, class Sys, class D>
+// OPT: what every step may assume (ort_device.h OPT_*); a step's status carries its intersection count
+// (surface_step NISK) when kDietStatusCarriesStep
+template <int K> constexpr int nisk() { return kDietStatusCarriesStep ? K + 1 : -1; }
+
+template <bool FILT, class T, bool KEEP, int P, int K, int K1, bool FRESH, int OPT, class Sys, class D>
 __device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t surf, typename ConstPtrs<T>::aux_t aux, RayT<T> &r, D &draws,
                                   int &nis, int &st, int &xp, int &yp, bool &rare)
 {
@@ -413,26 +418,26 @@ __device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t su
                 // a refracting step with an aperture stop, in halves (surface_step PART): when the stop
                 // ends every ray of the wavefront — the doublet's first face does that to 9 of 10
                 // wavefronts of the ring loop — the normalisation and the Fresnel arithmetic are skipped
-                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 1>(
+                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 1, nisk<K>(), OPT>(
                     S, s, ax, r, draws, nis, st, xp, yp, rare);
                 if (wave_any(st < 0))
-                    surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 2>(
+                    surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 2, nisk<K>(), OPT>(
                         S, s, ax, r, draws, nis, st, xp, yp, rare);
             } else {
-                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH>(
+                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 0, nisk<K>(), OPT>(
                     S, s, ax, r, draws, nis, st, xp, yp, rare);
             }
 #ifdef ORT_ISA_MARKERS
             asm volatile("; ORT_STEP_END %0" ::"n"(K));
 #endif
-            walk_fixed<FILT, T, KEEP, P, K + 1, K1, FRESH && !draws_here>(S, surf, aux, r, draws, nis, st, xp, yp, rare);
+            walk_fixed<FILT, T, KEEP, P, K + 1, K1, FRESH && !draws_here, OPT>(S, surf, aux, r, draws, nis, st, xp, yp, rare);
         }
     }
 }
 
 // one half (PART 1 / 2, ort_device.h: surface_step) of step K of program P: the step the queue point
 // of trace_queue_kernel sits in
-template <bool FILT, class T, int P, int K, int PART, class Sys, class D>
+template <bool FILT, class T, int P, int K, int PART, int OPT, class Sys, class D>
 __device__ inline void step_part(const Sys &S, typename ConstPtrs<T>::surf_t surf, typename ConstPtrs<T>::aux_t aux, RayT<T> &r, D &draws,
                                  int &nis, int &st, int &xp, int &yp, bool &rare)
 {
@@ -442,7 +447,7 @@ __device__ inline void step_part(const Sys &S, typename ConstPtrs<T>::surf_t sur
 #ifdef ORT_ISA_MARKERS
         if (PART == 1) asm volatile("; ORT_STEP_BEGIN %0" ::"n"(K));
 #endif
-        surface_step<FILT, T, false, false, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), PART == 2, PART>(
+        surface_step<FILT, T, false, false, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), PART == 2, PART, nisk<K>(), OPT>(
             S, s, ax, r, draws, nis, st, xp, yp, rare);
 #ifdef ORT_ISA_MARKERS
         if (PART == 2) asm volatile("; ORT_STEP_END %0" ::"n"(K));
@@ -721,8 +726,14 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     uint64_t lo = (head ? 0 : a.head_rays) + wid * chunk; if (lo > end) lo = end;
     uint64_t hi = lo + chunk;  if (hi > end) hi = end;
 
+    // what the steps of a program kernel may assume (ort_device.h): fused rays have unit directions (they
+    // were emitted here), the lens spheres of every program are centred on the axis (host: matches<P>)
+    constexpr int OPT = fixed ? ((MODE == MODE_FUSED ? OPT_UNIT_DIR : 0) | OPT_ON_AXIS) : 0;
+    constexpr bool tagged = fixed && kDietStatusCarriesStep;     // st = ORT_ST_* | intersections << 8
     unsigned int lost = 0, isect = 0, binned = 0, help3 = 0, culled = 0;
-    auto finish = [&](int st, int nis, int xp, int yp) {
+    auto finish = [&](int st_in, int nis_in, int xp, int yp) {
+        const int st = tagged ? status_code(st_in) : st_in;
+        const int nis = tagged ? status_isect(st_in) : nis_in;
         isect += (unsigned)nis;
         if (st == ORT_ST_BINNED) {
             binned++;
@@ -768,8 +779,8 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             bool rare = false;
             if constexpr (fixed) {
                 // the queue point lies INSIDE step split - 1, behind its aperture test (step_part)
-                step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 2>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-                walk_fixed<FILT, T, false, PROG, queue_step<PROG, MODE>(), Prog<PROG>::n, false>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 2, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                walk_fixed<FILT, T, false, PROG, queue_step<PROG, MODE>(), Prog<PROG>::n, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
             } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
                 if (FILT && rare) defer(fixed ? (uint64_t)dw : d.ray_of_packed(dw, a.rng_base) - a.first_ray);
@@ -810,8 +821,8 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 st = est < 0 ? st : est;
             }
             if constexpr (fixed) {
-                walk_fixed<FILT, T, false, PROG, 0, queue_step<PROG, MODE>() - 1, false>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-                step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 1>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                walk_fixed<FILT, T, false, PROG, 0, queue_step<PROG, MODE>() - 1, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 1, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
             } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
             const bool deferred = FILT && rare && act;
             const bool survive = act && st < 0 && !deferred;
@@ -855,7 +866,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 const bool cand = act && !dies;
                 const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
                 if (cand) cq[(chead + ccount + lane_prefix(mask)) & (kQueueCap - 1)] = (uint32_t)i;
-                else if (act) { finish(ORT_ST_LOST_TELESCOPE, 1, 0, 0); culled++; }
+                else if (act) { finish(ORT_ST_LOST_TELESCOPE | (tagged ? 1 << 8 : 0), 1, 0, 0); culled++; }
                 ccount += __popcll(mask);
             }
             __builtin_amdgcn_wave_barrier();
@@ -990,11 +1001,20 @@ int check_system(const ort_system *sys)
 
 }  // namespace
 
+// Staged systems live in a ring of kSysSlots device slots fed from pinned host slots: ort_set_system copies
+// asynchronously into the NEXT slot and later launches read that one, so a sweep can queue system after
+// system without ever waiting for the stream (launches already queued keep reading the slot they were given).
+constexpr int kSysSlots = 16;
+
 struct ort_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
-    DevSystem *d_sys;
+    DevSystem *d_sys;            // the current slot of d_sys_ring
+    DevSystem *d_sys_ring, *h_sys_ring;          // kSysSlots each; h_: pinned staging
+    int sys_slot;
+    hipEvent_t sys_ev[kSysSlots];                // recorded when a slot stops being current: its readers precede it
+    bool sys_ev_set[kSysSlots];
     int32_t *d_image, *own_image;
     int32_t *d_replicas;         // kReplicas x 2 layers x kSlots: hits not yet folded into the image
     bool fold_pending[2];        // per layer: the replicas hold hits (fold_kernel runs when the image is needed)
@@ -1038,6 +1058,8 @@ static bool matches(const ort_system *sys)
         if (s.kind != Prog<P>::kind[k] || (int)(s.flags & ~ORT_F_TRACK) != Prog<P>::flags[k] ||
             (s.aperture >= 0.0) != (Prog<P>::ap[k] != 0))
             return false;
+        // OPT_ON_AXIS: the program kernels take pos.x - cx, pos.y - cy of a sphere for pos.x, pos.y
+        if (s.kind == ORT_SURF_SPHERE && !(s.cx == 0.0 && s.cy == 0.0 && !std::signbit(s.cx) && !std::signbit(s.cy))) return false;
     }
     return true;
 }
@@ -1082,18 +1104,28 @@ static void note_system(ort_ctx *c, const ort_system *sys)
     ring_cull_threshold(sys, c->prog[0] != PROG_GENERIC, &c->ring_cull, &c->ring_cullf);
 }
 
-// system + derived per-surface constants -> device (synchronises: the staging copy is a local)
-static int upload_system(ort_ctx *c, const ort_system *sys)
+// system + derived per-surface constants -> the next device slot, asynchronously (the staging copy is the
+// slot's own pinned host buffer).  A slot is reused kSysSlots systems later; by then the event recorded when it
+// was retired has normally long passed.
+static int upload_system(ort_ctx *c, const ort_system *sys, bool first = false)
 {
-    DevSystem h;
+    int slot = 0;
+    if (!first) {
+        HIP_TRY(hipEventRecord(c->sys_ev[c->sys_slot], c->stream));
+        c->sys_ev_set[c->sys_slot] = true;
+        slot = (c->sys_slot + 1) % kSysSlots;
+        if (c->sys_ev_set[slot]) HIP_TRY(hipEventSynchronize(c->sys_ev[slot]));
+    }
+    DevSystem &h = c->h_sys_ring[slot];
     h.sys = *sys;
     for (int p = 0; p < 2; ++p)
         for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.aux[p][k] = make_aux<double>(sys->surfaces[p][k]);
     convert_system(h.sysf, *sys);
     for (int p = 0; p < 2; ++p)
         for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.auxf[p][k] = make_aux<float>(h.sysf.surfaces[p][k]);
+    c->sys_slot = slot;
+    c->d_sys = c->d_sys_ring + slot;
     HIP_TRY(hipMemcpyAsync(c->d_sys, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     return ORT_OK;
 }
 
@@ -1180,7 +1212,9 @@ int ort_device_count(int *count)
 // everything of ort_create that can fail after the context exists (the caller destroys it on failure)
 static int create_on_device(ort_ctx *c, const ort_system *sys)
 {
-    HIP_TRY(hipMalloc(&c->d_sys, sizeof(DevSystem)));
+    HIP_TRY(hipMalloc(&c->d_sys_ring, kSysSlots * sizeof(DevSystem)));
+    HIP_TRY(hipHostMalloc(&c->h_sys_ring, kSysSlots * sizeof(DevSystem), hipHostMallocDefault));
+    for (int k = 0; k < kSysSlots; ++k) HIP_TRY(hipEventCreateWithFlags(&c->sys_ev[k], hipEventDisableTiming));
     HIP_TRY(hipMalloc(&c->own_image, ORT_IMAGE_BINS * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->own_counters, ORT_NUM_COUNTERS * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&c->d_replicas, kReplicas * kReplicaInts * sizeof(int32_t)));
@@ -1200,7 +1234,7 @@ static int create_on_device(ort_ctx *c, const ort_system *sys)
         HIP_TRY(hipEventCreate(&c->ring[k][1]));
     }
     note_system(c, sys);
-    const int rc = upload_system(c, sys);
+    const int rc = upload_system(c, sys, true);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->d_image, 0, ORT_IMAGE_BINS * sizeof(int32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, ORT_NUM_COUNTERS * sizeof(unsigned long long), c->stream));
@@ -1250,7 +1284,8 @@ int ort_destroy(ort_ctx *c)
         for (int j = 0; j < 2; ++j) if (c->ev[k][j]) (void)hipEventDestroy(c->ev[k][j]);
     for (int k = 0; k < kTimingRing; ++k)
         for (int j = 0; j < 2; ++j) if (c->ring[k][j]) (void)hipEventDestroy(c->ring[k][j]);
-    (void)hipFree(c->d_sys); (void)hipFree(c->own_image); (void)hipFree(c->own_counters); (void)hipFree(c->d_replicas); (void)hipFree(c->d_img_cdf);
+    for (int k = 0; k < kSysSlots; ++k) if (c->sys_ev[k]) (void)hipEventDestroy(c->sys_ev[k]);
+    (void)hipFree(c->d_sys_ring); (void)hipHostFree(c->h_sys_ring); (void)hipFree(c->own_image); (void)hipFree(c->own_counters); (void)hipFree(c->d_replicas); (void)hipFree(c->d_img_cdf);
     (void)hipFree(c->d_redo_list); (void)hipFree(c->d_redo_ctl); (void)hipFree(c->d_work);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1622,7 +1657,6 @@ int ort_attach_buffers(ort_ctx *c, void *d_image, void *d_counters)
         return fail(ORT_E_INVALID, "attach both buffers or neither");
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = flush_replicas(c); if (rc) return rc; }     // pending hits belong to the old accumulators
-    HIP_TRY(hipStreamSynchronize(c->stream));
     c->d_image = d_image ? (int32_t *)d_image : c->own_image;
     c->d_counters = d_counters ? (unsigned long long *)d_counters : c->own_counters;
     return ORT_OK;

@@ -5,8 +5,10 @@
 Same flags, same loops, same settings defaults and the same `data/<folder>/` outputs as
 runner.py (`-s` :113-133, `-p` :136-155, `-b` :209-228, `-i` :158-186, `-o` :189-208, `-l` :232-261,
 and `iSORS_vs_Bessel` :267-320, which runner.py defines but wires to no flag: `--isors` here);
-every simulation is one `run_settings` call on ONE reused GPU context instead of one
-`./install.sh -n 32 -f <settings>` process (runner.py:26-47).  `-b` needs the Bessel image
+the simulations of an experiment are QUEUED on one reused GPU context — system re-staged asynchronously,
+one device array of images for the whole batch, one wait and one copy back at the end (RayTracer.run_many)
+— instead of one `./install.sh -n 32 -f <settings>` process each (runner.py:26-47); `--one-by-one` runs
+them one `run_settings` call at a time (same files, bit for bit).  `-b` needs the Bessel image
 `bessel-smear.dat` (bpm.py's output, not shipped by the reference) in the res directory and fails
 with a clear message without it.
 """
@@ -18,7 +20,7 @@ import sys
 from typing import Dict, Iterable, List, Optional, Tuple
 
 from .params import Settings, resource_dir
-from .tracer import RayTracer, RunResult, run_settings
+from .tracer import RayTracer, RunResult, run_settings, write_outputs
 
 # runner.py:371-372 / :384-385
 BOTTLES = [("clearBottle-large.params", True), ("clearBottle-small.params", True),
@@ -31,35 +33,77 @@ L3_FOCALS = ["40.0", "45.0", "50.0", "60.0", "75.0"]       # runner.py:251
 OFFSETS_MM = list(range(4, 17, 2))                         # runner.py:200
 
 
+def _experiment(fn):
+    """An experiment queues its simulations and ends with the batch run."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        try:
+            return fn(self, *a, **k)
+        finally:
+            self.flush()
+    return wrapped
+
+
 class Sweep:
+    MAX_BATCH = 128        # simulations per device array: 128 x 1.29 MB of images
+
     def __init__(self, nphotons: int = 1_000_000_000, res_dir: Optional[str] = None,
                  data_dir: str = "data", device: int = 0, verbose: bool = False,
-                 settings_dir: Optional[str] = None):
+                 settings_dir: Optional[str] = None, batched: bool = True):
         self.nphotons, self.res_dir, self.data_dir = nphotons, res_dir or resource_dir(), data_dir
         self.device, self.verbose, self.settings_dir = device, verbose, settings_dir
+        self.batched = batched
         self.tracer: Optional[RayTracer] = None
         self.results: List[Tuple[str, Settings, RunResult]] = []
+        self._pending: List[Tuple[str, Settings]] = []
 
     def close(self) -> None:
+        self.flush()
         if self.tracer is not None:
             self.tracer.close()
             self.tracer = None
 
-    def run(self, name: str, **over) -> RunResult:
-        """make_settings + run_sim of runner.py for one parameter set."""
+    def _tracer_for(self, s: Settings) -> RayTracer:
+        if self.tracer is None:
+            from .system import OpticalSystem
+            self.tracer = RayTracer(OpticalSystem.from_settings(s, self.res_dir), device=self.device)
+        return self.tracer
+
+    def run(self, name: str, **over) -> Optional[RunResult]:
+        """make_settings + run_sim of runner.py for one parameter set.  Batched: the simulation is queued and
+        runs at the next flush() (every experiment ends with one); its result then appears in `results`."""
         s = Settings(nphotons=self.nphotons, **over)
         s.validate()
         if self.settings_dir:                              # runner.py:106-110: keep the settings text
             os.makedirs(self.settings_dir, exist_ok=True)
             s.write(os.path.join(self.settings_dir, name))
-        if self.tracer is None:
-            from .system import OpticalSystem
-            self.tracer = RayTracer(OpticalSystem.from_settings(s, self.res_dir), device=self.device)
-        res = run_settings(s, self.res_dir, self.data_dir, self.device, self.verbose, self.tracer)
-        self.results.append((name, s, res))
-        return res
+        # the tracker dumps ray paths through the synchronous per-ray entry: such a simulation runs on its own
+        if not self.batched or s.use_tracker:
+            self.flush()
+            res = run_settings(s, self.res_dir, self.data_dir, self.device, self.verbose, self._tracer_for(s))
+            self.results.append((name, s, res))
+            return res
+        self._pending.append((name, s))
+        if len(self._pending) >= self.MAX_BATCH:
+            self.flush()
+        return None
+
+    def flush(self) -> None:
+        """Run the queued simulations as one batch, then leave each one's files, in queue order."""
+        if not self._pending:
+            return
+        from .system import OpticalSystem
+        pending, self._pending = self._pending, []
+        systems = [OpticalSystem.from_settings(s, self.res_dir) for _, s in pending]
+        results = self._tracer_for(pending[0][1]).run_many(systems)
+        for (name, s), system, res in zip(pending, systems, results):
+            write_outputs(system, res, self.data_dir, self.verbose)
+            self.results.append((name, s, res))
 
     # ---- runner.py experiments -------------------------------------------------
+    @_experiment
     def spot_diagrams(self, bottles=BOTTLES) -> None:      # -s, runner.py:113-133
         for i, (bottle, use) in enumerate(bottles):
             keep, self.nphotons = self.nphotons, 100
@@ -69,11 +113,13 @@ class Sweep:
             finally:
                 self.nphotons = keep
 
+    @_experiment
     def point_images(self, bottles=BOTTLES) -> None:       # -p, runner.py:136-155
         for i, (bottle, use) in enumerate(bottles):
             self.run(f"test_{i}.params", light_source="point", make_images=True,
                      bottle_file=bottle, use_bottle=use, data_folder="images")
 
+    @_experiment
     def bessel_images(self, bottles=BOTTLES) -> None:      # -b, runner.py:209-228
         from .params import ParamsError
         src = os.path.join(self.res_dir, Settings().image_source)
@@ -84,6 +130,7 @@ class Sweep:
             self.run(f"test_{i}.params", light_source="image", make_images=True,
                      bottle_file=bottle, use_bottle=use, data_folder="images")
 
+    @_experiment
     def isors_vs_bessel(self) -> None:                     # iSORS_vs_Bessel, runner.py:267-320
         """isors source against the point source with the bottle moved so that the Bessel ring has
         the same spatial offset; 7 offsets 0 ... 1.5 mm each."""
@@ -126,6 +173,7 @@ class Sweep:
             f.write("\n".join(lines) + "\n")
         return path
 
+    @_experiment
     def iris_experiment(self, bottles=BOTTLES) -> None:    # -i, runner.py:158-186
         for i, (bottle, use) in enumerate(bottles):
             for iris in IRISES:
@@ -136,6 +184,7 @@ class Sweep:
                     if iris == "none":
                         break                              # one size is enough without an iris (:184-186)
 
+    @_experiment
     def offset_experiment(self) -> None:                   # -o, runner.py:189-208
         # runner.py asks for -4 ... -16 mm, but res/ only ships files down to -14 mm: the
         # reference's own sweep dies on its 7th simulation (open status="old").  Here the
@@ -148,6 +197,7 @@ class Sweep:
             self.run(f"test_{i}.params", light_source="point", make_images=True,
                      bottle_file=f"clearBottle-large_-{off}mm.params", data_folder="images-offset")
 
+    @_experiment
     def lens_experiment(self, bottles=LENS_BOTTLES) -> None:   # -l, runner.py:232-261
         for k, f3 in enumerate(L3_FOCALS):
             for j, f2 in enumerate(L2_FOCALS):
@@ -173,9 +223,10 @@ def main(argv: Optional[Iterable[str]] = None) -> int:
     ap.add_argument("--data-dir", default="data")
     ap.add_argument("--res-dir", default=None)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--one-by-one", action="store_true", help="one simulation at a time (default: queued in batches)")
     args = ap.parse_args(argv)
     sw = Sweep(args.nphotons, args.res_dir, args.data_dir, args.device, verbose=True,
-               settings_dir=os.path.join(args.data_dir, "settings"))
+               settings_dir=os.path.join(args.data_dir, "settings"), batched=not args.one_by_one)
     from .params import ParamsError
     try:
         if args.bessel or args.all:

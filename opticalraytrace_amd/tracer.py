@@ -160,6 +160,38 @@ class RayTracer(ShardedRun):
         n = self.system.settings.nphotons if nphotons is None else nphotons
         return super().run(n, seed, phases)
 
+    def run_many(self, systems, seed: int = DEFAULT_SEED, phases=(1, 2)):
+        """A batch of simulations (a sweep: runner.py starts one process per settings file, :26-47) queued
+        back to back on this context: per simulation the system is re-staged (asynchronously, ort_set_system),
+        the accumulators are pointed at that simulation's slice of ONE device array
+        [n_sim][2][401][401] (+ [n_sim][8] counters) and both loops are launched; the host waits once, at the
+        end, and copies everything back in one pass.  Returns one RunResult per system, each bit-identical to
+        `set_system(s); run()` done one at a time."""
+        torch = self.torch
+        n = len(systems)
+        if n == 0:
+            return []
+        images = torch.zeros((n, 2, IMAGE_N, IMAGE_N), dtype=torch.int32, device=self.device)
+        counters = torch.zeros((n, NUM_COUNTERS), dtype=torch.int64, device=self.device)
+        try:
+            for i, system in enumerate(systems):
+                self.set_system(system)
+                self.ctx.attach_buffers(images[i].data_ptr(), counters[i].data_ptr())
+                lo, cnt = shard_range(system.settings.nphotons, self.rank, self.world)
+                for phase in phases:
+                    self.ctx.trace(phase, lo, cnt, seed)
+        finally:
+            # back to the tracer's own accumulators: completes the last simulation's slice (stream-ordered)
+            self.ctx.attach_buffers(self.image.data_ptr(), self.counters.data_ptr())
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(images, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=self.group)
+        self._synchronize()
+        h_img = images.cpu().numpy()
+        h_cnt = counters.cpu().numpy().astype(np.uint64)
+        return [RunResult(h_img[i], h_cnt[i], s.settings.nphotons) for i, s in enumerate(systems)]
+
 
 # ---------------------------------------------------------------------------
 # output side of the boundary: src/main.f90:45-48, :168-185; src/imageMod.f90:93-114
@@ -270,13 +302,22 @@ def run_settings(settings: Settings, res_dir: Optional[str] = None, data_dir: st
     finally:
         if own:
             tracer.close()
+    write_outputs(system, res, data_dir, verbose)
+    return res
+
+
+def write_outputs(system: OpticalSystem, res: RunResult, data_dir: str = "data", verbose: bool = True) -> None:
+    """What `program raytrace` leaves behind for one simulation (src/main.f90:168-185): the stats row, the
+    two transmission lines, the three image files."""
+    settings = system.settings
+    folder = os.path.join(data_dir, settings.data_folder)
+    os.makedirs(folder, exist_ok=True)                      # setupMod.f90:124-131
     append_stats(folder, system, res)
     if verbose:                                             # main.f90:180-181
         print(f"Ring  transmitted:  {res.ring_transmitted:8.2f}%")
         print(f"Point transmitted:  {res.point_transmitted:8.2f}%")
     if settings.make_images and not settings.use_tracker:   # main.f90:183-185; the tracker
         write_images(res.image, os.path.join(folder, output_basename(system) + "_image"))   # deselects images (setupMod.f90:76-82)
-    return res
 
 
 def run_settings_file(settings_path: str, res_dir: Optional[str] = None, data_dir: str = "data",

@@ -48,6 +48,22 @@ def physical_cores(cpus):
     return len(cores) or len(cpus)
 
 
+def cpu_quota():
+    """CPU time this process's cgroup may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None: a
+    container can show 128 schedulable CPUs and still be capped at a share of them."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def run_once(kind: str, rays: int, phase: int, threads: int, repeats: int, bind: bool = False):
     """The timings of one thread count in a fresh process (the OpenMP team size is fixed at first use)."""
     import subprocess
@@ -81,20 +97,25 @@ def worker(kind: str, rays: int, phase: int, repeats: int):
         ref = Reference(s, resource_dir())
         ref.trace(phase, 0, warm, seed)
         times = []
+        c0 = time.process_time()
         for _ in range(repeats):
             t0 = time.perf_counter()
             ref.trace(phase, 0, rays, seed)
             times.append(time.perf_counter() - t0)
+        cpu = time.process_time() - c0
         _, c = orc.trace(phase, 0, rays, seed)              # untimed: the oracle counts the intersections
     else:
         orc.trace(phase, 0, warm, seed)
         times = []
+        c0 = time.process_time()
         for _ in range(repeats):
             t0 = time.perf_counter()
             _, c = orc.trace(phase, 0, rays, seed)
             times.append(time.perf_counter() - t0)
-    times.sort()
-    print(json.dumps({"seconds": times[len(times) // 2], "all_seconds": times, "intersections": int(c[2 + phase - 1])}))
+        cpu = time.process_time() - c0
+    # CPU seconds of all threads per second of wall time over the timed loops = the cores the OS really gave
+    print(json.dumps({"seconds": sorted(times)[len(times) // 2], "all_seconds": sorted(times), "cores_delivered": cpu / sum(times),
+                      "intersections": int(c[2 + phase - 1])}))
 
 
 def main():
@@ -124,13 +145,15 @@ def main():
         pass
     # thread counts tried: one per physical core, and every hardware thread, each unbound and bound to
     # cores; the best is reported.  Plus one thread on a sample scaled down by the core count.
-    tried = sorted({n_cores, n_threads})
+    quota = cpu_quota()
+    tried = sorted({n_cores, n_threads} | ({max(1, int(round(quota)))} if quota and quota < n_cores else set()))
     one_rays = max(200_000, args.rays // max(n_cores, 1))
     sweep = {}
     kinds = [kind] if kind == "port" else ["reference", "port"]
 
     def entry(r, t, rays, bind):
         return {"threads": t, "bind": "close/cores" if bind else "none", "rays": rays, "seconds": r["seconds"],
+                "cores_delivered": r["cores_delivered"],
                 "all_seconds": r["all_seconds"], "value": r["intersections"] / r["seconds"], "rays_per_s": rays / r["seconds"]}
 
     for k in kinds:
@@ -156,7 +179,7 @@ def main():
     best_t = best["threads"]
 
     def efficiency(k, key):
-        occupied = min(n_cores, sweep[key]["threads"])
+        occupied = min(n_cores, sweep[key]["threads"], quota or n_cores)   # cores' worth of CPU time the run could use
         return sweep[key]["value"] / (occupied * sweep[f"{k}@1"]["value"])
 
     extra = {}
@@ -171,9 +194,12 @@ def main():
         "value": best["value"], "unit": "intersections/s",
         "cores": min(n_cores, best_t),                      # physical cores the best run occupied
         "threads": best_t, "bind": best["bind"], "physical_cores_available": n_cores, "hardware_threads_available": n_threads,
+        "cgroup_cpu_quota_cores": quota,                    # None: uncapped
+        "cores_delivered": best["cores_delivered"],         # CPU seconds of all threads / wall second in the best run
         "kind": kind,
         "one_thread_value": sweep[f"{kind}@1"]["value"],
-        # best / (physical cores occupied x the one-thread figure): what the OpenMP loop of src/main.f90:83-89 with its
+        # best / (cores' worth of CPU time available x the one-thread figure); available = min(physical cores occupied,
+        # cgroup CPU quota): what the OpenMP loop of src/main.f90:83-89 with its
         # atomic image update (src/imageMod.f90:55) keeps of one core's rate at this thread count
         "parallel_efficiency": efficiency(kind, best_key),
         "sample": f"{args.rays} rays of phase {args.phase} (BASELINE configs[1] system, seed 123456789), "

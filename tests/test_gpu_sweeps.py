@@ -143,3 +143,32 @@ def test_isors_keyed_rays_vs_oracle(hip_library):
     orc.trace(1, 0, n, SEED, wimg, wc); orc.trace(2, 0, n, SEED, wimg, wc)
     assert np.abs(img.astype(np.int64) - wimg).sum() <= 6
     assert np.abs(cnt.astype(np.int64) - wc.astype(np.int64)).max() <= 3
+
+
+def test_batched_sweep_equals_one_by_one(hip_library, tmp_path):
+    """SURVEY f1's design point: the lens experiment's 75 systems queued as ONE batch (ort_set_system staged
+    asynchronously through the library's ring of 16 system slots — the batch is longer than the ring —, every
+    simulation binning into its own slice of one [75][2][401][401] device array, one wait, one copy back)
+    against the same 75 run one at a time: images, counters and the files they leave, identical."""
+    from opticalraytrace_amd.sweeps import Sweep
+    n = 60_000
+    out = {}
+    for mode, batched in (("batched", True), ("single", False)):
+        sw = Sweep(nphotons=n, data_dir=str(tmp_path / mode), batched=batched)
+        try:
+            sw.lens_experiment()
+            sw.iris_experiment(bottles=[("clearBottle-small.params", True)])     # images written (make_images)
+        finally:
+            sw.close()
+        out[mode] = sw.results
+    assert len(out["batched"]) == len(out["single"]) == 75 + 11
+    for (na, sa, ra), (nb, sb, rb) in zip(out["batched"], out["single"]):
+        assert na == nb and sa == sb
+        assert np.array_equal(ra.image, rb.image), na
+        assert np.array_equal(ra.counters, rb.counters), na
+    assert len({r.image.tobytes() for _, _, r in out["batched"]}) > 60          # the systems really differ
+    for folder in ("images-lens", "iris"):
+        a, b = tmp_path / "batched" / folder, tmp_path / "single" / folder
+        assert sorted(os.listdir(a)) == sorted(os.listdir(b))
+        for f in os.listdir(a):
+            assert open(a / f, "rb").read() == open(b / f, "rb").read(), f
