@@ -619,7 +619,8 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
     if constexpr (FILT) {
         const T hh = hb * hb;
         const T D = hh - a * c;
-        const bool neg = D < T(0.0);                  // :243 — no real root
+        const bool nneg = !(D < T(0.0));              // :243 — D < 0: no real root (one compare serves `ok` and `hit`)
+        const bool neg = !nneg;
         bool unused = false;
         const T sq = sqrt_f<true, T>(D, false, unused);   // range: see `ok`; NaN when neg (misses)
         const bool bpos = hb > T(0.0);
@@ -648,7 +649,7 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
         if constexpr (std::is_same<T, double>::value) t = div_plain(num, den);
         else t = ORT_DIV(num, den);
 #endif
-        hit = (qpos || cneg) && !neg;
+        hit = (qpos || cneg) && nneg;
         ORT_RARE(2, live & !ok);                     // tangent, degenerate, on the surface, out of range, or NaN
     } else {
         const T b = T(2.0) * hb;
@@ -758,10 +759,20 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
         // `sint2 > 1` (:353) holds whatever its rounding and it returns 1: u <= 1 reflects.
         // (diff is NaN there and is not consulted.)  NaN anywhere else -> undecided; c1 >= 1 and
         // k within 1e-6 of zero -> literal path.
+        if constexpr ((ORT_DIET & 32) != 0) {
+            // The same decisions in four compares instead of five.  With c1 < 1 and |k| > 1e-6: k > 0 makes c2,
+            // P, rhs and diff finite numbers; k < 0 makes c2 = sqrt(k) NaN and with it diff.  So "diff is NaN"
+            // IS total reflection there, and the two tests on diff are written so that a NaN takes the
+            // reflecting side: decided unless |diff| <= margin (unordered: decided), reflected unless diff >= 0.
+            const bool decided = (c1 < T(1.0)) & (fabs(k) > T(1e-6)) & !(fabs(diff) <= T(1e-10) * P);
+            reflected = !(diff >= T(0.0));
+            ORT_RARE(3, live & !decided);
+        } else {
         const bool tir = k < T(-1e-6);
         const bool decided = (c1 < T(1.0)) & (tir | ((k > T(1e-6)) & (fabs(diff) > T(1e-10) * P)));
         reflected = tir | (diff < T(0.0));
         ORT_RARE(3, live & !decided);
+        }
     } else {
         reflected = u <= fresnel(c1, n1, n2, eta);       // :275
     }
@@ -1246,9 +1257,21 @@ __device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r
 // ANYSRC = false instantiates only the two default emitters (ring for phase 1, point for phase
 // 2): the bulk kernels are compiled once for that case so that the rarely used emitters do not
 // cost registers (143 vs 121 VGPRs, i.e. 3 vs 4 waves per SIMD) on the path that is benchmarked.
-template <class T, bool ANYSRC, bool FILT = false, class Sys, class D>
+// EMITTER >= 0 (surface programs): the emitter is the compile-time constant ORT_EMIT_* of the program.
+template <class T, bool ANYSRC, bool FILT = false, int EMITTER = -1, class Sys, class D>
 __device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf, bool &rare)
 {
+    if constexpr (EMITTER >= 0) {
+        bool unused = false;                              // the emitters other than ring / point are literal throughout
+        if constexpr (EMITTER == ORT_EMIT_RING) emit_ring<T, FILT>(S, r, draws, rare);
+        else if constexpr (EMITTER == ORT_EMIT_POINT) emit_point<T, FILT>(S, r, draws, rare);
+        else if constexpr (EMITTER == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray);
+        else if constexpr (EMITTER == ORT_EMIT_CRS) emit_crs<T>(S, r, draws);
+        else if constexpr (EMITTER == ORT_EMIT_ISORS) return emit_isors<T>(S, r, draws) ? -1 : ORT_ST_NO_INTERSECTION;
+        else return emit_image<T>(S, cdf, r, draws, ray) ? -1 : ORT_ST_LOST_TELESCOPE;
+        (void)unused;
+        return -1;
+    }
     if (!ANYSRC) {
         if (phase == 1) emit_ring<T, FILT>(S, r, draws, rare);
         else emit_point<T, FILT>(S, r, draws, rare);
@@ -1374,7 +1397,13 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         } else {
             N2 = {T(0.), T(0.), T(-1.)};
         }
-        const T u2 = draws.template at<T, DK, FRESH>();
+        T u2;
+        if constexpr (DK >= 0) {
+            u2 = draws.template at<T, DK, FRESH>();
+        } else {
+            u2 = draws.template peek_as<T>();
+            draws.advance(live);
+        }
         const bool reflected2 = reflect_refract<FILT, KEEP, T, DIES>(r.dir, N2, s.n1, s.n2, s.eta, ax.eta2, u2, live, rare);
         const bool dies2 = reflected2 && (flags & ORT_F_SKIP_ON_REFLECT);
         st = (live & dies2) ? lost : st;

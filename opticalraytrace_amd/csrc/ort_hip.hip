@@ -299,10 +299,13 @@ __device__ inline SurfAuxT<T> load_aux(typename ConstPtrs<T>::aux_t p)
 // back to back: -8 % kernel time.  The host selects a program only when the staged system
 // matches it field for field (match_program); everything else runs the generic walk.
 enum { PROG_GENERIC = 0, PROG_POINT, PROG_RING, PROG_POINT_IRIS_B, PROG_POINT_IRIS_A, PROG_RING_IRIS_B, PROG_RING_IRIS_A,
-       PROG_POINT_BARE, PROG_POINT_ELLIPSE };
-// every program but the generic one: X(name)
+       PROG_POINT_BARE, PROG_POINT_ELLIPSE, PROG_CRS, PROG_ISORS, PROG_IMAGE };
+// every program of the default emitters (ring / point): X(name) — instantiated fused and resident, in every arithmetic
 #define ORT_PROGRAMS(X) X(PROG_POINT) X(PROG_RING) X(PROG_POINT_IRIS_B) X(PROG_POINT_IRIS_A) X(PROG_RING_IRIS_B) X(PROG_RING_IRIS_A) \
     X(PROG_POINT_BARE) X(PROG_POINT_ELLIPSE)
+// the default surface lists behind the other bulk light sources (runner.py's crs / iSORS / Bessel-image experiments):
+// fused, exact fp64 only; everything else of those sources (iris variants, resident bundles, fp32) runs the generic walk
+#define ORT_SOURCE_PROGRAMS(X) X(PROG_CRS) X(PROG_ISORS) X(PROG_IMAGE)
 
 namespace prog {
 constexpr int CYL = ORT_SURF_CYLINDER, ELL = ORT_SURF_ELLIPSE, PLN = ORT_SURF_PLANE, SPH = ORT_SURF_SPHERE, IRS = ORT_SURF_IRIS, IMG = ORT_SURF_IMAGE;
@@ -312,6 +315,7 @@ template <int P> struct Prog;
 // point loop, src/main.f90:127-162: bottle (2 cylinders), plano-convex (flat, curved), doublet (3 faces), image
 template <> struct Prog<PROG_POINT> {
     static constexpr int phase = 2, n = 8, split = 5;
+    static constexpr int emitter = ORT_EMIT_POINT;
     static constexpr int kind[n] = {prog::CYL, prog::CYL, prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
     static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
     static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 0};
@@ -319,6 +323,7 @@ template <> struct Prog<PROG_POINT> {
 // ring loop, src/main.f90:90-109: plano-convex, doublet, image
 template <> struct Prog<PROG_RING> {
     static constexpr int phase = 1, n = 6, split = 1;
+    static constexpr int emitter = ORT_EMIT_RING;
     static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
     static constexpr int flags[n] = {0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
     static constexpr int ap[n] = {1, 0, 1, 0, 0, 0};
@@ -326,12 +331,14 @@ template <> struct Prog<PROG_RING> {
 // the same with the iris in front of the doublet (src/lens.f90:551-565) ...
 template <> struct Prog<PROG_POINT_IRIS_B> {
     static constexpr int phase = 2, n = 9, split = 6;
+    static constexpr int emitter = ORT_EMIT_POINT;
     static constexpr int kind[n] = {prog::CYL, prog::CYL, prog::PLN, prog::SPH, prog::IRS, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
     static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, 0, prog::SK, prog::SK, prog::H3, 0};
     static constexpr int ap[n] = {0, 0, 1, 0, 1, 1, 0, 0, 0};
 };
 template <> struct Prog<PROG_RING_IRIS_B> {
     static constexpr int phase = 1, n = 7, split = 1;
+    static constexpr int emitter = ORT_EMIT_RING;
     static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::IRS, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
     static constexpr int flags[n] = {0, prog::SK, 0, prog::SK, prog::SK, prog::H3, 0};
     static constexpr int ap[n] = {1, 0, 1, 1, 0, 0, 0};
@@ -339,12 +346,14 @@ template <> struct Prog<PROG_RING_IRIS_B> {
 // ... and behind it (src/lens.f90:632-644)
 template <> struct Prog<PROG_POINT_IRIS_A> {
     static constexpr int phase = 2, n = 9, split = 5;
+    static constexpr int emitter = ORT_EMIT_POINT;
     static constexpr int kind[n] = {prog::CYL, prog::CYL, prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IRS, prog::IMG};
     static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, prog::SK, prog::SK, prog::H3, 0, 0};
     static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 1, 0};
 };
 template <> struct Prog<PROG_RING_IRIS_A> {
     static constexpr int phase = 1, n = 7, split = 1;
+    static constexpr int emitter = ORT_EMIT_RING;
     static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IRS, prog::IMG};
     static constexpr int flags[n] = {0, prog::SK, prog::SK, prog::SK, prog::H3, 0, 0};
     static constexpr int ap[n] = {1, 0, 1, 0, 0, 1, 0};
@@ -353,6 +362,7 @@ template <> struct Prog<PROG_RING_IRIS_A> {
 // the point loop without the bottle (use_bottle = false, src/main.f90:147)
 template <> struct Prog<PROG_POINT_BARE> {
     static constexpr int phase = 2, n = 6, split = 3;
+    static constexpr int emitter = ORT_EMIT_POINT;
     static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
     static constexpr int flags[n] = {0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
     static constexpr int ap[n] = {1, 0, 1, 0, 0, 0};
@@ -361,15 +371,35 @@ template <> struct Prog<PROG_POINT_BARE> {
 // the point loop through an elliptical bottle (src/lens.f90:221-225)
 template <> struct Prog<PROG_POINT_ELLIPSE> {
     static constexpr int phase = 2, n = 8, split = 5;
+    static constexpr int emitter = ORT_EMIT_POINT;
     static constexpr int kind[n] = {prog::ELL, prog::ELL, prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
     static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
     static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 0};
 };
 
-template <int P> constexpr bool prog_is_ring()
+// the default lists behind the crs source (point_on_bottle, src/sourceMod.f90:50-89, src/main.f90:99), the isors source
+// (iSORS, :162-247, main.f90:97) and the image source (emit_image, :303-361, main.f90:133)
+template <> struct Prog<PROG_CRS> : Prog<PROG_RING> { static constexpr int emitter = ORT_EMIT_CRS; };
+template <> struct Prog<PROG_ISORS> : Prog<PROG_RING> { static constexpr int emitter = ORT_EMIT_ISORS; };
+template <> struct Prog<PROG_IMAGE> : Prog<PROG_POINT> { static constexpr int emitter = ORT_EMIT_IMAGE; };
+
+template <int P> constexpr bool prog_is_ring()             // phase-1 list (plano-convex first)
 {
     if constexpr (P == PROG_GENERIC) return false;
     else return Prog<P>::phase == 1;
+}
+// segment 0 (the cull by the third draw) belongs to the ring EMITTER
+template <int P> constexpr bool prog_culls()
+{
+    if constexpr (P == PROG_GENERIC) return false;
+    else return Prog<P>::phase == 1 && Prog<P>::emitter == ORT_EMIT_RING;
+}
+// does every ray reach step K at the same draw index?  ring (4 draws), point (2), image (4): yes; crs and isors
+// draw a variable number (polar Box-Muller, src/random_mod.f90:59-85): their steps count draws per lane
+template <int P> constexpr bool prog_static_draws()
+{
+    if constexpr (P == PROG_GENERIC) return false;
+    else return Prog<P>::emitter == ORT_EMIT_RING || Prog<P>::emitter == ORT_EMIT_POINT || Prog<P>::emitter == ORT_EMIT_IMAGE;
 }
 // the step the queue point of trace_queue_kernel lies in, + 1.  Prog<P>::split (the host's choice for
 // the list: behind the stop that removes most rays) — except in the fused ring programs: their
@@ -390,7 +420,8 @@ template <int P, int MODE> constexpr int queue_step()
 // plane draw nothing)
 template <int P> constexpr int draw_index(int K)
 {
-    int d = Prog<P>::phase == 1 ? 4 : 2;
+    if (!prog_static_draws<P>()) return -1;              // surface_step DK < 0: per-lane draw counter
+    int d = Prog<P>::emitter == ORT_EMIT_POINT ? 2 : 4;
     for (int j = 0; j < K; ++j)
         if (Prog<P>::kind[j] != ORT_SURF_IRIS && Prog<P>::kind[j] != ORT_SURF_IMAGE) d++;
     return d;
@@ -662,12 +693,13 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     // 26.6 KB per workgroup of a program kernel in fp64 (6 workgroups per CU's 160 KB), 14 KB in fp32
     constexpr bool fixed = PROG != PROG_GENERIC;        // surface program known at compile time
     using QT = typename std::conditional<std::is_same<T, float>::value, float, double>::type;
-    using QD = typename std::conditional<fixed, uint32_t, uint64_t>::type;   // program: the ray's index in the launch
+    constexpr bool sdraws = prog_static_draws<PROG>();  // every lane at the same, compile-time draw index (ProgDraws)
+    using QD = typename std::conditional<sdraws, uint32_t, uint64_t>::type;  // static draws: the ray's index in the launch
     __shared__ QT Q[kWavesPerBlock][kQueueFields][kQueueCap];
     __shared__ QD QDRAW[kWavesPerBlock][kQueueCap];
     // ring programs, fused: segment 0 (below) culls the rays that are certain to miss the first aperture
     // before anything is emitted; the others wait here (ray index in the launch) for a full wave
-    constexpr bool PRE = prog_is_ring<PROG>() && MODE == MODE_FUSED;
+    constexpr bool PRE = prog_culls<PROG>() && MODE == MODE_FUSED;
     __shared__ uint32_t CQ[kWavesPerBlock][PRE ? kQueueCap : 1];
     // intersections evaluated before the queue point: `split` for every survivor unless a surface
     // scatters (extended instantiation), so only that one carries the count through the queue
@@ -689,7 +721,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     QD *qd = QDRAW[wave];
     uint32_t *cq = CQ[wave];
     int *qn = QN[wave];
-    using DrawsT = typename std::conditional<fixed, ProgDraws, KeyedDraws>::type;
+    using DrawsT = typename std::conditional<sdraws, ProgDraws, KeyedDraws>::type;
     int phase = a.phase, ns, split;
     if constexpr (fixed) {
         phase = Prog<PROG>::phase; ns = Prog<PROG>::n; split = queue_step<PROG, MODE>();   // host: match_program
@@ -774,7 +806,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 dw = qd[slot];
                 nis = SCAT ? qn[slot] : split;
             }
-            if constexpr (fixed) d.init_index(z0, dw, 0);
+            if constexpr (sdraws) d.init_index(z0, dw, 0);
             else d.unpack(dw, a.rng_base);
             bool rare = false;
             if constexpr (fixed) {
@@ -783,7 +815,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 walk_fixed<FILT, T, false, PROG, queue_step<PROG, MODE>(), Prog<PROG>::n, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
             } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
-                if (FILT && rare) defer(fixed ? (uint64_t)dw : d.ray_of_packed(dw, a.rng_base) - a.first_ray);
+                if (FILT && rare) defer(sdraws ? (uint64_t)dw : d.ray_of_packed(dw, a.rng_base) - a.first_ray);
                 else finish(st, nis, xp, yp);
             }
             __builtin_amdgcn_wave_barrier();
@@ -808,15 +840,15 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
             bool rare = false;
             if (MODE == MODE_RESIDENT) {
-                if constexpr (fixed) d.init_index(z0, (uint32_t)ic, a.draw_base);
+                if constexpr (sdraws) d.init_index(z0, (uint32_t)ic, a.draw_base);
                 else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
                 r.pos = {T(a.pos_dir_in[0 * ns_in + ic]), T(a.pos_dir_in[1 * ns_in + ic]), T(a.pos_dir_in[2 * ns_in + ic])};
                 r.dir = {T(a.pos_dir_in[3 * ns_in + ic]), T(a.pos_dir_in[4 * ns_in + ic]), T(a.pos_dir_in[5 * ns_in + ic])};
             } else {
-                if constexpr (fixed) d.init_index(z0, (uint32_t)ic, 0);
+                if constexpr (sdraws) d.init_index(z0, (uint32_t)ic, 0);
                 else d.init_keyed(a.rng_base, a.first_ray + ic, 0);
                 int est;
-                if constexpr (fixed) est = emit<T, ANYSRC, FILT && !ANYSRC>(*csys, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
+                if constexpr (fixed) est = emit<T, false, FILT, Prog<PROG>::emitter>(*csys, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
                 else est = emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
                 st = est < 0 ? st : est;
             }
@@ -831,7 +863,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 const int slot = (qhead + qcount + lane_prefix(mask)) & (kQueueCap - 1);
                 q[0][slot] = (QT)r.pos.x; q[1][slot] = (QT)r.pos.y; q[2][slot] = (QT)r.pos.z;
                 q[3][slot] = (QT)r.dir.x; q[4][slot] = (QT)r.dir.y; q[5][slot] = (QT)r.dir.z;
-                if constexpr (fixed) qd[slot] = (uint32_t)i;
+                if constexpr (sdraws) qd[slot] = (uint32_t)i;
                 else qd[slot] = d.pack();
                 if (SCAT) qn[slot] = nis;
             } else if (deferred) {
@@ -1052,7 +1084,7 @@ static bool matches(const ort_system *sys)
 {
     const int p = Prog<P>::phase - 1;
     if (sys->n_surfaces[p] != Prog<P>::n || sys->split[p] != Prog<P>::split) return false;
-    if (sys->emitter[p] != (p == 0 ? ORT_EMIT_RING : ORT_EMIT_POINT)) return false;
+    if (sys->emitter[p] != Prog<P>::emitter) return false;
     for (int k = 0; k < Prog<P>::n; ++k) {
         const ort_surface &s = sys->surfaces[p][k];
         if (s.kind != Prog<P>::kind[k] || (int)(s.flags & ~ORT_F_TRACK) != Prog<P>::flags[k] ||
@@ -1099,9 +1131,10 @@ static void note_system(ort_ctx *c, const ort_system *sys)
     c->prog[0] = c->prog[1] = PROG_GENERIC;
 #define ORT_MATCH(P) if (matches<P>(sys)) c->prog[Prog<P>::phase - 1] = P;
     ORT_PROGRAMS(ORT_MATCH)
+    ORT_SOURCE_PROGRAMS(ORT_MATCH)
 #undef ORT_MATCH
     if (getenv("ORT_NO_PROGRAMS")) c->prog[0] = c->prog[1] = PROG_GENERIC;      // development knob (A/B)
-    ring_cull_threshold(sys, c->prog[0] != PROG_GENERIC, &c->ring_cull, &c->ring_cullf);
+    ring_cull_threshold(sys, c->prog[0] != PROG_GENERIC && sys->emitter[0] == ORT_EMIT_RING, &c->ring_cull, &c->ring_cullf);
 }
 
 // system + derived per-surface constants -> the next device slot, asynchronously (the staging copy is the
@@ -1364,6 +1397,13 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
     } else if (mode == MODE_DEBUG) {
         if (filt) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, double, true>));
         else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, double, true>));
+    } else if (anysrc && filt && queued && mode == MODE_FUSED && !scat && c->prog[a.phase - 1] >= PROG_CRS) {
+        // the other bulk light sources in front of a default surface list: their own program kernels
+        switch (c->prog[a.phase - 1]) {
+#define ORT_CASE(P) case P: ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, double, P>)); break;
+            ORT_SOURCE_PROGRAMS(ORT_CASE)
+#undef ORT_CASE
+        }
     } else if (anysrc || !filt || !queued) {
         // alternate emitters and the A/B variants share the generic instantiations
         if (mode == MODE_FUSED) {
