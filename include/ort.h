@@ -300,8 +300,9 @@ int ort_set_precision(ort_ctx *ctx, int precision);
  * bin straight into the image, clear (default) = bin into 8 private replicas folded into the
  * image after the launch; bit 3 set = the ring loop emits every ray, clear (default) = ring rays
  * whose third draw already puts them outside the first aperture are counted without being emitted
- * (queued surface-program kernels).  All combinations produce bit-identical rays, images and
- * counters.  Default 1. */
+ * (queued surface-program kernels); bit 4 set = scattering bottles run the monolithic kernel (the random walk
+ * compiled into the surface walk), clear (default) = the scattering pipeline (walk stages on full wavefronts in
+ * front of the lean walk).  All combinations produce bit-identical rays, images and counters.  Default 1. */
 int ort_set_kernel_variant(ort_ctx *ctx, int variant);
 
 #ifdef __cplusplus

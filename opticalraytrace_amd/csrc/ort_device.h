@@ -1377,7 +1377,7 @@ template <bool FILT, class T, bool EXT, bool KEEP = true, int KIND = -1, int FLA
 __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<T> &ax, RayT<T> &r, D &draws,
                                     int &nis, int &st, int &xp, int &yp, bool &rare)
 {
-    constexpr int tag = NISK >= 0 ? (NISK << 8) : 0;
+    constexpr int tag = (NISK >= 0 ? NISK : 0) << 8;
     constexpr bool DIES = kDietDiesOnReflect && !KEEP && FLAGS >= 0 && (FLAGS & ORT_F_SKIP_ON_REFLECT) != 0;
     static_assert(PART == 0 || (!EXT && !KEEP && KIND >= 0 && KIND != ORT_SURF_IMAGE && KIND != ORT_SURF_IRIS),
                   "half steps exist for the refracting steps of the surface programs");

@@ -64,7 +64,7 @@ constexpr int kMaxBlocks = 256 * 12;    // grid cap of the lockstep kernels and 
 constexpr uint64_t kChunkRays = ORT_MAX_RAYS_PER_LAUNCH;   // rays per launch of the queued kernel (bounds the re-run list: 4 B per ray)
 constexpr int kRedoBlocks = 128;        // grid of the literal re-run kernel (it normally finds an empty list and returns)
 
-enum { MODE_FUSED = 0, MODE_RESIDENT = 1, MODE_DEBUG = 2 };
+enum { MODE_FUSED = 0, MODE_RESIDENT = 1, MODE_DEBUG = 2, MODE_CONTINUE = 3 };
 
 struct TraceArgs {
     const ort_system *sys;       // device copy (DevSystem.sys)
@@ -101,6 +101,16 @@ struct TraceArgs {
     // debug outputs (any may be null)
     double *pos_dir_out, *emitted_out;
     int32_t *status, *bin_xy, *n_isect, *n_draws;
+    // scattering pipeline (scatter_front_kernel -> trace_queue_kernel<MODE_CONTINUE>): the rays that leave the
+    // scattering surfaces alive: state SoA [6][cont_cap], keyed draw counter (ray << 24) + draws consumed
+    // (kNoRay: the slot holds no ray), intersections evaluated so far.  A wave of the front kernel fills the slots
+    // of its own ray range from the bottom and marks the rest empty: no shared counter (one returning atomic per
+    // hand-over on ONE address serialised the whole kernel: 1.4 ms per 4e6 rays, 73 % of the wave cycles waiting)
+    double *cont_pos_dir;
+    uint64_t *cont_draw;
+    int32_t *cont_nis;
+    uint64_t cont_cap;
+    int cont_k0;                 // first surface of the continuation (= last scattering surface + 1)
     const long long *img_cdf;    // image-source table or null
     double *path;                // [n][ORT_MAX_PATH][3] or null (tracker)
     int32_t *npath;
@@ -674,6 +684,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
 // order are exactly those of the lockstep kernel, so results are bit-identical.
 // With filtered predicates the kernel holds no literal formula at all: see `defer` below.
 // ---------------------------------------------------------------------------
+constexpr uint64_t kNoRay = ~0ull;   // hand-over bundle of the scattering pipeline: a slot without a ray
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kQueueCap = 128;      // >= 63 leftover + 64 new survivors
 constexpr int kQueueFields = 6;     // px py pz dx dy dz (+ the draw state: its own array)
@@ -703,7 +714,8 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     __shared__ uint32_t CQ[kWavesPerBlock][PRE ? kQueueCap : 1];
     // intersections evaluated before the queue point: `split` for every survivor unless a surface
     // scatters (extended instantiation), so only that one carries the count through the queue
-    __shared__ int QN[kWavesPerBlock][SCAT ? kQueueCap : 1];
+    constexpr bool CARRY = SCAT || MODE == MODE_CONTINUE;     // the count differs from ray to ray at the queue point
+    __shared__ int QN[kWavesPerBlock][CARRY ? kQueueCap : 1];
     __shared__ unsigned int blk[5];       // lost, isect, binned, help3, culled
     __shared__ SurfAuxT<T> AUX[PROG == PROG_GENERIC ? ORT_MAX_SURFACES : 1];
     // a program kernel reads everything it needs of the system (surface records, emitter and image
@@ -746,8 +758,11 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
         caux = (typename ConstPtrs<T>::aux_t)a.aux;
     }
     int32_t *layer = hist_layer(a);
+    // MODE_CONTINUE: the slots of the hand-over bundle, one per ray of the launch, some of them empty
     const uint64_t n = a.n_rays;
-    const uint64_t ns_in = a.in_stride;
+    const uint64_t ns_in = MODE == MODE_CONTINUE ? a.cont_cap : a.in_stride;
+    const int k0 = MODE == MODE_CONTINUE ? a.cont_k0 : 0;     // first surface walked here
+    if (MODE == MODE_CONTINUE && split <= k0) split = ns;     // no queue point behind the start: one segment
 
     // contiguous, 64-aligned range of ray indices for this wave: long ranges for the workgroups of
     // the first rounds, short ones for the last workgroups (plan_ranges), so that the chip drains evenly
@@ -804,7 +819,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
                 r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
                 dw = qd[slot];
-                nis = SCAT ? qn[slot] : split;
+                nis = CARRY ? qn[slot] : split;
             }
             if constexpr (sdraws) d.init_index(z0, dw, 0);
             else d.unpack(dw, a.rng_base);
@@ -839,7 +854,17 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             DrawsT d;
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
             bool rare = false;
-            if (MODE == MODE_RESIDENT) {
+            uint64_t ridx = i;                           // the ray's index in the launch (what a deferral lists)
+            if constexpr (MODE == MODE_CONTINUE) {
+                const uint64_t c0 = a.cont_draw[ic];
+                act = act && c0 != kNoRay;
+                st = act ? -1 : ORT_ST_NA_REJECT;
+                d.unpack(c0, a.rng_base);
+                ridx = (c0 >> 24) - a.first_ray;
+                nis = a.cont_nis[ic];
+                r.pos = {T(a.cont_pos_dir[0 * ns_in + ic]), T(a.cont_pos_dir[1 * ns_in + ic]), T(a.cont_pos_dir[2 * ns_in + ic])};
+                r.dir = {T(a.cont_pos_dir[3 * ns_in + ic]), T(a.cont_pos_dir[4 * ns_in + ic]), T(a.cont_pos_dir[5 * ns_in + ic])};
+            } else if (MODE == MODE_RESIDENT) {
                 if constexpr (sdraws) d.init_index(z0, (uint32_t)ic, a.draw_base);
                 else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
                 r.pos = {T(a.pos_dir_in[0 * ns_in + ic]), T(a.pos_dir_in[1 * ns_in + ic]), T(a.pos_dir_in[2 * ns_in + ic])};
@@ -855,7 +880,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             if constexpr (fixed) {
                 walk_fixed<FILT, T, false, PROG, 0, queue_step<PROG, MODE>() - 1, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
                 step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 1, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-            } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, 0, split, r, d, nis, st, xp, yp, rare);
+            } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, k0, split, r, d, nis, st, xp, yp, rare);
             const bool deferred = FILT && rare && act;
             const bool survive = act && st < 0 && !deferred;
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(survive);
@@ -865,9 +890,9 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 q[3][slot] = (QT)r.dir.x; q[4][slot] = (QT)r.dir.y; q[5][slot] = (QT)r.dir.z;
                 if constexpr (sdraws) qd[slot] = (uint32_t)i;
                 else qd[slot] = d.pack();
-                if (SCAT) qn[slot] = nis;
+                if (CARRY) qn[slot] = nis;
             } else if (deferred) {
-                defer(i);
+                defer(ridx);
             } else if (act) {
                 finish(st, nis, xp, yp);
             }
@@ -913,6 +938,235 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     if (threadIdx.x < 4 && blk[threadIdx.x])
         atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
     if (PRE && threadIdx.x == 4 && blk[4]) atomicAdd(&a.work[ORT_W_CULLED], (unsigned long long)blk[4]);
+}
+
+
+// ---------------------------------------------------------------------------
+// In-bottle scattering (src/lens.f90:262-282, :312-333, src/surfaces.f90:13-50,
+// src/stokes.f90:7-166) as its own kernel in front of the lean walk.
+//
+// The random walk is a loop of unknown length per ray around ~800 instructions of log / atan2 / acos /
+// sin / cos; compiled INTO the surface walk it costs every lane of every step 200+ VGPRs (2 waves per SIMD)
+// and runs in lockstep until the last of 64 rays has left its walk (lanes busy: ~20 %).  Here the surfaces up to
+// the last scattering one (the bottle's two walls) are cut into three stages, each run on FULL wavefronts fed
+// from wave-private LDS queues — the scheme of trace_queue_kernel with a cycle in it:
+//   E  64 fresh rays: emit, ENTER surface 0
+//   W  64 walking rays: one scattering event (move, absorb?, stokes, next leg by tauint); a ray that goes on
+//      walking returns to the walk queue, one that reaches the wall (or leaves the cylinder) goes to the arrival queue
+//   A  64 arrived rays: the rest of the surface step (back test, move, normal, Fresnel), then ENTER the next
+//      surface, or — behind the last scattering surface — hand the ray over
+//   ENTER surface k: intersect; if the medium in front of it scatters, the first leg (tauint)
+// Rays that survive are appended to the hand-over bundle in HBM (state, keyed draw counter, intersections so far)
+// and trace_queue_kernel<MODE_CONTINUE> walks the remaining surfaces at its own register budget.  Every
+// operation of a ray is the one the monolithic kernel (and the lockstep kernel) performs, in the same order with
+// the same draws — literal predicates throughout, nothing is deferred here — so rays, images and counters are
+// bit-identical to theirs (tests: the pipeline against the lockstep kernel; both against the oracle).
+// One wavefront per workgroup: the two queues take 17 KB of LDS per wave (7 waves per CU; the kernel's 171 VGPRs
+// allow 8).
+// ---------------------------------------------------------------------------
+constexpr int kSQCap = 128;        // at most 128 rays in flight per wave: stage E runs only while <= 64 are (a power of two)
+struct ScatQueue {
+    double f[7][kSQCap];           // px py pz dx dy dz t (length of the next leg)
+    uint64_t c[kSQCap];            // keyed draw counter
+    uint32_t m[kSQCap];            // intersections so far << 8 | surface index
+};
+
+// ENTER surface k (per lane) for the lanes `on`: src/lens.f90:255-261 / :303-311 up to the first tauint
+__device__ inline void scat_enter(const ort_surface *surf, int k, int kind0, bool on, const Ray &r, KeyedDraws &d,
+                                  int &nis, double &t, bool &walking, bool &arrived, int &ended)
+{
+    const ort_surface &s = surf[k];
+    nis += on ? 1 : 0;
+    double tt;
+    bool hit, unused = false;
+    if (kind0 == ORT_SURF_ELLIPSE) intersect_ellipse<false, double>(r, s.cy, s.cz, s.radius, s.radius_b, 0., 0., on, tt, hit, unused);
+    else intersect_quadric<false, double>(r, s.cx, s.cy, s.cz, s.radius, 0., true, on, tt, hit, unused);
+    const unsigned flags = s.flags;
+    const int lost = (flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE;
+    ended = (on && !hit) ? ((flags & ORT_F_MISS_IS_HELP3) ? ORT_ST_HELP3 : lost) : ended;
+    const bool go = on && hit;
+    const bool scat = (flags & ORT_F_SCATTER) != 0;
+    double dist;
+    bool at_wall, ok;
+    tauint<double>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, go && scat, d, dist, at_wall, ok, nis);
+    ended = (go && scat && !ok) ? ORT_ST_NO_INTERSECTION : ended;
+    t = go ? (scat ? dist : tt) : t;
+    const bool alive = go && (!scat || ok);
+    walking = alive && scat && !at_wall;
+    arrived = alive && !walking;
+}
+
+// ANYSRC = false: the point source only (the default of the loop the bottle belongs to, src/main.f90:136)
+template <bool ANYSRC>
+__global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
+{
+    __shared__ ort_system S;
+    __shared__ ScatQueue WQ, AQ;
+    __shared__ unsigned int blk[4];
+    stage_system(S, a.sys);
+    if (threadIdx.x < 4) blk[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const int ph = a.phase - 1;
+    const ort_surface *surf = S.surfaces[ph];
+    const int kind0 = __builtin_amdgcn_readfirstlane(surf[0].kind);      // host: the same for every surface in front of cont_k0
+    const int klast = a.cont_k0 - 1;
+    // this wave's contiguous range of ray indices (equal ranges: the walk lengths average out over a range)
+    const uint64_t per = ((a.n_rays + gridDim.x - 1) / gridDim.x + 63) & ~63ull;
+    uint64_t lo = (uint64_t)blockIdx.x * per;  if (lo > a.n_rays) lo = a.n_rays;
+    uint64_t hi = lo + per;                     if (hi > a.n_rays) hi = a.n_rays;
+
+    unsigned int lost = 0, isect = 0, help3 = 0;
+    auto end_ray = [&](int st, int nis) {                 // a ray that ends inside the bottle (nothing is binned here)
+        isect += (unsigned)nis;
+        lost++;                                           // every status a ray can end with here counts as lost
+        if (st == ORT_ST_HELP3) help3++;
+    };
+    int wcount = 0, whead = 0, acount = 0, ahead = 0;
+    auto push = [&](ScatQueue &Q, int &count, int head, bool cond, const Ray &r, double t, const KeyedDraws &d, int nis, int k) {
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(cond);
+        if (cond) {
+            const int slot = (head + count + lane_prefix(mask)) & (kSQCap - 1);
+            Q.f[0][slot] = r.pos.x; Q.f[1][slot] = r.pos.y; Q.f[2][slot] = r.pos.z;
+            Q.f[3][slot] = r.dir.x; Q.f[4][slot] = r.dir.y; Q.f[5][slot] = r.dir.z;
+            Q.f[6][slot] = t;
+            Q.c[slot] = d.c;
+            Q.m[slot] = ((uint32_t)nis << 8) | (uint32_t)k;
+        }
+        count += __popcll(mask);
+    };
+    auto pop = [&](ScatQueue &Q, int &count, int &head, bool &act, Ray &r, double &t, KeyedDraws &d, int &nis, int &k) {
+        const int m = count < 64 ? count : 64;
+        act = lane < m;
+        const int slot = (head + lane) & (kSQCap - 1);
+        head = (head + m) & (kSQCap - 1);
+        count -= m;
+        r = {{0., 0., 0.}, {0., 0., 1.}};
+        t = 0.; nis = 0; k = 0;
+        d.base = a.rng_base; d.c = 0;
+        if (act) {
+            r.pos = {Q.f[0][slot], Q.f[1][slot], Q.f[2][slot]};
+            r.dir = {Q.f[3][slot], Q.f[4][slot], Q.f[5][slot]};
+            t = Q.f[6][slot];
+            d.c = Q.c[slot];
+            const uint32_t mm = Q.m[slot];
+            nis = (int)(mm >> 8); k = (int)(mm & 0xffu);
+        }
+    };
+    // behind the last scattering surface: the next free slots of this wave's part of the hand-over bundle
+    uint64_t handed = 0;
+    auto hand_over = [&](bool cond, const Ray &r, const KeyedDraws &d, int nis) {
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(cond);
+        if (cond) {
+            const uint64_t j = lo + handed + (uint64_t)lane_prefix(mask), cap = a.cont_cap;
+            a.cont_pos_dir[0 * cap + j] = r.pos.x; a.cont_pos_dir[1 * cap + j] = r.pos.y; a.cont_pos_dir[2 * cap + j] = r.pos.z;
+            a.cont_pos_dir[3 * cap + j] = r.dir.x; a.cont_pos_dir[4 * cap + j] = r.dir.y; a.cont_pos_dir[5 * cap + j] = r.dir.z;
+            a.cont_draw[j] = d.c;
+            a.cont_nis[j] = nis;
+        }
+        handed += (uint64_t)__popcll(mask);
+    };
+
+    uint64_t next = lo;
+    for (;;) {
+        const bool have_new = next < hi;
+        // a full wavefront of walking rays first, then of arrived ones; fresh rays while at most 64 are in flight (the
+        // queues hold 128); otherwise the fuller queue runs on a partial wavefront
+        const bool may_emit = have_new && wcount + acount <= 64;
+        if (wcount >= 64 || (wcount > 0 && acount < 64 && !may_emit && wcount >= acount)) {
+            // ---- W: one scattering event (src/lens.f90:264-281 / :315-332) for up to 64 walking rays
+            bool act;
+            Ray r;
+            double t;
+            KeyedDraws d;
+            int nis, k;
+            pop(WQ, wcount, whead, act, r, t, d, nis, k);
+            const ort_surface &s = surf[k];
+            int ended = -1;
+            bool walking = act;
+            r.pos = vselect(walking, vadd(r.pos, vscale(r.dir, t)), r.pos);
+            const double albedo = s.mus / (s.mus + s.mua);
+            const double u = d.peek();
+            d.advance(walking);
+            const bool absorbed = walking && !(u < albedo);
+            ended = absorbed ? ORT_ST_LOST_BOTTLE : ended;
+            walking = walking && !absorbed;
+            stokes_hg<double>(r.dir, s.hgg, S.twopi, walking, d);
+            double dist;
+            bool at_wall, ok;
+            tauint<double>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, walking, d, dist, at_wall, ok, nis);
+            const bool lostw = walking && !ok;
+            ended = lostw ? ORT_ST_NO_INTERSECTION : ended;
+            t = (walking && ok) ? dist : t;
+            const bool out = sqrt(r.pos.x * r.pos.x + r.pos.z * r.pos.z) >= s.scat_radius;        // sic: x, z
+            const bool still = walking && ok && !out && !at_wall;
+            const bool arrived = walking && ok && !still;
+            push(WQ, wcount, whead, still, r, t, d, nis, k);
+            push(AQ, acount, ahead, arrived, r, t, d, nis, k);
+            if (act && ended >= 0) end_ray(ended, nis);
+            __builtin_amdgcn_wave_barrier();
+        } else if (acount >= 64 || (acount > 0 && !may_emit)) {
+            // ---- A: the rest of the surface step for up to 64 rays that reached the wall, then the next surface
+            bool act;
+            Ray r;
+            double t;
+            KeyedDraws d;
+            int nis, k;
+            pop(AQ, acount, ahead, act, r, t, d, nis, k);
+            const ort_surface &s = surf[k];
+            const unsigned flags = s.flags;
+            int ended = -1;
+            const bool back = act && (flags & ORT_F_SCATTER) != 0 && r.dir.z < 0.;       // lens.f90:283, :334
+            ended = back ? ORT_ST_LOST_BOTTLE : ended;
+            const bool live = act && !back;
+            r.pos = vselect(live, vadd(r.pos, vscale(r.dir, t)), r.pos);
+            const Vec Nraw = {0.0, s.cy - r.pos.y, s.cz - r.pos.z};                      // lens.f90:288-290
+            const Vec N = vnormalise(Nraw);
+            const double u = d.peek();
+            d.advance(live);
+            bool unused = false;
+            const bool reflected = reflect_refract<false, true, double>(r.dir, N, s.n1, s.n2, s.eta, 0., u, live, unused);
+            const bool dies = live && reflected && (flags & ORT_F_SKIP_ON_REFLECT) != 0;
+            ended = dies ? ((flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE) : ended;
+            const bool on = live && !dies;
+            hand_over(on && k >= klast, r, d, nis);
+            const bool enter = on && k < klast;
+            bool walking = false, arrived = false;
+            const int k1 = enter ? k + 1 : k;
+            if (wave_any(enter)) {                       // (a wavefront of rays that all arrived at the last wall skips it)
+                scat_enter(surf, k1, kind0, enter, r, d, nis, t, walking, arrived, ended);
+                push(WQ, wcount, whead, walking, r, t, d, nis, k1);
+                push(AQ, acount, ahead, arrived, r, t, d, nis, k1);
+            }
+            if (act && ended >= 0) end_ray(ended, nis);
+            __builtin_amdgcn_wave_barrier();
+        } else if (may_emit) {
+            // ---- E: 64 fresh rays
+            const uint64_t i = next + (uint64_t)lane;
+            const bool act = i < hi;
+            next += 64;
+            const uint64_t ic = act ? i : hi - 1;
+            Ray r;
+            KeyedDraws d;
+            d.init_keyed(a.rng_base, a.first_ray + ic, 0);
+            int ended = emit<double, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf);
+            int nis = 0;
+            double t = 0.;
+            bool walking, arrived;
+            scat_enter(surf, 0, kind0, act && ended < 0, r, d, nis, t, walking, arrived, ended);
+            push(WQ, wcount, whead, walking, r, t, d, nis, 0);
+            push(AQ, acount, ahead, arrived, r, t, d, nis, 0);
+            if (act && ended >= 0) end_ray(ended, nis);
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            break;
+        }
+    }
+    for (uint64_t j = lo + handed + (uint64_t)lane; j < hi; j += 64) a.cont_draw[j] = kNoRay;    // the slots left over
+    atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect); atomicAdd(&blk[3], help3);
+    __syncthreads();
+    if (threadIdx.x < 4 && blk[threadIdx.x])
+        atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int phase,
@@ -1069,6 +1323,11 @@ struct ort_ctx {
     int emitter[2];              // host copy of ort_system.emitter
     bool scatter[2];             // per phase: some surface of its list carries ORT_F_SCATTER
     int prog[2];                 // per phase: PROG_* the staged system matches (match_program)
+    int scat_k0[2];              // per phase: > 0: the scattering pipeline applies, its continuation starts at this surface
+    double *d_cont_pos_dir;      // hand-over bundle of the scattering pipeline (scatter_front_kernel), cont_cap entries
+    uint64_t *d_cont_draw;
+    int32_t *d_cont_nis;
+    uint64_t cont_cap;
     double ring_cull;            // TraceArgs.cull of the staged system (ring_cull_threshold), +inf: no culling
     float ring_cullf;
     hipEvent_t ev[3][2];
@@ -1127,6 +1386,19 @@ static void note_system(ort_ctx *c, const ort_system *sys)
         c->scatter[p] = false;
         for (int k = 0; k < sys->n_surfaces[p]; ++k)
             if (sys->surfaces[p][k].flags & ORT_F_SCATTER) c->scatter[p] = true;
+    }
+    // the scattering pipeline takes the surfaces up to the last scattering one: they must be the walls of one
+    // bottle (one kind — circular or elliptical cylinder —, no aperture stop) with something left behind them
+    for (int p = 0; p < 2; ++p) {
+        int last = -1;
+        for (int k = 0; k < sys->n_surfaces[p]; ++k)
+            if (sys->surfaces[p][k].flags & ORT_F_SCATTER) last = k;
+        bool ok = last >= 0 && last + 1 < sys->n_surfaces[p] && last < 255;
+        for (int k = 0; ok && k <= last; ++k) {
+            const ort_surface &s = sys->surfaces[p][k];
+            ok = (s.kind == ORT_SURF_CYLINDER || s.kind == ORT_SURF_ELLIPSE) && s.kind == sys->surfaces[p][0].kind && !(s.aperture >= 0.0);
+        }
+        c->scat_k0[p] = ok ? last + 1 : 0;
     }
     c->prog[0] = c->prog[1] = PROG_GENERIC;
 #define ORT_MATCH(P) if (matches<P>(sys)) c->prog[Prog<P>::phase - 1] = P;
@@ -1320,6 +1592,7 @@ int ort_destroy(ort_ctx *c)
     for (int k = 0; k < kSysSlots; ++k) if (c->sys_ev[k]) (void)hipEventDestroy(c->sys_ev[k]);
     (void)hipFree(c->d_sys_ring); (void)hipHostFree(c->h_sys_ring); (void)hipFree(c->own_image); (void)hipFree(c->own_counters); (void)hipFree(c->d_replicas); (void)hipFree(c->d_img_cdf);
     (void)hipFree(c->d_redo_list); (void)hipFree(c->d_redo_ctl); (void)hipFree(c->d_work);
+    (void)hipFree(c->d_cont_pos_dir); (void)hipFree(c->d_cont_draw); (void)hipFree(c->d_cont_nis);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ORT_OK;
@@ -1449,6 +1722,24 @@ static int reserve_list(ort_ctx *c, uint64_t n_rays)
     return ORT_OK;
 }
 
+// Scratch of the scattering pipeline: one hand-over entry (60 bytes) per ray of a launch; launches of that path
+// cover at most kScatterChunk rays (250 MB of the 288 GB).
+constexpr uint64_t kScatterChunk = 1ull << 22;
+static int reserve_handover(ort_ctx *c, uint64_t n_rays)
+{
+    const uint64_t want = n_rays < kScatterChunk ? n_rays : kScatterChunk;
+    if (want <= c->cont_cap) return ORT_OK;
+    { const int rc = close_group(c); if (rc) return rc; }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_cont_pos_dir); (void)hipFree(c->d_cont_draw); (void)hipFree(c->d_cont_nis);
+    c->d_cont_pos_dir = nullptr; c->d_cont_draw = nullptr; c->d_cont_nis = nullptr; c->cont_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_cont_pos_dir, 6 * want * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_cont_draw, want * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&c->d_cont_nis, want * sizeof(int32_t)));
+    c->cont_cap = want;
+    return ORT_OK;
+}
+
 static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
 {
     a0.sys = &c->d_sys->sys; a0.aux = c->d_sys->aux[a0.phase - 1];
@@ -1466,13 +1757,23 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     if (a0.n_rays == 0) return ORT_OK;
     const bool queued = (c->variant & 1) && mode != MODE_DEBUG;
     const bool filt = (c->variant & 2) == 0 && c->precision != 1;      // fp32: literal predicates, nothing is deferred
-    const bool anysrc = c->emitter[a0.phase - 1] != (a0.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT) || c->scatter[a0.phase - 1];
+    const bool anysrc_emitter = c->emitter[a0.phase - 1] != (a0.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT);
+    const bool anysrc = anysrc_emitter || c->scatter[a0.phase - 1];
     // The queued filtered kernel defers the rays that sit on a decision boundary to a list, which
     // the literal lockstep kernel traces right after it.  Every ray of a launch could be on it
     // (an axial beam meets every flat face at costt == 1), so a launch covers at most kChunkRays.
     const bool deferring = queued && filt;
     const uint64_t total = a0.n_rays;
-    const uint64_t step = deferring ? kChunkRays : total;
+    // scattering media, exact fp64, the default kernel variant: the three-stage pipeline (scatter_front_kernel)
+    const bool pipeline = mode == MODE_FUSED && deferring && c->precision == 0 && c->scatter[a0.phase - 1] &&
+                          c->scat_k0[a0.phase - 1] > 0 && (c->variant & 16) == 0;
+    const uint64_t step = pipeline ? kScatterChunk : (deferring ? kChunkRays : total);
+    if (pipeline) {
+        const int rc = reserve_handover(c, total);
+        if (rc) return rc;
+        a0.cont_pos_dir = c->d_cont_pos_dir; a0.cont_draw = c->d_cont_draw; a0.cont_nis = c->d_cont_nis;
+        a0.cont_cap = c->cont_cap; a0.cont_k0 = c->scat_k0[a0.phase - 1];
+    }
     if (deferring) {
         const int rc = reserve_list(c, total);
         if (rc) return rc;
@@ -1484,7 +1785,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     // hands the pair to the launch itself (hipExtLaunchKernel: start / stop of that dispatch, no
     // packet of its own); every separate event record is a packet the command processor handles
     // between two kernels (~2 us each at 1e7 rays per launch).
-    const bool one_launch = total <= step;
+    const bool one_launch = total <= step && !pipeline;        // the pipeline is two kernels per launch
     const bool ext_timed = c->timing && evk == 0 && one_launch;
     if (c->timing && evk > 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
     if (c->timing && evk == 0 && !ext_timed) HIP_TRY(hipEventRecord(c->ring[slot][0], c->stream));
@@ -1516,6 +1817,16 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
             if (rc) return rc;
         }
         if (ext_timed) { c->launch_ev[0] = c->ring[slot][0]; c->launch_ev[1] = c->ring[slot][1]; }
+        if (pipeline) {
+            // one wavefront per workgroup, ~2 rounds of the 7 workgroups a CU holds
+            uint64_t waves = (a.n_rays + 127) / 128;
+            if (waves > 3584) waves = 3584;
+            if (anysrc_emitter) hipLaunchKernelGGL(scatter_front_kernel<true>, dim3((unsigned)waves), dim3(64), 0, c->stream, a);
+            else hipLaunchKernelGGL(scatter_front_kernel<false>, dim3((unsigned)waves), dim3(64), 0, c->stream, a);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL((trace_queue_kernel<MODE_CONTINUE, true, false, double, PROG_GENERIC, false>), dim3(grid), dim3(kBlock), 0,
+                               c->stream, a);
+        } else
         launch_one(c, mode, a, grid, queued, filt, anysrc);
         c->launch_ev[0] = c->launch_ev[1] = nullptr;
         HIP_TRY(hipGetLastError());                         // a failed launch is reported where it happened
@@ -1829,7 +2140,7 @@ int ort_synchronize(ort_ctx *c)
 int ort_set_kernel_variant(ort_ctx *c, int variant)
 {
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
-    if (variant < 0 || variant > 15) return fail(ORT_E_INVALID, "variant must be in 0..15");
+    if (variant < 0 || variant > 31) return fail(ORT_E_INVALID, "variant must be in 0..31");
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = close_group(c); if (rc) return rc; }
     c->variant = variant;

@@ -563,3 +563,25 @@ def test_deferred_rays_of_a_group_of_launches(hip_library):
         assert np.array_equal(img[1], want[1]) and np.abs(img[0].astype(np.int64) - want[0]).sum() <= 2
         assert np.array_equal(cnt[[1, 3, 5, 7]], wc[[1, 3, 5, 7]])
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("name", ["small_scatter_c", "small_scatter_bc"])
+def test_scattering_pipeline_equals_monolithic_and_lockstep_kernels(ctxs, name):
+    """The scattering pipeline (scatter_front_kernel: the random walk in stages on full wavefronts, then the lean
+    walk from a hand-over bundle) only reschedules: image and counters equal those of the monolithic queued
+    kernel (variant bit 4) and of the lockstep kernel, bit for bit — ragged sizes, a launch cut at the
+    pipeline's 2^22-ray chunk, both phases (phase 1 never meets the bottle)."""
+    osys, ctx = ctxs(name)
+    for n in (1, 63, 65, 4097, 300_007, (1 << 22) + 4321):
+        out = []
+        for variant in (1, 17, 0) if n < 4_000_000 else (1, 17):
+            ctx.set_kernel_variant(variant)
+            ctx.reset()
+            ctx.trace(2, 11, n, SEED)
+            ctx.trace(1, 5, min(n, 100_000), SEED)
+            out.append(ctx.read())
+        ctx.set_kernel_variant(1)
+        for v in range(1, len(out)):
+            assert np.array_equal(out[0][0], out[v][0]), (name, n, v)
+            assert np.array_equal(out[0][1], out[v][1]), (name, n, v, out[0][1], out[v][1])
+    assert int(out[0][1][5]) > 100_000                      # rays do get through
