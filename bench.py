@@ -176,7 +176,7 @@ def single_process(args, phases, rays_gpu, text) -> int:
     return 0
 
 
-def cpu_baseline(rays: int):
+def cpu_baseline(rays: int, program_runs: int = 0):
     """Time the CPU checker on a bounded sample of the same workload (rank 0, N=1 only).
 
     Runs in a child process (its OpenMP runtime stays out of this one).  Prefers
@@ -184,7 +184,7 @@ def cpu_baseline(rays: int):
     "reference"), else the C restatement (kind "port")."""
     try:
         out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"),
-                              "--rays", str(rays)], capture_output=True, text=True, timeout=900)
+                              "--rays", str(rays), "--program-runs", str(program_runs)], capture_output=True, text=True, timeout=1200)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:                                  # the baseline is reported, never required
@@ -227,6 +227,9 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast", action="store_true", help="skip the informational fast-fp64 leg")
     ap.add_argument("--no-fp32", action="store_true", help="skip the informational fp32 leg (configs[4])")
+    ap.add_argument("--sweep", action="store_true",
+                    help="also time runner.py's lens experiment (75 systems): batched / one by one / process per simulation, "
+                         "at 1e6 and 1e9 photons; adds the `sweep` object (several extra seconds)")
     ap.add_argument("--single-process", action="store_true",
                     help="one process, one context per GPU, ort_allreduce (the Fortran host's layout, INTEGRATION.md §C)")
     ap.add_argument("--force-dist", action="store_true",
@@ -261,7 +264,7 @@ def main() -> int:
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_dist:
-        cpu = cpu_baseline(args.cpu_rays)          # before the GPU is touched by this process
+        cpu = cpu_baseline(args.cpu_rays, 2 if args.sweep else 0)          # before the GPU is touched by this process
 
     import torch
     import torch.distributed as dist
@@ -545,6 +548,13 @@ def main() -> int:
         out["cpu_baseline"] = cpu
         if cpu.get("value"):
             out["gpu_over_cpu"] = value / cpu["value"]
+    if args.sweep and rank == 0 and world == 1:
+        from opticalraytrace_amd.sweeps import lens_experiment_rates
+        tracer.close()
+        out["sweep"] = {"1e6": lens_experiment_rates(1_000_000, local_rank, process_samples=3),
+                        "1e9": lens_experiment_rates(1_000_000_000, local_rank, process_samples=2)}
+        if cpu is not None and cpu.get("reference_program"):
+            out["sweep"]["reference_program"] = cpu["reference_program"]
     if os.environ.get("ORT_BENCH_DUMP_KERNEL_MS"):               # development: the per-launch series
         out["kernel_ms_series"] = [round(x, 4) for x in kernel_ms]
     if rank == 0:

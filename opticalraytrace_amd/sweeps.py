@@ -208,6 +208,53 @@ class Sweep:
                              L2_file=f"planoConvex-f{f2}mm.params")
 
 
+def lens_experiment_rates(nphotons: int, device: int = 0, modes=("batched", "one_by_one"), process_samples: int = 0) -> dict:
+    """Simulations per second of runner.py's lens experiment (75 systems, :232-261) on one GPU: queued as one
+    batch, one `run_settings` at a time on a reused context, and — `process_samples` simulations of it — one
+    `python -m opticalraytrace_amd <settings>` PROCESS per simulation, which is runner.py's own model (:26-47).
+    Outputs (the stats rows; the lens experiment writes no images) go to a scratch directory."""
+    import subprocess
+    import tempfile
+    import time
+    out = {"experiment": "lens_experiment (runner.py:232-261): 5 doublets x 5 plano-convex lenses x 3 bottles", "nphotons": nphotons}
+    with tempfile.TemporaryDirectory(prefix="ort_sweep_") as tmp:
+        for mode in modes:
+            sw = Sweep(nphotons=nphotons, data_dir=os.path.join(tmp, mode), device=device, batched=(mode == "batched"))
+            try:
+                sw.run("warm.params", light_source="point", make_images=False, data_folder="warm")   # context, code objects
+                sw.flush()
+                t0 = time.perf_counter()
+                sw.lens_experiment()
+                el = time.perf_counter() - t0
+            finally:
+                sw.close()
+            n = len(sw.results) - 1
+            out[mode] = {"simulations": n, "seconds": el, "simulations_per_s": n / el,
+                         "rays_per_s": 2.0 * nphotons * n / el}
+        if process_samples:
+            sw = Sweep(nphotons=nphotons, data_dir=os.path.join(tmp, "p"), settings_dir=os.path.join(tmp, "settings"), batched=True)
+            sw.tracer = None
+            names = []
+            for k, f3 in enumerate(L3_FOCALS[:process_samples]):
+                s = Settings(nphotons=nphotons, light_source="point", make_images=False, bottle_file=LENS_BOTTLES[0][0],
+                             data_folder="images-lens", L3_file=f"achromaticDoublet-f{f3}mm.params",
+                             L2_file=f"planoConvex-f{L2_FOCALS[k % len(L2_FOCALS)]}mm.params")
+                os.makedirs(sw.settings_dir, exist_ok=True)
+                s.write(os.path.join(sw.settings_dir, f"p_{k}.params"))
+                names.append(f"p_{k}.params")
+            times = []
+            for name in names:
+                t0 = time.perf_counter()
+                subprocess.run([sys.executable, "-m", "opticalraytrace_amd", os.path.join(sw.settings_dir, name), "--res", sw.res_dir,
+                                "--data", os.path.join(tmp, "p"), "--quiet", "--device", str(device)], check=True,
+                               cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+                times.append(time.perf_counter() - t0)
+            out["process_per_simulation"] = {"samples": len(times), "seconds_per_simulation": sum(times) / len(times),
+                                             "simulations_per_s": len(times) / sum(times),
+                                             "what": "python -m opticalraytrace_amd <settings>: interpreter + context + run + files per simulation"}
+    return out
+
+
 def main(argv: Optional[Iterable[str]] = None) -> int:
     ap = argparse.ArgumentParser(usage="%(prog)s [OPTION]", description=__doc__,
                                  formatter_class=argparse.RawDescriptionHelpFormatter)

@@ -118,8 +118,46 @@ def worker(kind: str, rays: int, phase: int, repeats: int):
                       "intersections": int(c[2 + phase - 1])}))
 
 
+def reference_program_runs(runs: int, nphotons: int = 1_000_000):
+    """runner.py's model on the CPU (runner.py:26-47): one PROCESS of the unmodified reference program
+    (oracle/_ref/raytrace, all 13 sources incl. its own random_mod.f90 + main.f90, the serial build: under flang the
+    OpenMP build is SLOWER — its random_number is one locked generator) per simulation of the lens experiment — wall seconds per simulation at `nphotons` photons per layer."""
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    from opticalraytrace_amd.params import Settings, resource_dir
+    from oracle.binding import REF_PROG
+    if not os.path.exists(REF_PROG):
+        return None
+    tmp = tempfile.mkdtemp(prefix="ortref_sweep_")
+    try:
+        for d in ("bin", "res", "data"):
+            os.makedirs(os.path.join(tmp, d))
+        for f in os.listdir(resource_dir()):
+            if f.endswith(".params"):
+                shutil.copy(os.path.join(resource_dir(), f), os.path.join(tmp, "res", f))
+        np.ones((512, 512)).tofile(os.path.join(tmp, "res", "ones.dat"))      # opened unconditionally (src/setupMod.f90:120-121)
+        times = []
+        for k in range(runs):
+            f3, f2 = ("40.0", "45.0", "50.0")[k % 3], ("59.8", "49.8", "39.9")[k % 3]
+            Settings(nphotons=nphotons, light_source="point", make_images=False, image_source="ones.dat", data_folder="images-lens",
+                     bottle_file="clearBottle-large.params", L3_file=f"achromaticDoublet-f{f3}mm.params",
+                     L2_file=f"planoConvex-f{f2}mm.params").write(os.path.join(tmp, "res", f"cfg{k}.params"))
+            t0 = time.perf_counter()
+            subprocess.run([REF_PROG, f"cfg{k}.params"], cwd=os.path.join(tmp, "bin"), capture_output=True, check=True, timeout=900)
+            times.append(time.perf_counter() - t0)
+        return {"runs": runs, "nphotons": nphotons, "seconds_per_simulation": sum(times) / len(times), "all_seconds": times,
+                "simulations_per_s": len(times) / sum(times),
+                "what": "oracle/_ref/raytrace: the unmodified reference program, one process per simulation (runner.py:26-47), "
+                        "serial build (flang's OpenMP build is slower: one locked random_number generator, SURVEY §6)"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--program-runs", type=int, default=0, help="also time this many runs of the unmodified reference program")
     ap.add_argument("--rays", type=int, default=50_000_000)
     ap.add_argument("--phase", type=int, default=2)
     ap.add_argument("--kind", choices=["auto", "reference", "port"], default="auto")
@@ -206,7 +244,8 @@ def main():
                   f"{isect} intersections in {best['seconds']:.3f} s wall (median of {args.repeats}) on {best_t} threads "
                   f"(best of threads = {tried} x binding none / close-to-cores; one-thread point on {one_rays} rays); {what}",
         "rays_per_s": best["rays_per_s"], "seconds": best["seconds"], "cpu": cpu_model,
-        "thread_sweep": sweep, **extra}))
+        "thread_sweep": sweep, **extra,
+        **({"reference_program": reference_program_runs(args.program_runs)} if args.program_runs else {})}))
 
 
 if __name__ == "__main__":
