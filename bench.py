@@ -428,6 +428,16 @@ def main() -> int:
     prof = prof or {}
     traffic = prof.get("hbm_bytes_per_launch")
 
+    def leg_counters(leg):
+        """executed-work counters of an informational leg's kernel, from the committed PMC passes of this build"""
+        p, _ = profiled_counters(f"{args.workload}_{leg}" if not custom else "custom", build)
+        p = p or {}
+        vi, ni = p.get("valu_instructions_per_launch"), p.get("intersections_per_launch")
+        return {"valu_busy": p.get("valu_busy_frac"), "valu_lane_utilisation": p.get("valu_lane_utilisation"),
+                "valu_instr_per_intersection": vi * 64.0 / ni if vi and ni else None,
+                "instruction_classes_per_launch": {k: p[k] for k in ("fma_f32", "mul_f32", "add_f32", "trans_f32", "int32", "fma_f64",
+                                                                       "mul_f64", "add_f64", "trans_f64") if k in p} or None}
+
     def fp_roofline(kms, r, culled, peak, bound, kernels):
         """per CALL here: the fp32 path is not cut into launches of 2^25 rays (nothing is deferred)"""
         ks = (sum(kms) / len(kms)) * 1e-3 / kernels
@@ -527,7 +537,7 @@ def main() -> int:
         i32, b32 = isect_binned(r)
         out["fp32"] = {
             "value": i32 / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3, "dtype": "f32",
-            "roofline": fp_roofline(kms, r, cul, FP32_VEC_PEAK_TFLOPS, "valu_fp32", 1),
+            "roofline": {**fp_roofline(kms, r, cul, FP32_VEC_PEAK_TFLOPS, "valu_fp32", 1), **leg_counters("fp32")},
             "image_l1_vs_exact": int(abs(r.image.astype("int64") - res.image.astype("int64")).sum()),
             "image_l1_vs_exact_frac_of_binned": float(abs(r.image.astype("int64") - res.image.astype("int64")).sum()) / max(binned_total, 1),
             "binned": b32, "binned_exact": binned_total, "intersections": i32, "intersections_exact": isect_total,
@@ -539,7 +549,7 @@ def main() -> int:
         i2, _ = isect_binned(r)
         out["fast_fp64"] = {
             "value": i2 / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3,
-            "roofline": fp_roofline(kms, r, cul, FP64_VEC_PEAK_TFLOPS, "valu_fp64", kernels_per_call),
+            "roofline": {**fp_roofline(kms, r, cul, FP64_VEC_PEAK_TFLOPS, "valu_fp64", kernels_per_call), **leg_counters("fast_fp64")},
             "image_l1_vs_exact": int(abs(r.image.astype("int64") - res.image.astype("int64")).sum()),
             "note": "ort_set_precision(2): FMA contraction + Newton reciprocal/rsqrt; ~1e-15 relative from the "
                     "exact path, not bit-identical (tests/test_gpu_fastd.py)",

@@ -24,6 +24,9 @@ sys.path.insert(0, ROOT)
 DOMINANT = {"point1e7": "trace_queue_kernel<0, true, false, double, 1, false>",
             "ring1e8": "trace_queue_kernel<0, true, false, double, 2, false>",
             "full1e9": "trace_queue_kernel<0, true, false, double, 1, false>"}
+# the informational legs of a workload: their program kernels (bench.py `fp32` / `fast_fp64`)
+LEGS = {"point1e7": {"fp32": "trace_queue_kernel<0, false, false, float, 1, false>",
+                     "fast_fp64": "trace_queue_kernel<0, true, false, ort::fastd, 1, false>"}}
 
 
 def short(name):
@@ -103,6 +106,27 @@ def main():
                 entry["intersections_per_launch"] = per_step / launches
         stamped["workloads"][w] = entry
         print(w, json.dumps(entry, indent=1))
+        for leg, kname in LEGS.get(w, {}).items():
+            lk = summ.get(kname)
+            if not lk:
+                print(f"{w}: leg {leg}: kernel {kname} not in the PMC output")
+                continue
+            gl = lambda c: lk.get(c, {}).get("mean_per_launch")      # noqa: E731
+            e2 = {"kernel": kname, "intersections_per_launch": entry.get("intersections_per_launch")}
+            if gl("SQ_ACTIVE_INST_VALU") and gl("GRBM_GUI_ACTIVE"):
+                e2["valu_busy_frac"] = gl("SQ_ACTIVE_INST_VALU") * 4.0 / 1024.0 / (gl("GRBM_GUI_ACTIVE") / 8.0)
+            if gl("SQ_THREAD_CYCLES_VALU") and gl("SQ_ACTIVE_INST_VALU"):
+                e2["valu_lane_utilisation"] = gl("SQ_THREAD_CYCLES_VALU") / (64.0 * gl("SQ_ACTIVE_INST_VALU"))
+            for c, key in (("SQ_INSTS_VALU", "valu_instructions_per_launch"), ("SQ_INSTS_SALU", "salu_instructions_per_launch"),
+                           ("SQ_WAVES", "waves_per_launch"), ("SQ_WAIT_INST_ANY", "wave_cycles_waiting_for_issue"),
+                           ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_INSTS_VALU_FMA_F32", "fma_f32"), ("SQ_INSTS_VALU_MUL_F32", "mul_f32"),
+                           ("SQ_INSTS_VALU_ADD_F32", "add_f32"), ("SQ_INSTS_VALU_TRANS_F32", "trans_f32"),
+                           ("SQ_INSTS_VALU_INT32", "int32"), ("SQ_INSTS_VALU_FMA_F64", "fma_f64"), ("SQ_INSTS_VALU_MUL_F64", "mul_f64"),
+                           ("SQ_INSTS_VALU_ADD_F64", "add_f64"), ("SQ_INSTS_VALU_TRANS_F64", "trans_f64")):
+                if gl(c) is not None:
+                    e2[key] = gl(c)
+            stamped["workloads"][f"{w}_{leg}"] = e2
+            print(w, leg, json.dumps(e2, indent=1))
     json.dump(stamped, open(os.path.join(ROOT, "profiles", "pmc_per_launch.json"), "w"), indent=1)
 
 
