@@ -474,7 +474,7 @@ using Ray = RayT<double>;
 
 // What a surface step may ASSUME (OPT bit mask; 0 = nothing, the generic walk and every entry that takes
 // rays from the caller).  Each bit removes instructions whose result is known in advance; none changes a
-// result (tests: every kernel variant against the lockstep kernel and the oracle, bit for bit).
+// result (tests: every kernel variant against the lockstep kernel and the CPU checker, bit for bit).
 //   OPT_UNIT_DIR   the direction is a unit vector up to rounding: it was emitted by `point` / `ring`
 //                  (normalised there) and every surface passed since left I alpha + N beta with
 //                  |I| = |N| = 1 and alpha^2 (1 - c1^2) + ... = 1 (refract: eta^2 (1 - c1^2) + c2^2 = 1 by

@@ -960,7 +960,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
 // and trace_queue_kernel<MODE_CONTINUE> walks the remaining surfaces at its own register budget.  Every
 // operation of a ray is the one the monolithic kernel (and the lockstep kernel) performs, in the same order with
 // the same draws — literal predicates throughout, nothing is deferred here — so rays, images and counters are
-// bit-identical to theirs (tests: the pipeline against the lockstep kernel; both against the oracle).
+// bit-identical to theirs (tests: the pipeline against the lockstep kernel; both against the CPU checker).
 // One wavefront per workgroup: the two queues take 17 KB of LDS per wave (7 waves per CU; the kernel's 171 VGPRs
 // allow 8).
 // ---------------------------------------------------------------------------

@@ -224,25 +224,30 @@ def write_images(image: np.ndarray, stem: str) -> Tuple[str, str, str]:
     return names
 
 
-STATS_HEADER = (" r/%, p/%, l2%f, l3%f, bottle?, radiusA, radiusB, iris_pos, iris_radius, "
-                "offset, source_type, seperation")     # main.f90:171
+STATS_HEADER = ("r/%, p/%, l2%f, l3%f, bottle?, radiusA, radiusB, iris_pos, iris_radius, "
+                "offset, source_type, seperation")      # main.f90:171
+
+
+def stats_row(system: OpticalSystem, res: RunResult) -> str:
+    """The record of src/main.f90:173-178, laid out as list-directed output of the compiler the reference is
+    built with here (flang: fstr.list_directed_record — blanks, shortest-digit reals, records of 79 columns);
+    equal, character for character, to what the unmodified program leaves (tests/golden/refprog_*.npz)."""
+    s, b = system.settings, system.bottle
+    iris = {"before": (True, False), "after": (False, True), "none": (False, False)}[s.iris]
+    return fstr.list_directed_record([
+        res.ring_transmitted, ",", res.point_transmitted, ",", system.L2[1].f, ",", system.L3[1].f, ",", bool(s.use_bottle), ",",
+        b.radiusa, ",", b.radiusb, ",", iris[0], iris[1], ",", fstr.str_real(s.iris_size, 7), ",", b.centre[2], ",",
+        s.light_source.strip() + ",", s.isors_offset])
 
 
 def append_stats(folder: str, system: OpticalSystem, res: RunResult) -> str:
-    """The trans-stats.dat row of src/main.f90:168-178.  Field order and separators are the
-    reference's; the exact column padding of list-directed output is compiler-specific."""
-    s, b = system.settings, system.bottle
+    """Append the trans-stats.dat record of src/main.f90:168-178 (header first if the file is new)."""
     path = os.path.join(folder, "trans-stats.dat")
     new = not os.path.exists(path)
-    iris = {"before": "T F", "after": "F T", "none": "F F"}[s.iris]
-    row = (f" {res.ring_transmitted!r} , {res.point_transmitted!r} , {system.L2[1].f!r} , "
-           f"{system.L3[1].f!r} , {fstr.str_logical(s.use_bottle)} , {b.radiusa!r} , {b.radiusb!r} , "
-           f"{iris} , {fstr.str_real(s.iris_size, 7)} , {b.centre[2]!r} , {s.light_source.strip()}, "
-           f"{s.isors_offset!r}")
     with open(path, "a") as f:
         if new:
-            f.write(STATS_HEADER + "\n")
-        f.write(row + "\n")
+            f.write(fstr.list_directed_record([STATS_HEADER]))
+        f.write(stats_row(system, res))
     return path
 
 

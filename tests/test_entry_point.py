@@ -76,7 +76,7 @@ def test_entry_point_writes_what_run_settings_writes(tmp_path, hip_library):
         assert a.size == 401 * 401 and np.array_equal(a, b), n
     assert np.fromfile(got_dir / names[2]).sum() == res.image.sum()   # -total = ring + point
     rows = open(got_dir / "trans-stats.dat").read().splitlines()
-    assert len(rows) == 2 and rows == open(want_root / "images" / "trans-stats.dat").read().splitlines()
+    assert len(rows) == 4 and rows == open(want_root / "images" / "trans-stats.dat").read().splitlines()   # header + record, two lines each
     # explicit paths instead of the bin/ layout
     p = _run(str(tmp_path), "res/test_0.params", "--data", "data2", "--quiet")
     assert p.returncode == 0 and p.stdout == ""

@@ -1,7 +1,7 @@
 """Fast fp64 mode (ort_set_precision(ctx, 2), csrc/ort_fastd.h): fused multiply-adds and
 Newton-refined reciprocal / rsqrt instead of IEEE divide / sqrt.  Deviation from the exact fp64
 path, same rays, same draws: per-ray |dpos| / binwid, status agreement, per-bin count deltas.
-The figures are written to gpurun_out/fastd_study_*.json (copied to profiles/ when recorded)."""
+The figures are written to $ORT_STUDY_DIR/fastd_study_*.json when that is set (copied to profiles/ when recorded)."""
 import json
 import os
 
@@ -13,6 +13,15 @@ from parity import SEED
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _record(figures, name):
+    """The measured figures go where ORT_STUDY_DIR says (set when a round's figures are recorded for profiles/);
+    a plain test run writes nothing into the tree."""
+    d = os.environ.get("ORT_STUDY_DIR")
+    if d:
+        os.makedirs(d, exist_ok=True)
+        json.dump(figures, open(os.path.join(d, name), "w"), indent=1)
 
 
 @pytest.fixture(scope="module")
@@ -45,8 +54,7 @@ def _study(osys, ctx, phase, n):
 def test_fastd_per_ray_deviation(ctx):
     osys, c = ctx
     out = [_study(osys, c, 2, 200_000), _study(osys, c, 1, 400_000)]
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "fastd_study_rays.json"), "w"), indent=1)
+    _record(out, "fastd_study_rays.json")
     p = out[0]
     assert p["status_agree"] > 0.99999         # discrete outcomes flip for < 1e-5 of the rays
     assert p["dpos_bins_median"] < 1e-9        # landing error ~1e-12 of a bin: far inside 1e-10 relative
@@ -73,7 +81,7 @@ def test_fastd_image_deviation(ctx):
                l1_fraction=l1 / tot, lost_fp64=int(c64[1]), lost_fp32=int(c32[1]),
                isect_fp64=int(c64[3]), isect_fp32=int(c32[3]),
                max_abs_bin_delta=int(np.abs(i64[1].astype(np.int64) - i32[1]).max()))
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "fastd_study_image.json"), "w"), indent=1)
+    _record(res, "fastd_study_image.json")
     # totals agree to a few 1e-4; rays hop to a neighbouring bin (each hop counts twice in L1)
     assert abs(res["binned_fp32"] - tot) <= 8
     assert abs(res["lost_fp32"] - res["lost_fp64"]) <= 8

@@ -83,7 +83,11 @@ def test_end_to_end_settings_file_run(hip_library, tmp_path):
     tot = np.fromfile(folder / f"{stem}_image-total.dat", np.float64)
     assert tot.sum() == res.image.sum() and tot.sum() > 0
     rows = open(folder / "trans-stats.dat").read().splitlines()
-    assert len(rows) == 2 and rows[0].lstrip().startswith("r/%")
+    assert len(rows) == 4 and rows[0].lstrip().startswith("r/%")              # header and record: two 79-column lines each
+    # the record's layout is the reference program's (flang list-directed): same line breaks, same fields 3..12
+    ref_rows = str(g["stats"]).splitlines()
+    assert rows[:2] == ref_rows[:2] and rows[3] == ref_rows[3]
+    assert rows[2].split(" , ")[2:] == ref_rows[2].split(" , ")[2:]
     # the reference program printed 2.46 % / 60.07 % for this set-up at 1e6 rays
     assert abs(res.ring_transmitted - 2.46) < 0.1 and abs(res.point_transmitted - 60.07) < 0.3
     ring, point = _ref_layers(g)
