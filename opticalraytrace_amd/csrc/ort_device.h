@@ -76,6 +76,10 @@ template <class T> __device__ inline T unit_from(uint32_t w)
 }
 __device__ inline uint32_t draw_word(uint64_t h, bool odd) { return odd ? (uint32_t)h : (uint32_t)(h >> 32); }
 
+// the i1 ballot builtin: an s_and of the compare mask with exec.  (HIP's __ballot(int) first
+// materialises the predicate as 0/1 in a VGPR and compares it again: two VALU instructions.)
+__device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 // Per-ray draw source of the parity / debug entry.  peek() is the next uniform, advance(c)
 // consumes it where c.  Keyed stream, or an explicit table: draw k at table[k*stride].
 struct Draws {
@@ -109,6 +113,11 @@ struct Draws {
     __device__ inline void take(bool cnd, const Draws &o) { k = cnd ? o.k : k; c = cnd ? o.c : c; }   // same stream
     template <class T> __device__ inline T peek_as() const { return (T)peek(); }
     template <class T> __device__ inline T next_as() { return (T)next(); }
+    template <class T> __device__ inline void next_pair_as(bool cnd, T &u1, T &u2)
+    {
+        u1 = peek_as<T>(); advance(cnd);
+        u2 = peek_as<T>(); advance(cnd);
+    }
 };
 
 // keyed-only variant of the bulk kernels that walk a list they do not know at compile time
@@ -139,6 +148,21 @@ struct KeyedDraws {
         const T u = peek_as<T>();
         c += 1ull;
         return u;
+    }
+    // two consecutive draws for the lanes `cnd` (a rejection loop's pair, src/random_mod.f90:68-69).  Draws 2j and
+    // 2j + 1 are the two halves of ONE hash: when every lane of the wave stands at an even draw — it does in the
+    // Box-Muller loops of the crs and isors sources, which start at draw 2 / 0 and consume pairs — one hash serves both
+    template <class T> __device__ inline void next_pair_as(bool cnd, T &u1, T &u2)
+    {
+        if (!wave_any((c & 1ull) != 0)) {
+            const uint64_t h = mix64(base + kGolden * ((c >> 1) + 1ull));
+            u1 = unit_from<T>((uint32_t)(h >> 32));
+            u2 = unit_from<T>((uint32_t)h);
+            c += cnd ? 2ull : 0ull;
+        } else {
+            u1 = peek_as<T>(); advance(cnd);
+            u2 = peek_as<T>(); advance(cnd);
+        }
     }
     __device__ inline uint64_t ray() const { return c >> 24; }
     // queue image of the state (one 64-bit word)
@@ -192,6 +216,7 @@ struct ProgDraws {
     // the dynamic interface is never instantiated for a program (surface_step takes the static one)
     template <class T> __device__ inline T peek_as() const { return T(0.5); }
     __device__ inline void advance(bool) {}
+    template <class T> __device__ inline void next_pair_as(bool, T &u1, T &u2) { u1 = u2 = T(0.5); }
 };
 
 // Division and square root of the traced arithmetic, by type.
@@ -231,9 +256,6 @@ __device__ inline float sqrt_t(float x) { return __builtin_amdgcn_sqrtf(x); }
 #define ORT_SQRT(x) sqrt_t(x)
 #define ORT_DIV(a, b) div_t(a, b)
 
-// the i1 ballot builtin: an s_and of the compare mask with exec.  (HIP's __ballot(int) first
-// materialises the predicate as 0/1 in a VGPR and compares it again: two VALU instructions.)
-__device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // ORT_RARE(site, cond): a lane raises its `rare` flag.  -DORT_DBG_RARE (development) also counts
 // the raises per site in ort_dbg_rare[].
 #ifdef ORT_DBG_RARE
@@ -1105,10 +1127,8 @@ __device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws)
     T x = T(0.), y = T(0.), s = T(1.);
     bool more = true;
     while (wave_any(more)) {                               // do while(s >= 1.)
-        T u1 = draws.template peek_as<T>();
-        draws.advance(more);
-        T u2 = draws.template peek_as<T>();
-        draws.advance(more);
+        T u1, u2;
+        draws.template next_pair_as<T>(more, u1, u2);
         T xn = T(-1.) + u1 * (T(1.) - T(-1.));             // ranu(-1., 1.)
         T yn = T(-1.) + u2 * (T(1.) - T(-1.));
         x = more ? xn : x;
@@ -1136,10 +1156,8 @@ __device__ inline void rang(D &draws, T sigma, T &gx, T &gy)
     T x = T(0.), y = T(0.), s = T(1.);
     bool more = true;
     while (wave_any(more)) {                               // do while(s >= 1.)
-        T u1 = draws.template peek_as<T>();
-        draws.advance(more);
-        T u2 = draws.template peek_as<T>();
-        draws.advance(more);
+        T u1, u2;
+        draws.template next_pair_as<T>(more, u1, u2);
         T xn = T(-1.) + u1 * (T(1.) - T(-1.));             // ranu(-1., 1.)
         T yn = T(-1.) + u2 * (T(1.) - T(-1.));
         x = more ? xn : x;
@@ -1219,19 +1237,43 @@ __device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws)
 // cell s with cdf[s] <= ray < cdf[s+1] (binary search in the 2 MB table, L2-resident), at a
 // uniform point of the 9.8 um cell, aimed at a uniform point of the lens disc.  Returns false
 // when the histogram is exhausted (the reference re-uses a stale ray there).
+// `hint` (the bulk program kernel): a wave emits successive batches of INCREASING ray indices, so the cell of one
+// batch's first ray bounds the next batch's cells from below, and they lie a few cells further on (1e9 rays over
+// 2^18 cells): a galloping search from the hint takes ~6 dependent loads instead of 18.  Same cell either way:
+// the largest s with cdf[s] <= ray.
 template <class T, class Sys, class D>
-__device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r, D &draws, uint64_t ray)
+__device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r, D &draws, uint64_t ray, int *hint = nullptr)
 {
     const long long key = (long long)ray;
     const bool have = cdf != nullptr && key < cdf[ORT_IMAGE_SOURCE_CELLS];
     int lo = 0, hi = ORT_IMAGE_SOURCE_CELLS;                 // cdf[lo] <= key < cdf[hi]
     if (cdf != nullptr) {
-        for (int it = 0; it < 18; ++it) {                    // 2^18 cells
-            const int mid = (lo + hi) >> 1;
-            const bool up = cdf[mid] <= key;
-            lo = up ? mid : lo;
-            hi = up ? hi : mid;
+        if (hint != nullptr && *hint >= 0) {
+            lo = *hint;                                      // wave-uniform, cdf[lo] <= key
+            int span = 1;
+            for (;;) {
+                const int probe = lo + span < ORT_IMAGE_SOURCE_CELLS ? lo + span : ORT_IMAGE_SOURCE_CELLS;
+                const bool up = lo + span < ORT_IMAGE_SOURCE_CELLS && cdf[probe] <= key;
+                if (!wave_any(up)) break;
+                lo = up ? probe : lo;
+                span = up ? span * 2 : span;
+            }
+            hi = lo + span < ORT_IMAGE_SOURCE_CELLS ? lo + span : ORT_IMAGE_SOURCE_CELLS;
+            while (wave_any(hi - lo > 1)) {
+                const int mid = (lo + hi) >> 1;
+                const bool up = cdf[mid] <= key;
+                lo = up ? mid : lo;
+                hi = up ? hi : mid;
+            }
+        } else {
+            for (int it = 0; it < 18; ++it) {                // 2^18 cells
+                const int mid = (lo + hi) >> 1;
+                const bool up = cdf[mid] <= key;
+                lo = up ? mid : lo;
+                hi = up ? hi : mid;
+            }
         }
+        if (hint != nullptr) *hint = __builtin_amdgcn_readfirstlane(lo);     // lane 0 holds the batch's smallest ray index
     }
     const int i = lo % 512 + 1, j = lo / 512 + 1;            // first, second index of imgin
     const T dx = T(5000e-6) / T(512.);
@@ -1259,7 +1301,8 @@ __device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r
 // cost registers (143 vs 121 VGPRs, i.e. 3 vs 4 waves per SIMD) on the path that is benchmarked.
 // EMITTER >= 0 (surface programs): the emitter is the compile-time constant ORT_EMIT_* of the program.
 template <class T, bool ANYSRC, bool FILT = false, int EMITTER = -1, class Sys, class D>
-__device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf, bool &rare)
+__device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf, bool &rare,
+                           int *img_hint = nullptr)
 {
     if constexpr (EMITTER >= 0) {
         bool unused = false;                              // the emitters other than ring / point are literal throughout
@@ -1268,7 +1311,7 @@ __device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64
         else if constexpr (EMITTER == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray);
         else if constexpr (EMITTER == ORT_EMIT_CRS) emit_crs<T>(S, r, draws);
         else if constexpr (EMITTER == ORT_EMIT_ISORS) return emit_isors<T>(S, r, draws) ? -1 : ORT_ST_NO_INTERSECTION;
-        else return emit_image<T>(S, cdf, r, draws, ray) ? -1 : ORT_ST_LOST_TELESCOPE;
+        else return emit_image<T>(S, cdf, r, draws, ray, img_hint) ? -1 : ORT_ST_LOST_TELESCOPE;
         (void)unused;
         return -1;
     }

@@ -798,6 +798,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     auto defer = [&](uint64_t i) { a.redo_list[atomicAdd(&a.redo_ctl[0], 1u)] = (uint32_t)(a.defer_base + i); };
 
     uint64_t next = lo;
+    int img_hint = -1;           // image source: the cell of the previous batch's first ray (emit_image)
     int qcount = 0, qhead = 0;
     int ccount = 0, chead = 0;
     const uint64_t z0 = zray_of(a.rng_base, a.first_ray);      // ProgDraws::init_index (a launch holds < 2^32 rays)
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 if constexpr (sdraws) d.init_index(z0, (uint32_t)ic, 0);
                 else d.init_keyed(a.rng_base, a.first_ray + ic, 0);
                 int est;
-                if constexpr (fixed) est = emit<T, false, FILT, Prog<PROG>::emitter>(*csys, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
+                if constexpr (fixed) est = emit<T, false, FILT, Prog<PROG>::emitter>(*csys, phase, r, d, a.first_ray + ic, a.img_cdf, rare, &img_hint);
                 else est = emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
                 st = est < 0 ? st : est;
             }

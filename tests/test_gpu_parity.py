@@ -585,3 +585,28 @@ def test_scattering_pipeline_equals_monolithic_and_lockstep_kernels(ctxs, name):
             assert np.array_equal(out[0][0], out[v][0]), (name, n, v)
             assert np.array_equal(out[0][1], out[v][1]), (name, n, v, out[0][1], out[v][1])
     assert int(out[0][1][5]) > 100_000                      # rays do get through
+
+
+@pytest.mark.parametrize("name", ["small_scatter_c", "small_scatter_bc"])
+def test_uniform_zero_in_the_walk_and_the_fresnel_steps(ctxs, name):
+    """ORT-RNG-v2 uniforms carry 32 bits (u = w 2^-32): an exact u == 0 occurs ~5 times per 1e9-ray layer (the
+    reference's 53-bit random_number practically never gives it).  Table mode, zeros planted at every draw position
+    of the scattering walk and the Fresnel steps: tauint's tau = -log(0) = +inf (the ray goes to the wall: benign),
+    `ran2() <= R` with u = 0 (always reflects, R > 0) — HIP and the CPU checker must agree on every outcome."""
+    osys, ctx = ctxs(name)
+    orc = _oracle(osys)
+    rng = np.random.default_rng(11)
+    n, nu = 6000, 48
+    u = rng.random((nu, n))
+    for k in range(nu):                        # ray j has its k-th draw zero for j = k (mod nu); one ray in 7 has ALL draws of a stride zero
+        u[k, k::nu] = 0.0
+    u[::3, 5::7] = 0.0
+    want = orc.trace_rays(2, n, u=u)
+    got = ctx.trace_rays(2, n, u=u)
+    assert np.array_equal(got["status"], want["status"])
+    assert np.array_equal(got["n_draws"], want["n_draws"]) and np.array_equal(got["n_isect"], want["n_isect"])
+    b = want["status"] == 0
+    assert np.array_equal(got["bin_xy"][:, b], want["bin_xy"][:, b])
+    reach = want["status"] <= 2
+    assert reach.sum() > 100 and rel_err(got["pos_dir"][:, reach], want["pos_dir"][:, reach]) <= 1e-9
+    assert want["n_draws"].max() > 12          # rays did walk
