@@ -106,7 +106,10 @@ struct TraceArgs {
     // (kNoRay: the slot holds no ray), intersections evaluated so far.  A wave of the front kernel fills the slots
     // of its own ray range from the bottom and marks the rest empty: no shared counter (one returning atomic per
     // hand-over on ONE address serialised the whole kernel: 1.4 ms per 4e6 rays, 73 % of the wave cycles waiting)
+    // A ray is handed over when it ARRIVES at the last scattering wall: the continuation starts with the rest of that
+    // surface's step (back test, move by cont_t, normal, Fresnel) in its own filtered arithmetic.
     double *cont_pos_dir;
+    double *cont_t;
     uint64_t *cont_draw;
     int32_t *cont_nis;
     uint64_t cont_cap;
@@ -865,6 +868,23 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 nis = a.cont_nis[ic];
                 r.pos = {T(a.cont_pos_dir[0 * ns_in + ic]), T(a.cont_pos_dir[1 * ns_in + ic]), T(a.cont_pos_dir[2 * ns_in + ic])};
                 r.dir = {T(a.cont_pos_dir[3 * ns_in + ic]), T(a.cont_pos_dir[4 * ns_in + ic]), T(a.cont_pos_dir[5 * ns_in + ic])};
+                // the rest of the step of surface k0 - 1, where the ray arrived after its walk (lens.f90:283-297, :334-348):
+                // back test, move, normal, Fresnel — surface_step's tail for a wall of the bottle (no aperture stop)
+                const typename SysTypes<T>::Surf &sw = surf[k0 - 1];
+                const SurfAuxT<T> &axw = AUX[k0 - 1];
+                const unsigned wflags = (unsigned)__builtin_amdgcn_readfirstlane((int)sw.flags);
+                const int wlost = (wflags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE;
+                const bool back = act && (wflags & ORT_F_SCATTER) != 0 && r.dir.z < T(0.);
+                const bool on = act && !back;
+                r.pos = vadd(r.pos, vscale(r.dir, T(a.cont_t[ic])));
+                const VecT<T> Nraw = {T(0.0), sw.cy - r.pos.y, sw.cz - r.pos.z};
+                // (a ray that left its walk by the reference's `out` test is not on the wall: no estimate of |N| holds)
+                const VecT<T> Nw = vnormalise_f<FILT, T>(Nraw, on, rare, true);
+                const T uw = d.template peek_as<T>();
+                d.advance(on);
+                const bool refl = reflect_refract<FILT, false, T>(r.dir, Nw, sw.n1, sw.n2, sw.eta, axw.eta2, uw, on, rare);
+                const bool diesw = on && refl && (wflags & ORT_F_SKIP_ON_REFLECT) != 0;
+                st = (back || diesw) ? wlost : st;
             } else if (MODE == MODE_RESIDENT) {
                 if constexpr (sdraws) d.init_index(z0, (uint32_t)ic, a.draw_base);
                 else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
@@ -1056,12 +1076,13 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
     };
     // behind the last scattering surface: the next free slots of this wave's part of the hand-over bundle
     uint64_t handed = 0;
-    auto hand_over = [&](bool cond, const Ray &r, const KeyedDraws &d, int nis) {
+    auto hand_over = [&](bool cond, const Ray &r, double t, const KeyedDraws &d, int nis) {
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(cond);
         if (cond) {
             const uint64_t j = lo + handed + (uint64_t)lane_prefix(mask), cap = a.cont_cap;
             a.cont_pos_dir[0 * cap + j] = r.pos.x; a.cont_pos_dir[1 * cap + j] = r.pos.y; a.cont_pos_dir[2 * cap + j] = r.pos.z;
             a.cont_pos_dir[3 * cap + j] = r.dir.x; a.cont_pos_dir[4 * cap + j] = r.dir.y; a.cont_pos_dir[5 * cap + j] = r.dir.z;
+            a.cont_t[j] = t;
             a.cont_draw[j] = d.c;
             a.cont_nis[j] = nis;
         }
@@ -1103,7 +1124,8 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             const bool still = walking && ok && !out && !at_wall;
             const bool arrived = walking && ok && !still;
             push(WQ, wcount, whead, still, r, t, d, nis, k);
-            push(AQ, acount, ahead, arrived, r, t, d, nis, k);
+            push(AQ, acount, ahead, arrived && k < klast, r, t, d, nis, k);
+            hand_over(arrived && k >= klast, r, t, d, nis);
             if (act && ended >= 0) end_ray(ended, nis);
             __builtin_amdgcn_wave_barrier();
         } else if (acount >= 64 || (acount > 0 && !may_emit)) {
@@ -1129,16 +1151,13 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             const bool reflected = reflect_refract<false, true, double>(r.dir, N, s.n1, s.n2, s.eta, 0., u, live, unused);
             const bool dies = live && reflected && (flags & ORT_F_SKIP_ON_REFLECT) != 0;
             ended = dies ? ((flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE) : ended;
-            const bool on = live && !dies;
-            hand_over(on && k >= klast, r, d, nis);
-            const bool enter = on && k < klast;
+            const bool enter = live && !dies;           // (rays arriving at the LAST wall never come here: handed over)
             bool walking = false, arrived = false;
             const int k1 = enter ? k + 1 : k;
-            if (wave_any(enter)) {                       // (a wavefront of rays that all arrived at the last wall skips it)
-                scat_enter(surf, k1, kind0, enter, r, d, nis, t, walking, arrived, ended);
-                push(WQ, wcount, whead, walking, r, t, d, nis, k1);
-                push(AQ, acount, ahead, arrived, r, t, d, nis, k1);
-            }
+            scat_enter(surf, k1, kind0, enter, r, d, nis, t, walking, arrived, ended);
+            push(WQ, wcount, whead, walking, r, t, d, nis, k1);
+            push(AQ, acount, ahead, arrived && k1 < klast, r, t, d, nis, k1);
+            hand_over(arrived && k1 >= klast, r, t, d, nis);
             if (act && ended >= 0) end_ray(ended, nis);
             __builtin_amdgcn_wave_barrier();
         } else if (may_emit) {
@@ -1156,7 +1175,8 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             bool walking, arrived;
             scat_enter(surf, 0, kind0, act && ended < 0, r, d, nis, t, walking, arrived, ended);
             push(WQ, wcount, whead, walking, r, t, d, nis, 0);
-            push(AQ, acount, ahead, arrived, r, t, d, nis, 0);
+            push(AQ, acount, ahead, arrived && klast > 0, r, t, d, nis, 0);
+            hand_over(arrived && klast <= 0, r, t, d, nis);
             if (act && ended >= 0) end_ray(ended, nis);
             __builtin_amdgcn_wave_barrier();
         } else {
@@ -1326,6 +1346,7 @@ struct ort_ctx {
     int prog[2];                 // per phase: PROG_* the staged system matches (match_program)
     int scat_k0[2];              // per phase: > 0: the scattering pipeline applies, its continuation starts at this surface
     double *d_cont_pos_dir;      // hand-over bundle of the scattering pipeline (scatter_front_kernel), cont_cap entries
+    double *d_cont_t;
     uint64_t *d_cont_draw;
     int32_t *d_cont_nis;
     uint64_t cont_cap;
@@ -1593,7 +1614,7 @@ int ort_destroy(ort_ctx *c)
     for (int k = 0; k < kSysSlots; ++k) if (c->sys_ev[k]) (void)hipEventDestroy(c->sys_ev[k]);
     (void)hipFree(c->d_sys_ring); (void)hipHostFree(c->h_sys_ring); (void)hipFree(c->own_image); (void)hipFree(c->own_counters); (void)hipFree(c->d_replicas); (void)hipFree(c->d_img_cdf);
     (void)hipFree(c->d_redo_list); (void)hipFree(c->d_redo_ctl); (void)hipFree(c->d_work);
-    (void)hipFree(c->d_cont_pos_dir); (void)hipFree(c->d_cont_draw); (void)hipFree(c->d_cont_nis);
+    (void)hipFree(c->d_cont_pos_dir); (void)hipFree(c->d_cont_draw); (void)hipFree(c->d_cont_nis); (void)hipFree(c->d_cont_t);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ORT_OK;
@@ -1732,9 +1753,10 @@ static int reserve_handover(ort_ctx *c, uint64_t n_rays)
     if (want <= c->cont_cap) return ORT_OK;
     { const int rc = close_group(c); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(c->d_cont_pos_dir); (void)hipFree(c->d_cont_draw); (void)hipFree(c->d_cont_nis);
-    c->d_cont_pos_dir = nullptr; c->d_cont_draw = nullptr; c->d_cont_nis = nullptr; c->cont_cap = 0;
+    (void)hipFree(c->d_cont_pos_dir); (void)hipFree(c->d_cont_draw); (void)hipFree(c->d_cont_nis); (void)hipFree(c->d_cont_t);
+    c->d_cont_pos_dir = nullptr; c->d_cont_draw = nullptr; c->d_cont_nis = nullptr; c->d_cont_t = nullptr; c->cont_cap = 0;
     HIP_TRY(hipMalloc(&c->d_cont_pos_dir, 6 * want * sizeof(double)));
+    HIP_TRY(hipMalloc(&c->d_cont_t, want * sizeof(double)));
     HIP_TRY(hipMalloc(&c->d_cont_draw, want * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&c->d_cont_nis, want * sizeof(int32_t)));
     c->cont_cap = want;
@@ -1772,7 +1794,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     if (pipeline) {
         const int rc = reserve_handover(c, total);
         if (rc) return rc;
-        a0.cont_pos_dir = c->d_cont_pos_dir; a0.cont_draw = c->d_cont_draw; a0.cont_nis = c->d_cont_nis;
+        a0.cont_pos_dir = c->d_cont_pos_dir; a0.cont_t = c->d_cont_t; a0.cont_draw = c->d_cont_draw; a0.cont_nis = c->d_cont_nis;
         a0.cont_cap = c->cont_cap; a0.cont_k0 = c->scat_k0[a0.phase - 1];
     }
     if (deferring) {
@@ -1820,8 +1842,9 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
         if (ext_timed) { c->launch_ev[0] = c->ring[slot][0]; c->launch_ev[1] = c->ring[slot][1]; }
         if (pipeline) {
             // one wavefront per workgroup, ~2 rounds of the 7 workgroups a CU holds
+            static const int max_waves = env_int("ORT_SCAT_WAVES", 3584);       // development knob
             uint64_t waves = (a.n_rays + 127) / 128;
-            if (waves > 3584) waves = 3584;
+            if (waves > (uint64_t)max_waves) waves = (uint64_t)max_waves;
             if (anysrc_emitter) hipLaunchKernelGGL(scatter_front_kernel<true>, dim3((unsigned)waves), dim3(64), 0, c->stream, a);
             else hipLaunchKernelGGL(scatter_front_kernel<false>, dim3((unsigned)waves), dim3(64), 0, c->stream, a);
             HIP_TRY(hipGetLastError());
