@@ -158,7 +158,7 @@ typedef struct ort_ctx ort_ctx;
 /* Library / device probing. */
 int ort_abi_version(void);
 /* Hash (first 16 hex digits of SHA-256) of the kernel sources the library was built from
- * (csrc/Makefile: ort_hip.hip, ort_device.h, ort_fastd.h, include/ort.h in that order), so a host
+ * (csrc/Makefile: ort_hip.hip, ort_device.h, ort_fastd.h, ort_pair.h, include/ort.h in that order), so a host
  * — and the tests — can tell a stale binary from the sources next to it. */
 const char *ort_build_id(void);
 const char *ort_last_error(void);
@@ -302,7 +302,9 @@ int ort_set_precision(ort_ctx *ctx, int precision);
  * whose third draw already puts them outside the first aperture are counted without being emitted
  * (queued surface-program kernels); bit 4 set = scattering bottles run the monolithic kernel (the random walk
  * compiled into the surface walk), clear (default) = the scattering pipeline (walk stages on full wavefronts in
- * front of the lean walk).  All combinations produce bit-identical rays, images and counters.  Default 1. */
+ * front of the lean walk); bit 5 set = the fp32 surface programs trace one ray per lane, clear (default) = two
+ * rays per lane (packed fp32 arithmetic).  All combinations produce bit-identical rays, images and counters.
+ * Default 1. */
 int ort_set_kernel_variant(ort_ctx *ctx, int variant);
 
 #ifdef __cplusplus

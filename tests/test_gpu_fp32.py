@@ -96,22 +96,23 @@ def test_fp32_image_deviation(ctx):
 @pytest.mark.parametrize("name", ["large", "large_iris_before", "small_iris_after", "ellipse",
                                   "small_f60_nobottle", "large_crs"])
 def test_fp32_queued_kernel_equals_fp32_lockstep_kernel(hip_library, name):
-    """fp32 runs on the queued program kernels (variant bit 0, default) exactly as fp64 does; per-ray
-    arithmetic and draw order are those of the fp32 lockstep kernel, so images and counters of the
-    two are identical — for every surface program and for a system that takes the generic walk."""
+    """fp32 runs on the queued program kernels (variant bit 0, default) exactly as fp64 does — with TWO RAYS
+    PER LANE (csrc/ort_pair.h: packed fp32 arithmetic; variant bit 5 switches back to one ray per lane); per-ray
+    arithmetic and draw order are those of the fp32 lockstep kernel, so images and counters of all of them are
+    identical — for every surface program and for a system that takes the generic walk."""
     from opticalraytrace_amd.capi import Context
     _, osys = make_system(name)
     n = 300_000
     with Context(osys) as c:
         c.set_precision(1)
         out = []
-        for variant in (1, 0, 9):            # queued; lockstep; queued without the ring cull
+        for variant in (1, 0, 9, 33, 41):    # two rays per lane; lockstep; ... without the ring cull; one ray per lane; ... without the cull
             c.set_kernel_variant(variant)
             c.reset()
             c.trace(1, 0, n, SEED)
             c.trace(2, 5, n, SEED)
             out.append(c.read())
-        for m in (1, 63, 64, 65, 129, 4097):              # ragged sizes: partial batches, queue flush at the tail
+        for m in (1, 63, 64, 65, 127, 128, 129, 191, 193, 4097):   # ragged sizes: partial batches of 128, queue flush at the tail
             res = []
             for variant in (1, 0):
                 c.set_kernel_variant(variant)
@@ -122,7 +123,8 @@ def test_fp32_queued_kernel_equals_fp32_lockstep_kernel(hip_library, name):
     (iq, cq), (il, cl) = out[0], out[1]
     assert int(cq[2]) > n and int(cq[3]) > n
     assert np.array_equal(iq, il) and np.array_equal(cq, cl)
-    assert np.array_equal(iq, out[2][0]) and np.array_equal(cq, out[2][1])
+    for k in (2, 3, 4):
+        assert np.array_equal(iq, out[k][0]) and np.array_equal(cq, out[k][1]), (name, k)
 
 
 def test_config4_fp32_full_size(ctx):
