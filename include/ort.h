@@ -302,9 +302,9 @@ int ort_set_precision(ort_ctx *ctx, int precision);
  * whose third draw already puts them outside the first aperture are counted without being emitted
  * (queued surface-program kernels); bit 4 set = scattering bottles run the monolithic kernel (the random walk
  * compiled into the surface walk), clear (default) = the scattering pipeline (walk stages on full wavefronts in
- * front of the lean walk); bit 5 set = the fp32 surface programs trace one ray per lane, clear (default) = two
- * rays per lane (packed fp32 arithmetic).  All combinations produce bit-identical rays, images and counters.
- * Default 1. */
+ * front of the lean walk); bit 5 set = the fp32 surface programs trace two rays per lane with packed fp32
+ * arithmetic (measured slower on gfx950: csrc/ort_pair.h), clear (default) = one ray per lane.  All
+ * combinations produce bit-identical rays, images and counters.  Default 1. */
 int ort_set_kernel_variant(ort_ctx *ctx, int variant);
 
 #ifdef __cplusplus

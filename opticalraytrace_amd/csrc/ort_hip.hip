@@ -964,8 +964,9 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
 
 
 // ---------------------------------------------------------------------------
-// trace_pair_kernel<PROG>: the fused surface programs in fp32 with TWO RAYS PER LANE (ort_pair.h): a wavefront
-// carries 128 rays, every add / mul / fma of the walk is a packed instruction serving both rays of a lane.  The
+// trace_pair_kernel<PROG> (opt-in, kernel variant bit 5; NOT the default: it is slower, ort_pair.h says why): the
+// fused surface programs in fp32 with TWO RAYS PER LANE: a wavefront carries 128 rays, every add / mul / fma of
+// the walk is a packed instruction serving both rays of a lane.  The
 // structure is trace_queue_kernel's — contiguous ray ranges per wave, segment 0 (ring cull), segment 1, wave-private
 // LDS queue, segment 2 on full wavefronts — with batches of 128; per-ray arithmetic, draws and outcomes are those
 // of the one-ray fp32 kernels, bit for bit.
@@ -1686,8 +1687,9 @@ static void launch_lean(ort_ctx *c, int mode, const TraceArgs &a, int grid)
     int prog = c->prog[a.phase - 1];
     if (mode != MODE_FUSED && a.draw_base != (a.phase == 1 ? 4 : 2)) prog = PROG_GENERIC;
     if constexpr (std::is_same<T, float>::value) {
-        // fp32, fused, a surface program: two rays per lane (variant bit 5 set: one ray per lane, the A/B baseline)
-        if (mode == MODE_FUSED && prog != PROG_GENERIC && (c->variant & 32) == 0) {
+        // variant bit 5: fp32, fused, a surface program with two rays per lane (ort_pair.h) — measured SLOWER than one
+        // ray per lane on gfx950 (0.226 vs 0.217 ms per 1e7 point rays), see ort_pair.h: kept as the A/B that shows it
+        if (mode == MODE_FUSED && prog != PROG_GENERIC && (c->variant & 32) != 0) {
             switch (prog) {
 #define ORT_PAIR(P) case P: ORT_LAUNCH((trace_pair_kernel<P>)); return;
                 ORT_PROGRAMS(ORT_PAIR)

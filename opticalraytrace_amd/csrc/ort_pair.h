@@ -1,13 +1,23 @@
-// ort_pair.h — the fp32 path (BASELINE configs[4]) with TWO RAYS PER LANE.
+// ort_pair.h — the fp32 path (BASELINE configs[4]) with TWO RAYS PER LANE: an experiment kept as evidence
+// (kernel variant bit 5), NOT the default — it is bit-identical to the one-ray kernels and 4 % SLOWER.
 //
-// gfx950 issues one vector instruction per cycle slot whatever its width: an fp32 add / mul / fma on one value
-// per lane runs at the fp64 rate (78.6 TFLOP/s); the 157 TFLOP/s fp32 peak exists only for the PACKED forms
-// v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, which work on a pair of values held in a 64-bit register pair.
-// Pairing unrelated scalars of ONE ray does not pay (the operands must first be moved next to each other: the
-// compiler's own attempt spends a v_mov per packed operand).  So a lane carries two independent rays, A and B,
-// component by component in register pairs (x_A, x_B), (y_A, y_B), ...: every arithmetic instruction of the walk is
-// then packed by construction and serves two rays; what has no packed form — compares, selects, v_rcp_f32 /
-// v_sqrt_f32, conversions, the integer hash — is issued once per ray.
+// The idea.  The 157 TFLOP/s fp32 vector peak of the MI355X exists only for the PACKED forms v_pk_add_f32 /
+// v_pk_mul_f32 / v_pk_fma_f32, which work on a pair of values held in a 64-bit register pair.  Pairing unrelated
+// scalars of ONE ray does not pay (the operands must first be moved next to each other: the compiler's SLP
+// vectoriser spends a v_mov per packed operand).  So a lane carries two independent rays, A and B, component by
+// component in register pairs (x_A, x_B), (y_A, y_B), ...: every arithmetic instruction of the walk is then packed
+// by construction and serves two rays; what has no packed form — compares, selects, v_rcp_f32 / v_sqrt_f32,
+// conversions, the integer hash — is issued once per ray.  Static count of the point program: 703 packed
+// arithmetic instructions + 1 147 others per PAIR of rays against 2 x 1 279 for two single rays: 28 % fewer.
+//
+// Why it loses (tools/ubench3.hip on the MI355X, issue cost per instruction per SIMD, saturated, in s_memtime ticks):
+//   v_mul_f32 / v_add_f32 1.82     v_fma_f32 2.43     v_fma_f64 2.80     v_pk_{mul,add,fma}_f32 2.88
+//   v_rcp_f32 / v_sqrt_f32 5.46    v_cmp_f32 6.28
+// A packed instruction costs 1.58 two-operand fp32 instructions: it is worth two of them only for fma.  This path is
+// 583 mul/add + 119 fma per ray, so packing buys 1.26 x on 55 % of the instructions, and the pair kernel pays for it
+// with the second ray's selects and compares staying un-packed, more hazard nops (203 vs 56: v_cmp -> v_cndmask
+// through SGPR masks), 84 VGPRs and 29-33 KB of LDS (5 waves per SIMD instead of 8).  Measured, 1e7 point rays:
+// 0.2261 ms (two rays per lane) vs 0.2170 ms (one ray per lane); ring loop 0.0830 vs 0.0735 ms.
 //
 // The arithmetic per ray is, operation for operation and in the same order, that of the one-ray fp32
 // instantiations of ort_device.h (literal predicates; hardware reciprocal + one correction step for '/', hardware
