@@ -8,9 +8,9 @@
 #include <vector>
 
 constexpr int ITERS = 512;
-enum Op { FMA64, FMA32, MUL32, ADD32, PKFMA, PKMUL, PKADD, RCP32, SQRT32, CMP32, NOPS };
+enum Op { FMA64, FMA32, MUL32, ADD32, PKFMA, PKMUL, PKADD, RCP32, SQRT32, CMP32, CMP64VCC, CMP64SGPR, CMP64SGPR4, NOPS };
 const char *names[] = {"v_fma_f64", "v_fma_f32", "v_mul_f32", "v_add_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_rcp_f32", "v_sqrt_f32",
-                       "v_cmp_gt_f32"};
+                       "v_cmp_gt_f32", "v_cmp_f64 -> vcc", "v_cmp_f64 -> sgpr", "v_cmp_f64 -> 4 sgprs"};
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <int OP, int CHAINS>
@@ -40,6 +40,14 @@ __global__ void k(double *out, unsigned long long *cycles, double seed)
                 else if (OP == PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[c]) : "v"(yp));
                 else if (OP == RCP32) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[c]));
                 else if (OP == SQRT32) asm volatile("v_sqrt_f32 %0, %0" : "+v"(f[c]));
+                else if (OP == CMP64VCC) asm volatile("v_cmp_gt_f64 vcc, %0, %1" : : "v"(v[c]), "v"(y) : "vcc");
+                else if (OP == CMP64SGPR) asm volatile("v_cmp_gt_f64 s[40:41], %0, %1" : : "v"(v[c]), "v"(y) : "s40", "s41");
+                else if (OP == CMP64SGPR4) {
+                    if ((c & 3) == 0) asm volatile("v_cmp_gt_f64 s[40:41], %0, %1" : : "v"(v[c]), "v"(y) : "s40", "s41");
+                    else if ((c & 3) == 1) asm volatile("v_cmp_gt_f64 s[42:43], %0, %1" : : "v"(v[c]), "v"(y) : "s42", "s43");
+                    else if ((c & 3) == 2) asm volatile("v_cmp_gt_f64 s[44:45], %0, %1" : : "v"(v[c]), "v"(y) : "s44", "s45");
+                    else asm volatile("v_cmp_gt_f64 s[46:47], %0, %1" : : "v"(v[c]), "v"(y) : "s46", "s47");
+                }
                 else if (OP == CMP32) { unsigned long long m; asm volatile("v_cmp_gt_f32 %0, %1, %2" : "=s"(m) : "v"(f[c]), "v"(yf)); acc ^= m; }
             }
         }
@@ -74,6 +82,6 @@ void run(int waves_per_simd)
 
 int main()
 {
-    RUN_ALL(FMA64) RUN_ALL(FMA32) RUN_ALL(MUL32) RUN_ALL(ADD32) RUN_ALL(PKFMA) RUN_ALL(PKMUL) RUN_ALL(PKADD) RUN_ALL(RCP32) RUN_ALL(SQRT32) RUN_ALL(CMP32)
+    RUN_ALL(FMA64) RUN_ALL(FMA32) RUN_ALL(MUL32) RUN_ALL(ADD32) RUN_ALL(PKFMA) RUN_ALL(PKMUL) RUN_ALL(PKADD) RUN_ALL(RCP32) RUN_ALL(SQRT32) RUN_ALL(CMP32) RUN_ALL(CMP64VCC) RUN_ALL(CMP64SGPR) RUN_ALL(CMP64SGPR4)
     return 0;
 }
