@@ -48,7 +48,27 @@ def parse_logical(tok: str) -> bool:
 
 
 def first_tokens(path: str) -> List[str]:
-    """First token of every non-blank record (list-directed reads skip blank records)."""
+    """First token of every non-blank record (list-directed reads skip blank records).  A sweep reads the same
+    few lens / bottle files for every one of its systems: the tokens are kept per (path, size, mtime)."""
+    try:
+        st = os.stat(path)
+        key = (path, st.st_size, st.st_mtime_ns)
+    except OSError:
+        key = None
+    if key is not None and key in _TOKENS:
+        return list(_TOKENS[key])
+    toks = _first_tokens(path)
+    if key is not None:
+        if len(_TOKENS) > 512:
+            _TOKENS.clear()
+        _TOKENS[key] = tuple(toks)
+    return toks
+
+
+_TOKENS: dict = {}
+
+
+def _first_tokens(path: str) -> List[str]:
     toks: List[str] = []
     with open(path, "r") as f:
         for line in f:

@@ -10,6 +10,7 @@ Reference file:line followed here
 """
 from __future__ import annotations
 
+import functools
 import math
 import os
 from dataclasses import dataclass
@@ -30,6 +31,7 @@ F_SKIP_ON_REFLECT, F_MISS_IS_HELP3, F_BOTTLE, F_TRACK, F_SCATTER = 1, 2, 4, 8, 1
 MAX_SURFACES = 12
 
 
+@functools.lru_cache(maxsize=16)
 def acos_threshold(na: float) -> float:
     """min{x in [0,1] : acos(x) <= na} over the doubles, by bisection on the bit pattern."""
     import struct
