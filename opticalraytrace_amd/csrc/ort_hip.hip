@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(kBlock, 4) void trace_pair_kernel(TraceArgs a)
             const int sa = (qhead + lane) & (kPairQueueCap - 1), sb = (qhead + 64 + lane) & (kPairQueueCap - 1);
             qhead = (qhead + m) & (kPairQueueCap - 1);
             qcount -= m;
-            // (the slots of idle lanes hold finite floats of earlier rays or the zeros the LDS was... never read: masked)
+            // (idle lanes read no slot: they carry a harmless ray along the axis)
             float fa0 = 0.f, fa1 = 0.f, fa2 = 0.f, fa3 = 0.f, fa4 = 0.f, fa5 = 1.f, fb0 = 0.f, fb1 = 0.f, fb2 = 0.f, fb3 = 0.f, fb4 = 0.f, fb5 = 1.f;
             uint32_t ia = 0, ib = 0;
             if (act.a) { fa0 = q[0][sa]; fa1 = q[1][sa]; fa2 = q[2][sa]; fa3 = q[3][sa]; fa4 = q[4][sa]; fa5 = q[5][sa]; ia = qi[sa]; }

@@ -111,12 +111,16 @@ def res_dir_with_image(src_res: str) -> str:
         for name, mu in SCATTER_BOTTLES.items():            # 16-value bottle files (lens.f90:195-208)
             with open(os.path.join(d, name), "w") as f:
                 f.write("\n".join(base + [repr(m) for m in mu]) + "\n")
+        # ... and an elliptical bottle that scatters (no golden fixture: HIP kernel variants and the oracle only)
+        base = open(os.path.join(d, "clearBottle-ellipse.params")).read().splitlines()[:12]
+        with open(os.path.join(d, "scatterBottle-ellipse.params"), "w") as f:
+            f.write("\n".join(base + [repr(m) for m in SCATTER_BOTTLES["scatterBottle-both.params"]]) + "\n")
         source_image().tofile(os.path.join(d, "synthetic-source.dat"))
     return d
 
 
 def needs_extended_res(settings) -> bool:
-    return settings.light_source == "image" or settings.bottle_file in SCATTER_BOTTLES
+    return settings.light_source == "image" or settings.bottle_file in SCATTER_BOTTLES or settings.bottle_file == "scatterBottle-ellipse.params"
 
 
 def make_system(name: str):

@@ -616,3 +616,36 @@ def test_uniform_zero_in_the_walk_and_the_fresnel_steps(ctxs, name):
     err = (np.abs(a - w) / scale).max(axis=0)
     assert reach.sum() > 100 and np.mean(err > 1e-10) < 0.01 and err.max() < 1e-6, (np.mean(err > 1e-10), err.max())
     assert want["n_draws"].max() > 12          # rays did walk
+
+
+def test_scattering_pipeline_with_an_elliptical_bottle_and_another_source(hip_library):
+    """The pipeline beyond the fixtures' circular bottle and point source: an ELLIPTICAL bottle that scatters in
+    contents and wall (the walls are intersect_ellipse, the walk's legs stay in the circular cylinder as in the
+    reference) and, on the circular one, the `image` light source in front of it (the front kernel with every
+    emitter compiled in).  Pipeline == monolithic == lockstep, bit for bit; and the oracle's image within the
+    scattering budget of test_scattering_bottle_vs_oracle."""
+    from opticalraytrace_amd.capi import Context
+    from opticalraytrace_amd.params import Settings, resource_dir
+    from opticalraytrace_amd.system import OpticalSystem
+    from conftest import res_dir_with_image
+    res = res_dir_with_image(resource_dir())
+    n = 200_003
+    for kw in (dict(bottle_file="scatterBottle-ellipse.params"),
+               dict(bottle_file="scatterBottle-both.params", light_source="image", image_source="synthetic-source.dat", nphotons=150_000)):
+        osys = OpticalSystem.from_settings(Settings(**{**dict(nphotons=n, make_images=True), **kw}), res)
+        m = osys.settings.nphotons
+        with Context(osys) as ctx:
+            out = []
+            for variant in (1, 17, 0):
+                ctx.set_kernel_variant(variant)
+                ctx.reset()
+                ctx.trace(2, 0, m, SEED)
+                out.append(ctx.read())
+        for v in (1, 2):
+            assert np.array_equal(out[0][0], out[v][0]) and np.array_equal(out[0][1], out[v][1]), (kw, v)
+        assert int(out[0][1][3]) > 2 * m, kw                  # (the elliptical bottle loses every ray: the walk still runs)
+        orc = _oracle(osys)
+        wimg = np.zeros((2, 401, 401), np.int32); wc = np.zeros(8, np.uint64)
+        orc.trace(2, 0, m, SEED, wimg, wc)
+        assert np.abs(out[0][0].astype(np.int64) - wimg).sum() <= 8, kw
+        assert np.abs(out[0][1].astype(np.int64) - wc.astype(np.int64)).max() <= 4, kw

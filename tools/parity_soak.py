@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): parity soak over many random optical systems (tests/random_systems.py).
 Per system: explicit-input rays HIP vs oracle bit for bit (status, bins, intersection and draw
-counts, final state), and the queued filtered kernel's image == the literal lockstep kernel's.
+counts, final state), the queued filtered kernel's image == the literal lockstep kernel's, and — round 3 — the
+PRODUCTION kernel's image and counters == the oracle's for the same keyed rays (two rays of emission budget).
 usage: python tools/parity_soak.py [--systems 300] [--rays 100000] [--first 100]   -> one line per
 system + a summary (kept as profiles/rNN/parity_soak.log)."""
 import argparse
@@ -30,6 +31,7 @@ def main():
     args = ap.parse_args()
     bad = 0
     rays = 0
+    worst = 0
     t0 = time.time()
     print(f"# library build {capi.build_id()}, {args.systems} systems from seed {args.first}, {args.rays} rays per phase")
     for seed in range(args.first, args.first + args.systems):
@@ -58,11 +60,21 @@ def main():
                 imgs.append(ctx.read())
             if not (np.array_equal(imgs[0][0], imgs[1][0]) and np.array_equal(imgs[0][1], imgs[1][1])):
                 notes.append("queued filtered image != lockstep literal image")
+            want_img = np.zeros((2, 401, 401), np.int32)
+            want_cnt = np.zeros(8, np.uint64)
+            orc.trace(1, 0, 2 * n, SEED, want_img, want_cnt)
+            orc.trace(2, 0, 2 * n, SEED, want_img, want_cnt)
+            l1 = int(np.abs(imgs[1][0].astype(np.int64) - want_img).sum())
+            dc = int(np.abs(imgs[1][1].astype(np.int64) - want_cnt.astype(np.int64)).max())
+            if l1 > 4 or dc > 2:
+                notes.append(f"production image vs oracle: L1 {l1}, counter delta {dc}")
+            worst = max(worst, l1)
             binned = int(imgs[1][1][4]) + int(imgs[1][1][5])
         bad += bool(notes)
         print(f"seed {seed:4d} iris {settings.iris:6s} bottle {int(settings.use_bottle)} binned {binned:7d} "
               f"{'OK' if not notes else 'MISMATCH: ' + '; '.join(notes)}", flush=True)
-    print(f"# {args.systems} systems, {rays} explicit rays, {bad} systems with a mismatch, {time.time() - t0:.0f} s")
+    print(f"# {args.systems} systems, {rays} explicit rays, {bad} systems with a mismatch, largest production-vs-oracle image L1 "
+          f"distance {worst}, {time.time() - t0:.0f} s")
     return 1 if bad else 0
 
 
