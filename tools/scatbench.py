@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): the scattering bottle — pipeline (scatter_front_kernel + continuation) against the
-monolithic kernel (variant bit 4), per ray count.   usage: python tools/scatbench.py [--rays 1000000,10000000]"""
+monolithic kernel (variant bit 4), per ray count.   usage: python tools/scatbench.py [--rays 1000000,10000000]   (ORT_HIP_LIB=build/ab/x.so selects another build)"""
 import argparse
 import os
 import sys
