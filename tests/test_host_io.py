@@ -84,3 +84,21 @@ def test_bench_refuses_more_ranks_than_gpus_before_touching_a_gpu():
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 2 and "GPU(s)" in p.stderr and "Traceback" not in p.stderr
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_list_directed_reals_and_records():
+    """fstr.list_directed_*: the layout of flang's `write(u,*)` as reconstructed from the reference program's own
+    files (shortest round-trip digits; F form for 0.1 <= |x| < 1e16, else d.dddE+-XX; records of 79 columns)."""
+    R = fstr.list_directed_real
+    for x, want in ((0.034800000000001496, "3.4800000000001496E-02"), (49.250400000000006, "49.250400000000006"),
+                    (0.0399, "3.99E-02"), (0.05, "5.E-02"), (-2e-3, "-2.E-03"), (0.0, "0."), (60.07, "60.07"),
+                    (100.0, "100."), (0.5, "0.5"), (0.1, "0.1"), (1e-10, "1.E-10"), (1234.5, "1234.5"), (-0.25, "-0.25")):
+        assert R(x) == want, (x, R(x), want)
+        assert float(R(x).replace("E", "e")) == x
+    rec = fstr.list_directed_record
+    assert rec([1.5, ",", True, False, "ab", "cd", 2.0]) == " 1.5 , T F abcd 2.\n"
+    long = "x" * 100
+    out = rec([long])
+    assert out == " " + "x" * 78 + "\n " + "x" * 22 + "\n" and all(len(ln) <= 79 for ln in out.splitlines())
+    out = rec([1.0 / 3.0] * 6)                     # 6 x 19 characters: the fifth item starts a new record
+    assert [len(ln) for ln in out.splitlines()] == [76, 38]
