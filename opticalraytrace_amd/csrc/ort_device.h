@@ -24,6 +24,13 @@
 #include "../../include/ort.h"
 #include "ort_fastd.h"
 
+// ORT_DIET (development, A/B builds): mask of the round-3 optimisations compiled in (see OPT_* below); the build
+// uses all of them.  Bit 6: instruction selection by hand (inline asm) in neg_unless / neg_if / vnormalise_est.
+#ifndef ORT_DIET
+#define ORT_DIET 0xff
+#endif
+#define ORT_DIET_ASM ((ORT_DIET & 64) != 0)
+
 namespace ort {
 
 // ----------------------------------------------------------------------------
@@ -458,8 +465,22 @@ __device__ inline VecT<T> vnormalise_est(VecT<T> a, T t0, T h0, T k0, T s_tol, b
     if constexpr (FILT && std::is_same<T, double>::value) {
         const double s = a.x * a.x + a.y * a.y + a.z * a.z;
         const double e = __builtin_fma(-t0, t0, s);
+#if (ORT_DIET_ASM)
+        // t0, h0, k0 are wave-uniform (SGPR pairs) and a vector instruction reads at most ONE scalar operand: left to
+        // itself the compiler copies two of them into VGPRs (two v_mov_b64 per call).  h0 is the one both need.
+        double vh0, g1, h1;
+        if (__builtin_constant_p(h0)) {                      // literal arguments (emit_ring: 1, 0.5, 0.25): inline constants
+            g1 = __builtin_fma(e, h0, t0);
+            h1 = __builtin_fma(-e, k0, h0);
+        } else {
+            asm("v_mov_b64 %0, %1" : "=v"(vh0) : "s"(h0));
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(g1) : "v"(e), "v"(vh0), "s"(t0));
+            asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(h1) : "v"(e), "s"(k0), "v"(vh0));
+        }
+#else
         const double g1 = __builtin_fma(e, h0, t0);
         const double h1 = __builtin_fma(-e, k0, h0);
+#endif
         const double d = __builtin_fma(-g1, g1, s);
         const double t = __builtin_fma(d, h1, g1);
         const double y = h1 + h1;
@@ -505,10 +526,7 @@ using Ray = RayT<double>;
 //                  guard in solve_and_pick, and the NA test of make_image may take dir.z for dir.z / |dir|.
 //   OPT_ON_AXIS    the surface's centre has cx = cy = +0.0 exactly (host: match_program): pos.x - cx and
 //                  pos.y - cy are pos.x and pos.y, bit for bit (x - (+0) = x for every x, -0 included).
-// ORT_DIET (development, A/B builds): mask of the optimisations compiled in; the build uses all of them.
-#ifndef ORT_DIET
-#define ORT_DIET 0xff
-#endif
+// ORT_DIET (top of this file): mask of these optimisations compiled in; the build uses all of them.
 constexpr int OPT_UNIT_DIR = (ORT_DIET & 1) ? 1 : 0, OPT_ON_AXIS = (ORT_DIET & 2) ? 2 : 0;
 constexpr bool kDietStatusCarriesStep = (ORT_DIET & 4) != 0;   // program kernels: see surface_step NISK
 constexpr bool kDietDiesOnReflect = (ORT_DIET & 8) != 0;       // reflect_refract DIES
@@ -557,6 +575,39 @@ __device__ inline double fmad(double a, double b, double c) { return __builtin_f
 __device__ inline fastd fmad(fastd a, fastd b, fastd c) { return fastd(__builtin_fma(a.v, b.v, c.v)); }
 __device__ inline float fmad(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ inline fastd rsq_approx(fastd s) { return fastd(rsq_approx(s.v)); }
+
+// keep ? x : -x.  For fp64 the compiler flips the sign with a v_xor and then selects (two instructions); the
+// select instruction itself can negate a source (the `neg` modifier works on bit 31 of a 32-bit source: the high
+// dword of a double): one v_cndmask.  Pure bit manipulation: the same value as the plain expression, NaNs included.
+__device__ inline double neg_unless(double x, bool keep)
+{
+#if (ORT_DIET_ASM)
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+    const int hi = __double2hiint(x);
+    int out;
+    asm("v_cndmask_b32_e64 %0, -%1, %1, %2" : "=v"(out) : "v"(hi), "s"(m));
+    return __hiloint2double(out, __double2loint(x));
+#else
+    return keep ? x : -x;
+#endif
+}
+// flip ? -x : x
+__device__ inline double neg_if(double x, bool flip)
+{
+#if (ORT_DIET_ASM)
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(flip);
+    const int hi = __double2hiint(x);
+    int out;
+    asm("v_cndmask_b32_e64 %0, %1, -%1, %2" : "=v"(out) : "v"(hi), "s"(m));
+    return __hiloint2double(out, __double2loint(x));
+#else
+    return flip ? -x : x;
+#endif
+}
+__device__ inline float neg_if(float x, bool flip) { return flip ? -x : x; }
+__device__ inline fastd neg_if(fastd x, bool flip) { return fastd(neg_if(x.v, flip)); }
+__device__ inline float neg_unless(float x, bool keep) { return keep ? x : -x; }
+__device__ inline fastd neg_unless(fastd x, bool keep) { return fastd(neg_unless(x.v, keep)); }
 
 // The staged system as the kernels see it.  For T = double this is ort_system itself (the
 // device copy is staged byte for byte); for T = float a converted copy is staged.
@@ -645,9 +696,8 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
         const bool neg = !nneg;
         bool unused = false;
         const T sq = sqrt_f<true, T>(D, false, unused);   // range: see `ok`; NaN when neg (misses)
-        const bool bpos = hb > T(0.0);
-        const T q = -(hb + (bpos ? sq : -sq));        // :249-253
-        const bool qpos = !bpos;                      // q = -(hb + s) < 0 for hb > 0, = s - hb > 0 otherwise (s > 0)
+        const bool qpos = !(hb > T(0.0));             // q = -(hb + s) < 0 for hb > 0, = s - hb > 0 otherwise (s > 0)
+        const T q = (-hb) - neg_if(sq, qpos);         // :249-253: -(hb + s), as (-hb) - s (negation commutes with rounding): no sign flip afterwards
         const bool cneg = c < T(0.0);
         const bool use_qa = qpos && cneg;
         const T num = use_qa ? q : c, den = use_qa ? a : q;
@@ -802,7 +852,7 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
     //   reflect (:297)      I - (2 c1s) N         = I*1   + N*(-(2 c1s))     (x*1 and a + (-b) are exact)
     //   refract (:320-329)  eta I + (eta c1 - c2) Nt,  Nt = N or -N  = I*eta + N*(+-(eta c1 - c2))
     // so the two scalars are selected, not the six components.
-    const T mm = (c1s < T(0.)) ? m : -m;
+    const T mm = neg_unless(m, c1s < T(0.));
     const T alpha = DIES ? eta : (reflected ? T(1.) : eta);
     const T beta = DIES ? mm : (reflected ? -(T(2.) * c1s) : mm);
     const VecT<T> out = vadd(vscale(I, alpha), vscale(N, beta));
