@@ -116,6 +116,44 @@ class ShardedRun:
         self.reduce()
         return self.result(nphotons)
 
+    # ---- a batch of simulations (a sweep): hooks for where the accumulators live and how a system is staged
+    def _new_accumulators(self, n: int):
+        raise NotImplementedError
+
+    def _begin_simulation(self, system, image, counters) -> None:
+        raise NotImplementedError
+
+    def _end_batch(self) -> None:
+        pass
+
+    def run_many(self, systems, seed: int = DEFAULT_SEED, phases=(1, 2)):
+        """A batch of simulations (a sweep: runner.py starts one process per settings file, :26-47) queued
+        back to back: per simulation the system is staged (`_begin_simulation`: on the GPU asynchronously,
+        ort_set_system), the accumulators are that simulation's slice of ONE array [n_sim][2][401][401]
+        (+ [n_sim][8] counters) and this rank's shard of both loops is launched; then ONE sum over the ranks of
+        the whole arrays, one wait, one copy back.  Returns one RunResult per system, each bit-identical to
+        `set_system(s); run()` done one at a time, on every rank."""
+        n = len(systems)
+        if n == 0:
+            return []
+        images, counters = self._new_accumulators(n)
+        try:
+            for i, system in enumerate(systems):
+                self._begin_simulation(system, images[i], counters[i])
+                lo, cnt = shard_range(system.settings.nphotons, self.rank, self.world)
+                for phase in phases:
+                    self._trace_shard(phase, lo, cnt, seed)
+        finally:
+            self._end_batch()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(images, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=self.group)
+        self._synchronize()
+        h_img = images.cpu().numpy()
+        h_cnt = counters.cpu().numpy().astype(np.uint64)
+        return [RunResult(h_img[i], h_cnt[i], s.settings.nphotons) for i, s in enumerate(systems)]
+
 
 class RayTracer(ShardedRun):
     """One rank's MI355X tracer.  `device` is the local HIP device index.  No CPU fallback."""
@@ -160,37 +198,19 @@ class RayTracer(ShardedRun):
         n = self.system.settings.nphotons if nphotons is None else nphotons
         return super().run(n, seed, phases)
 
-    def run_many(self, systems, seed: int = DEFAULT_SEED, phases=(1, 2)):
-        """A batch of simulations (a sweep: runner.py starts one process per settings file, :26-47) queued
-        back to back on this context: per simulation the system is re-staged (asynchronously, ort_set_system),
-        the accumulators are pointed at that simulation's slice of ONE device array
-        [n_sim][2][401][401] (+ [n_sim][8] counters) and both loops are launched; the host waits once, at the
-        end, and copies everything back in one pass.  Returns one RunResult per system, each bit-identical to
-        `set_system(s); run()` done one at a time."""
-        torch = self.torch
-        n = len(systems)
-        if n == 0:
-            return []
-        images = torch.zeros((n, 2, IMAGE_N, IMAGE_N), dtype=torch.int32, device=self.device)
-        counters = torch.zeros((n, NUM_COUNTERS), dtype=torch.int64, device=self.device)
-        try:
-            for i, system in enumerate(systems):
-                self.set_system(system)
-                self.ctx.attach_buffers(images[i].data_ptr(), counters[i].data_ptr())
-                lo, cnt = shard_range(system.settings.nphotons, self.rank, self.world)
-                for phase in phases:
-                    self.ctx.trace(phase, lo, cnt, seed)
-        finally:
-            # back to the tracer's own accumulators: completes the last simulation's slice (stream-ordered)
-            self.ctx.attach_buffers(self.image.data_ptr(), self.counters.data_ptr())
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(images, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=self.group)
-        self._synchronize()
-        h_img = images.cpu().numpy()
-        h_cnt = counters.cpu().numpy().astype(np.uint64)
-        return [RunResult(h_img[i], h_cnt[i], s.settings.nphotons) for i, s in enumerate(systems)]
+    # ---- hooks of ShardedRun.run_many
+    def _new_accumulators(self, n: int):
+        images = self.torch.zeros((n, 2, IMAGE_N, IMAGE_N), dtype=self.torch.int32, device=self.device)
+        counters = self.torch.zeros((n, NUM_COUNTERS), dtype=self.torch.int64, device=self.device)
+        return images, counters
+
+    def _begin_simulation(self, system: OpticalSystem, image, counters) -> None:
+        self.set_system(system)                                          # asynchronous: the next slot of the ring
+        self.ctx.attach_buffers(image.data_ptr(), counters.data_ptr())   # asynchronous: completes the previous slice
+
+    def _end_batch(self) -> None:
+        # back to the tracer's own accumulators: completes the last simulation's slice (stream-ordered)
+        self.ctx.attach_buffers(self.image.data_ptr(), self.counters.data_ptr())
 
 
 # ---------------------------------------------------------------------------
