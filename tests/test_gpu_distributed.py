@@ -195,3 +195,41 @@ def test_c_abi_allreduce_over_two_devices(plain):
         for c in (a, b):
             img, cnt = c.read()
             assert np.array_equal(img, want.image) and np.array_equal(cnt, want.counters)
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import make_system as mk
+    from opticalraytrace_amd.tracer import RayTracer
+    _, osys = mk("large")
+    t = RayTracer(osys, device=0, rank=rank, world=world)
+    try:
+        res = t.run(N, seed=SEED)
+        many = t.run_many([osys, osys])                      # a batch: one all-reduce of the stacked images
+    finally:
+        t.close()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), image=res.image, counters=res.counters,
+             many_image=np.stack([m.image for m in many]), many_counters=np.stack([m.counters for m in many]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_over_gloo(plain, tmp_path):
+    """The N > 1 path of the PRODUCT code with N = 2 on this one GPU: two processes, each a RayTracer (HIP context,
+    attached torch tensors, its shard of the global ray range), the sum over ranks by torch.distributed — over gloo,
+    because RCCL needs one device per rank (that leg is the 8-GPU node's).  Both ranks end with the single run's image
+    and counters, bit for bit; so does a batch (run_many)."""
+    import torch.multiprocessing as mp
+    osys, want = plain
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        g = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(g["image"], want.image) and np.array_equal(g["counters"], want.counters), r
+        n2 = osys.settings.nphotons                          # run_many traces the systems' own photon counts
+        assert g["many_image"].shape[0] == 2 and np.array_equal(g["many_image"][0], g["many_image"][1])
+        assert int(g["many_counters"][0][3]) > 6 * n2 * 0.9
