@@ -63,7 +63,7 @@ def launch_ranks(args, argv) -> int:
     this process may not be replaced once a GPU runtime is loaded, and it has loaded none yet)."""
     import torch                                    # device_count() does not initialise the GPU
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (args.rehearse and have >= 1):
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); "
                          "one rank per GPU is the only supported layout\n")
         return 2
@@ -232,6 +232,9 @@ def main() -> int:
                          "at 1e6 and 1e9 photons; adds the `sweep` object (several extra seconds)")
     ap.add_argument("--single-process", action="store_true",
                     help="one process, one context per GPU, ort_allreduce (the Fortran host's layout, INTEGRATION.md §C)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="development: run the N-rank flow on ONE GPU (every rank on device 0, gloo instead of RCCL); "
+                         "the line says so in config.rehearsal and is not a scaling measurement")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and all-reduce even with one rank (exercises the N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -277,13 +280,18 @@ def main() -> int:
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py needs an MI355X: the trace path has no CPU fallback\n")
         return 2
+    if args.rehearse:
+        local_rank = 0                              # every rank on the one GPU
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     settings = Settings(nphotons=min(total_rays, 2**31 - 1), make_images=True,
                         bottle_file="clearBottle-large.params",
@@ -480,6 +488,8 @@ def main() -> int:
                    "rays_deferred_to_literal_rerun_per_step": deferred_total / args.steps,
                    "rays_per_s": total_rays * len(phases) * args.steps / elapsed,
                    "settle_launches": SETTLE_LAUNCHES,
+                   **({"rehearsal": "all ranks on device 0, gloo instead of RCCL: the N-rank flow, not a scaling measurement"}
+                      if args.rehearse else {}),
                    "build_id": build},
         # the BINDING bound of this path: fp64 vector-ALU issue (no MFMA: there is no contraction)
         "roofline": {

@@ -68,9 +68,15 @@ def main(argv=None) -> int:
         if world > 1:
             import torch
             import torch.distributed as dist
+            # ORT_DIST_BACKEND=gloo (development): rehearse the multi-rank run where RCCL cannot be used — e.g. all
+            # ranks on one GPU (`--device 0` on every rank)
+            backend = os.environ.get("ORT_DIST_BACKEND", "nccl")
             torch.cuda.set_device(device)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
         tracer = RayTracer(system, device=device, rank=rank, world=world, process_group=group)
         try:
             res = tracer.run()

@@ -81,3 +81,30 @@ def test_entry_point_writes_what_run_settings_writes(tmp_path, hip_library):
     p = _run(str(tmp_path), "res/test_0.params", "--data", "data2", "--quiet")
     assert p.returncode == 0 and p.stdout == ""
     assert sorted(f for f in os.listdir(tmp_path / "data2" / "images") if "image" in f) == names
+
+
+@pytest.mark.gpu
+def test_entry_point_under_a_two_rank_launcher(tmp_path, hip_library):
+    """`torch.distributed.run --nproc-per-node 2 -m opticalraytrace_amd <settings>`: every rank traces its shard, the
+    image is summed over the ranks, rank 0 alone writes — the same three image files and stats record as the one-process
+    run, byte for byte.  Rehearsed on one GPU (both ranks on device 0, ORT_DIST_BACKEND=gloo: RCCL needs a device per
+    rank — that leg belongs to a multi-GPU node)."""
+    import socket
+    _tree(tmp_path, bottle_file="clearBottle-large.params", nphotons=300_001)
+    p = _run(str(tmp_path), "res/test_0.params", "--data", "one", "--quiet")
+    assert p.returncode == 0, p.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), ORT_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    q = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "opticalraytrace_amd", "res/test_0.params", "--data", "two", "--device", "0"],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0, q.stderr[-3000:]
+    assert q.stdout.count("Ring  transmitted:") == 1                     # rank 0 alone reports
+    a, b = tmp_path / "one" / "images", tmp_path / "two" / "images"
+    assert sorted(os.listdir(a)) == sorted(os.listdir(b)) and len(os.listdir(a)) == 4
+    for f in os.listdir(a):
+        assert open(a / f, "rb").read() == open(b / f, "rb").read(), f

@@ -233,3 +233,18 @@ def test_two_ranks_share_one_gpu_over_gloo(plain, tmp_path):
         n2 = osys.settings.nphotons                          # run_many traces the systems' own photon counts
         assert g["many_image"].shape[0] == 2 and np.array_equal(g["many_image"][0], g["many_image"][1])
         assert int(g["many_counters"][0][3]) > 6 * n2 * 0.9
+
+
+def test_bench_two_rank_flow_rehearsed_on_one_gpu():
+    """`bench.py --gpus 2 --rehearse`: the driver's N > 1 invocation end to end on one GPU — bench.py starts its own
+    two ranks (torch.distributed.run), both trace their shard on device 0, barrier + max over ranks, the sum of image and
+    counters inside the timed region (gloo here, RCCL on a real node), rank 0 prints ONE line."""
+    p = _bench("--gpus", "2", "--rehearse", "--steps", "3", "--warmup", "1", "--no-fast", "--no-fp32", "--rays", "1000000")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and "rehearsal" in line["config"]
+    assert line["config"]["rays_per_layer_per_step"] == 2_000_000 and line["config"]["rays_per_gpu_per_launch"] == 1_000_000
+    assert abs(line["config"]["intersections_per_step"] / 2e6 - 6.31) < 0.05          # both shards counted
+    assert line["value"] > 1e9 and line["reduce_ms"] > 0
