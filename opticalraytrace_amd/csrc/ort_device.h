@@ -26,10 +26,12 @@
 
 // ORT_DIET (development, A/B builds): mask of the round-3 optimisations compiled in (see OPT_* below); the build
 // uses all of them.  Bit 6: instruction selection by hand (inline asm) in neg_unless / neg_if / vnormalise_est.
+// Bit 7: the late items (OPT_AXIAL_START, the literal zero of a cylinder normal, wave_any_live, unconditional queue loads).
 #ifndef ORT_DIET
 #define ORT_DIET 0xff
 #endif
 #define ORT_DIET_ASM ((ORT_DIET & 64) != 0)
+#define ORT_DIET_LATE ((ORT_DIET & 128) != 0)
 
 namespace ort {
 
@@ -86,6 +88,13 @@ __device__ inline uint32_t draw_word(uint64_t h, bool odd) { return odd ? (uint3
 // the i1 ballot builtin: an s_and of the compare mask with exec.  (HIP's __ballot(int) first
 // materialises the predicate as 0/1 in a VGPR and compares it again: two VALU instructions.)
 __device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// "is any ray of the wavefront still alive" (st < 0) with the status word opaque at this point: the compiler
+// otherwise re-derives the test from the selects that produced st (one compare + mask logic per select)
+__device__ inline bool wave_any_live(int &st)
+{
+    if (ORT_DIET_LATE) asm("" : "+v"(st));
+    return __builtin_amdgcn_ballot_w64(st < 0) != 0ull;
+}
 
 // Per-ray draw source of the parity / debug entry.  peek() is the next uniform, advance(c)
 // consumes it where c.  Keyed stream, or an explicit table: draw k at table[k*stride].
@@ -491,6 +500,9 @@ __device__ inline VecT<T> vnormalise_est(VecT<T> a, T t0, T h0, T k0, T s_tol, b
         q.x = __builtin_fma(__builtin_fma(-t, mx, a.x), r, mx);
         q.y = __builtin_fma(__builtin_fma(-t, my, a.y), r, my);
         q.z = __builtin_fma(__builtin_fma(-t, mz, a.z), r, mz);
+        // the x of a cylinder normal (a literal +0, known at compile time in a program kernel): 0 r = +0, fma(-t, +0, +0) =
+        // +0, fma(+0, r, +0) = +0 for every finite r > 0 — and a lane whose r is anything else fails the test on e below
+        if (ORT_DIET_LATE && __builtin_constant_p(x_zero) && x_zero) q.x = 0.0;
         const bool odd = (!x_zero & !(fabs(a.x) > 0x1p-300)) | !(fabs(a.y) > 0x1p-300) | !(fabs(a.z) > 0x1p-300);
         ORT_RARE(1, need & (odd | !(fabs(e) < s_tol)));
         return q;
@@ -524,10 +536,13 @@ using Ray = RayT<double>;
 //                  c2^2 = k; reflect: 1 - 4 c1^2 + 4 c1^2), each to a few ulps — true for the fused
 //                  program kernels, whose rays never come from outside.  Then a = dir.dir needs no range
 //                  guard in solve_and_pick, and the NA test of make_image may take dir.z for dir.z / |dir|.
+//   OPT_AXIAL_START  the ray stands where `point` put it, (0, 0, 0 + offset), and this is the first surface of its loop
+//                  (a cylinder: the bottle): pos - centre and c = L.L - radius**2 are the system's (axial_start), not the ray's
 //   OPT_ON_AXIS    the surface's centre has cx = cy = +0.0 exactly (host: match_program): pos.x - cx and
 //                  pos.y - cy are pos.x and pos.y, bit for bit (x - (+0) = x for every x, -0 included).
 // ORT_DIET (top of this file): mask of these optimisations compiled in; the build uses all of them.
-constexpr int OPT_UNIT_DIR = (ORT_DIET & 1) ? 1 : 0, OPT_ON_AXIS = (ORT_DIET & 2) ? 2 : 0;
+constexpr int OPT_UNIT_DIR = (ORT_DIET & 1) ? 1 : 0, OPT_ON_AXIS = (ORT_DIET & 2) ? 2 : 0, OPT_AXIAL_START = (ORT_DIET & 128) ? 4 : 0;
+constexpr bool kDietLate = ORT_DIET_LATE;                      // axial start, the zero of a cylinder normal, wave_any_live, queue loads
 constexpr bool kDietStatusCarriesStep = (ORT_DIET & 4) != 0;   // program kernels: see surface_step NISK
 constexpr bool kDietDiesOnReflect = (ORT_DIET & 8) != 0;       // reflect_refract DIES
 constexpr bool kDietApertureBounds = (ORT_DIET & 16) != 0;     // outside_aperture on precomputed bounds
@@ -634,7 +649,7 @@ template <> struct SysTypes<fastd> { using Sys = ort_system; using Surf = ort_su
 // but fp64 arithmetic lives in the vector unit): formed once per workgroup next to the staged
 // system, by the very operations the per-ray code would use, so nothing changes bit-wise.  Only
 // the filtered path reads them; the literal path recomputes from the surface record.
-template <class T> struct SurfAuxT { T r2, ap2, ap_tol, eta2, ell_sa, ell_sb, rh, rk, r2_tol, ap_lo, ap_hi; };
+template <class T> struct SurfAuxT { T r2, ap2, ap_tol, eta2, ell_sa, ell_sb, rh, rk, r2_tol, ap_lo, ap_hi, ax_ly, ax_lz, ax_c; };
 template <class T, class Surf>
 __host__ __device__ inline SurfAuxT<T> make_aux(const Surf &s)
 {
@@ -653,7 +668,21 @@ __host__ __device__ inline SurfAuxT<T> make_aux(const Surf &s)
     a.rh = T(0.5) / r;                     // 1 / (2 |N|)
     a.rk = a.rh / (T(2.) * a.r2);          // d(1/(2 sqrt s))/ds at s = r^2, negated
     a.r2_tol = T(0x1p-32) * a.r2;          // |N.N - r^2| beyond this: not a point of the surface, literal path
+    a.ax_ly = a.ax_lz = a.ax_c = T(0.);    // OPT_AXIAL_START: set by axial_start() for the first surface of the point loop
     return a;
+}
+
+// OPT_AXIAL_START: the point source starts every ray at pos = (0, 0, 0 + offset) (emit_point), so at the FIRST
+// surface of its loop L = pos - centre and c = L.L - radius**2 are the same for every ray: formed here once per
+// system, operation for operation as intersect_quadric forms them per ray (cylinder: no x terms).
+template <class T, class Surf>
+__host__ __device__ inline void axial_start(SurfAuxT<T> &a, const Surf &s, T point_offset)
+{
+    const T py = T(0.0), pz = T(0.0) + point_offset;
+    const T Lx = T(0.0), Ly = py - s.cy, Lz = pz - s.cz;
+    a.ax_ly = Ly;
+    a.ax_lz = Lz;
+    a.ax_c = ((Lx * Lx) + (Ly * Ly) + (Lz * Lz)) - a.r2;
 }
 
 template <class T> __device__ inline bool aperture_present(T a);
@@ -747,16 +776,19 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
 // r2 = radius**2 (SurfAuxT); the literal path forms it itself.
 template <bool FILT, class T, int OPT = 0>
 __device__ inline void intersect_quadric(const RayT<T> &r, T cx, T cy, T cz, T radius, T r2,
-                                         bool cylinder, bool live, T &t, bool &hit, bool &rare)
+                                         bool cylinder, bool live, T &t, bool &hit, bool &rare,
+                                         T ax_ly = T(0.), T ax_lz = T(0.), T ax_c = T(0.))
 {
     constexpr bool axis = (OPT & 2) != 0;                // OPT_ON_AXIS: cx = cy = +0.0
+    constexpr bool start = (OPT & 4) != 0;               // OPT_AXIAL_START: L and c are the system's (axial_start), a cylinder
+    static_assert(!start || FILT, "the axial start serves the filtered program kernels");
     T Lx = cylinder ? T(0.0) : (axis ? r.pos.x : r.pos.x - cx);
-    T Ly = axis ? r.pos.y : r.pos.y - cy;
-    T Lz = r.pos.z - cz;
+    T Ly = start ? ax_ly : (axis ? r.pos.y : r.pos.y - cy);
+    T Lz = start ? ax_lz : r.pos.z - cz;
     T dx = cylinder ? T(0.0) : r.dir.x;
     T a = (dx * dx) + (r.dir.y * r.dir.y) + (r.dir.z * r.dir.z);
     T hb = (dx * Lx) + (r.dir.y * Ly) + (r.dir.z * Lz);
-    T c = ((Lx * Lx) + (Ly * Ly) + (Lz * Lz)) - (FILT ? r2 : radius * radius);
+    T c = start ? ax_c : ((Lx * Lx) + (Ly * Ly) + (Lz * Lz)) - (FILT ? r2 : radius * radius);
     solve_and_pick<FILT, T, (OPT & 1) != 0>(a, hb, c, live, t, hit, rare);
 }
 
@@ -1511,7 +1543,8 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
         bool hit;
         const bool cyl = kind != ORT_SURF_SPHERE;
         if (kind == ORT_SURF_ELLIPSE) intersect_ellipse<FILT, T>(r, s.cy, s.cz, s.radius, s.radius_b, ax.ell_sa, ax.ell_sb, live, t, hit, rare);
-        else intersect_quadric<FILT, T, (KIND == ORT_SURF_SPHERE ? OPT : (OPT & ~2))>(r, s.cx, s.cy, s.cz, s.radius, ax.r2, cyl, live, t, hit, rare);
+        else intersect_quadric<FILT, T, (KIND == ORT_SURF_SPHERE ? (OPT & ~4) : (OPT & ~2))>(r, s.cx, s.cy, s.cz, s.radius, ax.r2, cyl, live, t, hit, rare,
+                                                                                             ax.ax_ly, ax.ax_lz, ax.ax_c);
         int walk_end = -1;
         if (EXT && (flags & ORT_F_SCATTER)) {               // wave-uniform
             scatter_walk<T>(s, S.twopi, r, t, live && hit && !rare, draws, nis, walk_end);

@@ -246,7 +246,7 @@ __device__ inline void walk_pass(const Sys &S, const Surf *surf, const SurfAuxT<
                                  RayT<T> &r, D &draws, int &nis, int &st, int &xp, int &yp, bool &rare)
 {
     for (int k = k0; k < k1; ++k) {
-        if (!wave_any(st < 0)) break;
+        if (!wave_any_live(st)) break;
 #ifdef ORT_DBG_RARE
         const bool before = rare;
 #endif
@@ -303,6 +303,7 @@ __device__ inline SurfAuxT<T> load_aux(typename ConstPtrs<T>::aux_t p)
     a.ell_sa = T(p->ell_sa); a.ell_sb = T(p->ell_sb);
     a.rh = T(p->rh); a.rk = T(p->rk); a.r2_tol = T(p->r2_tol);
     a.ap_lo = T(p->ap_lo); a.ap_hi = T(p->ap_hi);
+    a.ax_ly = T(p->ax_ly); a.ax_lz = T(p->ax_lz); a.ax_c = T(p->ax_c);      // (read by step 0 of the point programs only)
     return a;
 }
 
@@ -415,6 +416,13 @@ template <int P> constexpr bool prog_static_draws()
     if constexpr (P == PROG_GENERIC) return false;
     else return Prog<P>::emitter == ORT_EMIT_RING || Prog<P>::emitter == ORT_EMIT_POINT || Prog<P>::emitter == ORT_EMIT_IMAGE;
 }
+// the rays of the program start where `point` puts them, in front of a circular cylinder (OPT_AXIAL_START)
+template <int P> constexpr bool prog_starts_on_axis()
+{
+    if constexpr (P == PROG_GENERIC) return false;
+    else return Prog<P>::emitter == ORT_EMIT_POINT && Prog<P>::kind[0] == ORT_SURF_CYLINDER;
+}
+
 // the step the queue point of trace_queue_kernel lies in, + 1.  Prog<P>::split (the host's choice for
 // the list: behind the stop that removes most rays) — except in the fused ring programs: their
 // segment 0 has already removed the rays the first stop would, every ray that reaches segment 1
@@ -452,24 +460,25 @@ __device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t su
                                   int &nis, int &st, int &xp, int &yp, bool &rare)
 {
     if constexpr (K < K1) {
-        if (wave_any(st < 0)) {
+        if (wave_any_live(st)) {
             const typename ConstPtrs<T>::Surf s = load_surface<T>(surf + K);
             const SurfAuxT<T> ax = load_aux<T>(aux + K);
 #ifdef ORT_ISA_MARKERS      // tools/isa_budget.py: comment lines that delimit the steps in the listing
             asm volatile("; ORT_STEP_BEGIN %0" ::"n"(K));
 #endif
             constexpr bool draws_here = Prog<P>::kind[K] != ORT_SURF_IRIS && Prog<P>::kind[K] != ORT_SURF_IMAGE;
+            constexpr int OPTK = K == 0 ? OPT : (OPT & ~OPT_AXIAL_START);       // the emitter's position holds at the first surface only
             if constexpr (draws_here && Prog<P>::ap[K] != 0 && !KEEP) {
                 // a refracting step with an aperture stop, in halves (surface_step PART): when the stop
                 // ends every ray of the wavefront — the doublet's first face does that to 9 of 10
                 // wavefronts of the ring loop — the normalisation and the Fresnel arithmetic are skipped
-                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 1, nisk<K>(), OPT>(
+                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 1, nisk<K>(), OPTK>(
                     S, s, ax, r, draws, nis, st, xp, yp, rare);
-                if (wave_any(st < 0))
-                    surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 2, nisk<K>(), OPT>(
+                if (wave_any_live(st))
+                    surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 2, nisk<K>(), OPTK>(
                         S, s, ax, r, draws, nis, st, xp, yp, rare);
             } else {
-                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 0, nisk<K>(), OPT>(
+                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 0, nisk<K>(), OPTK>(
                     S, s, ax, r, draws, nis, st, xp, yp, rare);
             }
 #ifdef ORT_ISA_MARKERS
@@ -486,13 +495,13 @@ template <bool FILT, class T, int P, int K, int PART, int OPT, class Sys, class 
 __device__ inline void step_part(const Sys &S, typename ConstPtrs<T>::surf_t surf, typename ConstPtrs<T>::aux_t aux, RayT<T> &r, D &draws,
                                  int &nis, int &st, int &xp, int &yp, bool &rare)
 {
-    if (wave_any(st < 0)) {
+    if (wave_any_live(st)) {
         const typename ConstPtrs<T>::Surf s = load_surface<T>(surf + K);
         const SurfAuxT<T> ax = load_aux<T>(aux + K);
 #ifdef ORT_ISA_MARKERS
         if (PART == 1) asm volatile("; ORT_STEP_BEGIN %0" ::"n"(K));
 #endif
-        surface_step<FILT, T, false, false, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), PART == 2, PART, nisk<K>(), OPT>(
+        surface_step<FILT, T, false, false, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), PART == 2, PART, nisk<K>(), (K == 0 ? OPT : (OPT & ~OPT_AXIAL_START))>(
             S, s, ax, r, draws, nis, st, xp, yp, rare);
 #ifdef ORT_ISA_MARKERS
         if (PART == 2) asm volatile("; ORT_STEP_END %0" ::"n"(K));
@@ -604,7 +613,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
                 };
                 push(true);                                          // main.f90:103,144
                 for (int k = 0; k < ns; ++k) {
-                    if (!wave_any(st < 0)) break;
+                    if (!wave_any_live(st)) break;
                     const bool was_live = st < 0;
                     bool unused = false;                 // the tracker walks with the literal predicates
                     surface_step<false, T, true>(S, surf[k], AUX[k], r, d, nis, st, xp, yp, unused);
@@ -779,7 +788,9 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
 
     // what the steps of a program kernel may assume (ort_device.h): fused rays have unit directions (they
     // were emitted here), the lens spheres of every program are centred on the axis (host: matches<P>)
-    constexpr int OPT = fixed ? ((MODE == MODE_FUSED ? OPT_UNIT_DIR : 0) | OPT_ON_AXIS) : 0;
+    // (axial start: exact fp64 only — fast fp64 contracts L.L into fmas that the constants of the host do not replay; fp32 keeps its literal steps)
+    constexpr bool axial = MODE == MODE_FUSED && prog_starts_on_axis<PROG>() && FILT && std::is_same<T, double>::value;
+    constexpr int OPT = fixed ? ((MODE == MODE_FUSED ? OPT_UNIT_DIR : 0) | OPT_ON_AXIS | (axial ? OPT_AXIAL_START : 0)) : 0;
     constexpr bool tagged = fixed && kDietStatusCarriesStep;     // st = ORT_ST_* | intersections << 8
     unsigned int lost = 0, isect = 0, binned = 0, help3 = 0, culled = 0;
     auto finish = [&](int st_in, int nis_in, int xp, int yp) {
@@ -816,11 +827,14 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             const int slot = (qhead + lane) & (kQueueCap - 1);
             qhead = (qhead + m) & (kQueueCap - 1);
             qcount -= m;
+            // (every lane loads: the slots of the lanes beyond m hold rays of earlier passes — or, in a wave's first
+            // partial pass, whatever the LDS held — whose arithmetic is discarded: st >= 0 keeps them out of every
+            // decision, side effect and deferral)
             RayT<T> r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}};
             DrawsT d;
             QD dw = 0;                                   // the queued image of the draw state
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
-            if (act) {
+            if (act || kDietLate) {
                 r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
                 r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
                 dw = qd[slot];
@@ -1168,15 +1182,21 @@ __global__ __launch_bounds__(kBlock, 4) void trace_pair_kernel(TraceArgs a)
 // operation of a ray is the one the monolithic kernel (and the lockstep kernel) performs, in the same order with
 // the same draws — literal predicates throughout, nothing is deferred here — so rays, images and counters are
 // bit-identical to theirs (tests: the pipeline against the lockstep kernel; both against the CPU checker).
-// One wavefront per workgroup: the two queues take 17 KB of LDS per wave (7 waves per CU; the kernel's 171 VGPRs
-// allow 8).
+// One wavefront per workgroup: pool + rings + the staged system take 12 KB of LDS per wave (13 waves per CU; the
+// kernel's 160 VGPRs allow 12).
 // ---------------------------------------------------------------------------
 constexpr int kSQCap = 128;        // at most 128 rays in flight per wave: stage E runs only while <= 64 are (a power of two)
-struct ScatQueue {
+// ONE pool of ray slots per wave and three rings of slot numbers over it — walking, arrived, free: a ray keeps its
+// slot from stage to stage, only its number moves between the rings (two queues of 128 full slots each were 17 KB
+// per wave: 7 waves per CU, and the kernel is latency-bound at that — profiles/r03/scatbench.log: 1 / 1.75 / 3
+// waves per SIMD)
+struct ScatPool {
     double f[7][kSQCap];           // px py pz dx dy dz t (length of the next leg)
     uint64_t c[kSQCap];            // keyed draw counter
     uint32_t m[kSQCap];            // intersections so far << 8 | surface index
+    uint8_t ring[3][kSQCap];       // slot numbers: RING_WALK, RING_ARRIVED, RING_FREE
 };
+constexpr int RING_WALK = 0, RING_ARRIVED = 1, RING_FREE = 2;
 
 // ENTER surface k (per lane) for the lanes `on`: src/lens.f90:255-261 / :303-311 up to the first tauint
 __device__ inline void scat_enter(const ort_surface *surf, int k, int kind0, bool on, const Ray &r, KeyedDraws &d,
@@ -1203,15 +1223,19 @@ __device__ inline void scat_enter(const ort_surface *surf, int k, int kind0, boo
     arrived = alive && !walking;
 }
 
+#ifdef ORT_SCAT_TIMING
+__device__ unsigned long long g_scat_times[4 * 16384];     // dev builds: start, last emission, end, passes per wave
+#endif
 // ANYSRC = false: the point source only (the default of the loop the bottle belongs to, src/main.f90:136)
 template <bool ANYSRC>
 __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
 {
     __shared__ ort_system S;
-    __shared__ ScatQueue WQ, AQ;
+    __shared__ ScatPool P;
     __shared__ unsigned int blk[4];
     stage_system(S, a.sys);
     if (threadIdx.x < 4) blk[threadIdx.x] = 0;
+    for (int j = threadIdx.x; j < kSQCap; j += 64) P.ring[RING_FREE][j] = (uint8_t)j;      // every slot starts free
     __syncthreads();
     const int lane = threadIdx.x;
     const int ph = a.phase - 1;
@@ -1229,36 +1253,49 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
         lost++;                                           // every status a ray can end with here counts as lost
         if (st == ORT_ST_HELP3) help3++;
     };
-    int wcount = 0, whead = 0, acount = 0, ahead = 0;
-    auto push = [&](ScatQueue &Q, int &count, int head, bool cond, const Ray &r, double t, const KeyedDraws &d, int nis, int k) {
+    // rings: wcount + acount + fcount + (slots held by the lanes of the running stage) = kSQCap
+    int wcount = 0, whead = 0, acount = 0, ahead = 0, fcount = kSQCap, fhead = 0;
+    auto give = [&](int which, int &count, int head, bool cond, int slot) {        // append the slot numbers of the lanes `cond`
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(cond);
-        if (cond) {
-            const int slot = (head + count + lane_prefix(mask)) & (kSQCap - 1);
-            Q.f[0][slot] = r.pos.x; Q.f[1][slot] = r.pos.y; Q.f[2][slot] = r.pos.z;
-            Q.f[3][slot] = r.dir.x; Q.f[4][slot] = r.dir.y; Q.f[5][slot] = r.dir.z;
-            Q.f[6][slot] = t;
-            Q.c[slot] = d.c;
-            Q.m[slot] = ((uint32_t)nis << 8) | (uint32_t)k;
-        }
+        if (cond) P.ring[which][(head + count + lane_prefix(mask)) & (kSQCap - 1)] = (uint8_t)slot;
         count += __popcll(mask);
     };
-    auto pop = [&](ScatQueue &Q, int &count, int &head, bool &act, Ray &r, double &t, KeyedDraws &d, int &nis, int &k) {
+    auto take = [&](int which, int &count, int &head, bool &act, int &slot) {      // the first (up to) 64 slot numbers
         const int m = count < 64 ? count : 64;
         act = lane < m;
-        const int slot = (head + lane) & (kSQCap - 1);
+        slot = act ? (int)P.ring[which][(head + lane) & (kSQCap - 1)] : 0;
         head = (head + m) & (kSQCap - 1);
         count -= m;
+    };
+    auto store = [&](bool cond, int slot, const Ray &r, double t, const KeyedDraws &d, int nis, int k) {
+        if (cond) {
+            P.f[0][slot] = r.pos.x; P.f[1][slot] = r.pos.y; P.f[2][slot] = r.pos.z;
+            P.f[3][slot] = r.dir.x; P.f[4][slot] = r.dir.y; P.f[5][slot] = r.dir.z;
+            P.f[6][slot] = t;
+            P.c[slot] = d.c;
+            P.m[slot] = ((uint32_t)nis << 8) | (uint32_t)k;
+        }
+    };
+    auto load = [&](bool act, int slot, Ray &r, double &t, KeyedDraws &d, int &nis, int &k) {
         r = {{0., 0., 0.}, {0., 0., 1.}};
         t = 0.; nis = 0; k = 0;
         d.base = a.rng_base; d.c = 0;
         if (act) {
-            r.pos = {Q.f[0][slot], Q.f[1][slot], Q.f[2][slot]};
-            r.dir = {Q.f[3][slot], Q.f[4][slot], Q.f[5][slot]};
-            t = Q.f[6][slot];
-            d.c = Q.c[slot];
-            const uint32_t mm = Q.m[slot];
+            r.pos = {P.f[0][slot], P.f[1][slot], P.f[2][slot]};
+            r.dir = {P.f[3][slot], P.f[4][slot], P.f[5][slot]};
+            t = P.f[6][slot];
+            d.c = P.c[slot];
+            const uint32_t mm = P.m[slot];
             nis = (int)(mm >> 8); k = (int)(mm & 0xffu);
         }
+    };
+    // where the rays of a stage go: back to the walk ring, to the arrival ring (state stored in their own slot), or out
+    // of the pool (ended / handed over: the slot is free again)
+    auto route = [&](bool held, int slot, bool to_walk, bool to_arrived, const Ray &r, double t, const KeyedDraws &d, int nis, int k) {
+        store(to_walk || to_arrived, slot, r, t, d, nis, k);
+        give(RING_WALK, wcount, whead, to_walk, slot);
+        give(RING_ARRIVED, acount, ahead, to_arrived, slot);
+        give(RING_FREE, fcount, fhead, held && !to_walk && !to_arrived, slot);
     };
     // behind the last scattering surface: the next free slots of this wave's part of the hand-over bundle
     uint64_t handed = 0;
@@ -1275,11 +1312,19 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
         handed += (uint64_t)__popcll(mask);
     };
 
+#ifdef ORT_SCAT_TIMING
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    unsigned long long t_emit = t_start, n_pass = 0;
+#endif
     uint64_t next = lo;
     for (;;) {
         const bool have_new = next < hi;
+#ifdef ORT_SCAT_TIMING
+        n_pass++;
+        if (have_new) t_emit = __builtin_readcyclecounter();
+#endif
         // a full wavefront of walking rays first, then of arrived ones; fresh rays while at most 64 are in flight (the
-        // queues hold 128); otherwise the fuller queue runs on a partial wavefront
+        // pool holds 128); otherwise the fuller ring runs on a partial wavefront
         const bool may_emit = have_new && wcount + acount <= 64;
         if (wcount >= 64 || (wcount > 0 && acount < 64 && !may_emit && wcount >= acount)) {
             // ---- W: one scattering event (src/lens.f90:264-281 / :315-332) for up to 64 walking rays
@@ -1288,7 +1333,9 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             double t;
             KeyedDraws d;
             int nis, k;
-            pop(WQ, wcount, whead, act, r, t, d, nis, k);
+            int slot;
+            take(RING_WALK, wcount, whead, act, slot);
+            load(act, slot, r, t, d, nis, k);
             const ort_surface &s = surf[k];
             int ended = -1;
             bool walking = act;
@@ -1309,8 +1356,7 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             const bool out = sqrt(r.pos.x * r.pos.x + r.pos.z * r.pos.z) >= s.scat_radius;        // sic: x, z
             const bool still = walking && ok && !out && !at_wall;
             const bool arrived = walking && ok && !still;
-            push(WQ, wcount, whead, still, r, t, d, nis, k);
-            push(AQ, acount, ahead, arrived && k < klast, r, t, d, nis, k);
+            route(act, slot, still, arrived && k < klast, r, t, d, nis, k);
             hand_over(arrived && k >= klast, r, t, d, nis);
             if (act && ended >= 0) end_ray(ended, nis);
             __builtin_amdgcn_wave_barrier();
@@ -1321,7 +1367,9 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             double t;
             KeyedDraws d;
             int nis, k;
-            pop(AQ, acount, ahead, act, r, t, d, nis, k);
+            int slot;
+            take(RING_ARRIVED, acount, ahead, act, slot);
+            load(act, slot, r, t, d, nis, k);
             const ort_surface &s = surf[k];
             const unsigned flags = s.flags;
             int ended = -1;
@@ -1341,8 +1389,7 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             bool walking = false, arrived = false;
             const int k1 = enter ? k + 1 : k;
             scat_enter(surf, k1, kind0, enter, r, d, nis, t, walking, arrived, ended);
-            push(WQ, wcount, whead, walking, r, t, d, nis, k1);
-            push(AQ, acount, ahead, arrived && k1 < klast, r, t, d, nis, k1);
+            route(act, slot, walking, arrived && k1 < klast, r, t, d, nis, k1);
             hand_over(arrived && k1 >= klast, r, t, d, nis);
             if (act && ended >= 0) end_ray(ended, nis);
             __builtin_amdgcn_wave_barrier();
@@ -1360,8 +1407,10 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             double t = 0.;
             bool walking, arrived;
             scat_enter(surf, 0, kind0, act && ended < 0, r, d, nis, t, walking, arrived, ended);
-            push(WQ, wcount, whead, walking, r, t, d, nis, 0);
-            push(AQ, acount, ahead, arrived && klast > 0, r, t, d, nis, 0);
+            bool held;
+            int slot;
+            take(RING_FREE, fcount, fhead, held, slot);      // 64 of them: at most 64 rays are in flight (may_emit)
+            route(held, slot, walking, arrived && klast > 0, r, t, d, nis, 0);
             hand_over(arrived && klast <= 0, r, t, d, nis);
             if (act && ended >= 0) end_ray(ended, nis);
             __builtin_amdgcn_wave_barrier();
@@ -1369,6 +1418,12 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             break;
         }
     }
+#ifdef ORT_SCAT_TIMING
+    if (lane == 0 && blockIdx.x < 16384) {
+        g_scat_times[4 * blockIdx.x + 0] = t_start; g_scat_times[4 * blockIdx.x + 1] = t_emit;
+        g_scat_times[4 * blockIdx.x + 2] = __builtin_readcyclecounter(); g_scat_times[4 * blockIdx.x + 3] = n_pass;
+    }
+#endif
     for (uint64_t j = lo + handed + (uint64_t)lane; j < hi; j += 64) a.cont_draw[j] = kNoRay;    // the slots left over
     atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect); atomicAdd(&blk[3], help3);
     __syncthreads();
@@ -1633,9 +1688,11 @@ static int upload_system(ort_ctx *c, const ort_system *sys, bool first = false)
     h.sys = *sys;
     for (int p = 0; p < 2; ++p)
         for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.aux[p][k] = make_aux<double>(sys->surfaces[p][k]);
+    axial_start<double>(h.aux[1][0], sys->surfaces[1][0], sys->point_offset);           // OPT_AXIAL_START (point programs, step 0)
     convert_system(h.sysf, *sys);
     for (int p = 0; p < 2; ++p)
         for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.auxf[p][k] = make_aux<float>(h.sysf.surfaces[p][k]);
+    axial_start<float>(h.auxf[1][0], h.sysf.surfaces[1][0], h.sysf.point_offset);
     c->sys_slot = slot;
     c->d_sys = c->d_sys_ring + slot;
     HIP_TRY(hipMemcpyAsync(c->d_sys, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
@@ -1941,12 +1998,35 @@ static int reserve_list(ort_ctx *c, uint64_t n_rays)
     return ORT_OK;
 }
 
-// Scratch of the scattering pipeline: one hand-over entry (60 bytes) per ray of a launch; launches of that path
-// cover at most kScatterChunk rays (250 MB of the 288 GB).
-constexpr uint64_t kScatterChunk = 1ull << 22;
+// Scratch of the scattering pipeline: one hand-over entry (68 bytes) per ray of a launch; launches of that path
+// cover at most 2^24 rays (1.1 GB of the 288 GB, allocated only as far as a trace needs it).  Every launch ends with
+// the longest random walks of its rays — one scattering event per pass of a wave, ~45 events for the longest of 4e6
+// rays, 0.18 ms that nothing else fills (profiles/r03/scatbench.log: time = 0.18 ms + 0.12..0.14 ms per 1e6 rays):
+// 2^22 rays per launch cost 20 % more per ray than 2^24.
+constexpr int kScatterChunkLog2 = 24;
+static uint64_t scatter_chunk()
+{
+    static const uint64_t chunk = 1ull << env_int("ORT_SCAT_CHUNK_LOG2", kScatterChunkLog2);     // development knob
+    return chunk;
+}
+// Wavefronts (= workgroups) of scatter_front_kernel for a launch of n rays: 12 fit a CU, 3072 fill the chip, and a
+// SIMD needs two resident waves to stay busy (per-wave timelines, tools/scat_timing.py: one wave alone issues 61 % of
+// the cycles, two or three 92 %).  Fewer than 3072 are placed unevenly (2048: some SIMDs get three waves, others one —
+// the launch takes as long as the fullest SIMD); beyond that ~2700 rays per wave (at 2^24 rays: 6144 waves; 3072
+// +3.5 %, 12288 +5 %).
+static unsigned scatter_waves(uint64_t n)
+{
+    static const int forced = env_int("ORT_SCAT_WAVES", 0);                       // development knob
+    uint64_t waves = n / 2730;
+    if (waves < 3072) waves = 3072;
+    if (waves > 6144) waves = 6144;
+    if (forced > 0) waves = (uint64_t)forced;
+    const uint64_t most = (n + 127) / 128;
+    return (unsigned)(waves < most ? waves : most);
+}
 static int reserve_handover(ort_ctx *c, uint64_t n_rays)
 {
-    const uint64_t want = n_rays < kScatterChunk ? n_rays : kScatterChunk;
+    const uint64_t want = n_rays < scatter_chunk() ? n_rays : scatter_chunk();
     if (want <= c->cont_cap) return ORT_OK;
     { const int rc = close_group(c); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1987,7 +2067,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     // scattering media, exact fp64, the default kernel variant: the three-stage pipeline (scatter_front_kernel)
     const bool pipeline = mode == MODE_FUSED && deferring && c->precision == 0 && c->scatter[a0.phase - 1] &&
                           c->scat_k0[a0.phase - 1] > 0 && (c->variant & 16) == 0;
-    const uint64_t step = pipeline ? kScatterChunk : (deferring ? kChunkRays : total);
+    const uint64_t step = pipeline ? scatter_chunk() : (deferring ? kChunkRays : total);
     if (pipeline) {
         const int rc = reserve_handover(c, total);
         if (rc) return rc;
@@ -2038,12 +2118,9 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
         }
         if (ext_timed) { c->launch_ev[0] = c->ring[slot][0]; c->launch_ev[1] = c->ring[slot][1]; }
         if (pipeline) {
-            // one wavefront per workgroup, ~2 rounds of the 7 workgroups a CU holds
-            static const int max_waves = env_int("ORT_SCAT_WAVES", 3584);       // development knob
-            uint64_t waves = (a.n_rays + 127) / 128;
-            if (waves > (uint64_t)max_waves) waves = (uint64_t)max_waves;
-            if (anysrc_emitter) hipLaunchKernelGGL(scatter_front_kernel<true>, dim3((unsigned)waves), dim3(64), 0, c->stream, a);
-            else hipLaunchKernelGGL(scatter_front_kernel<false>, dim3((unsigned)waves), dim3(64), 0, c->stream, a);
+            const unsigned waves = scatter_waves(a.n_rays);       // one wavefront per workgroup
+            if (anysrc_emitter) hipLaunchKernelGGL(scatter_front_kernel<true>, dim3(waves), dim3(64), 0, c->stream, a);
+            else hipLaunchKernelGGL(scatter_front_kernel<false>, dim3(waves), dim3(64), 0, c->stream, a);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL((trace_queue_kernel<MODE_CONTINUE, true, false, double, PROG_GENERIC, false>), dim3(grid), dim3(kBlock), 0,
                                c->stream, a);
@@ -2424,5 +2501,12 @@ int ort_last_kernel_ms(ort_ctx *c, int kind, float *ms)
 extern "C" int ort_debug_rare(unsigned long long out[16])
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ort::ort_dbg_rare), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef ORT_SCAT_TIMING
+extern "C" int ort_debug_scat_times(unsigned long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_scat_times), (size_t)n * 4 * sizeof(unsigned long long));
 }
 #endif

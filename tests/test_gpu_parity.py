@@ -570,9 +570,9 @@ def test_scattering_pipeline_equals_monolithic_and_lockstep_kernels(ctxs, name):
     """The scattering pipeline (scatter_front_kernel: the random walk in stages on full wavefronts, then the lean
     walk from a hand-over bundle) only reschedules: image and counters equal those of the monolithic queued
     kernel (variant bit 4) and of the lockstep kernel, bit for bit — ragged sizes, a launch cut at the
-    pipeline's 2^22-ray chunk, both phases (phase 1 never meets the bottle)."""
+    pipeline's 2^24-ray chunk, both phases (phase 1 never meets the bottle)."""
     osys, ctx = ctxs(name)
-    for n in (1, 63, 65, 4097, 300_007, (1 << 22) + 4321):
+    for n in (1, 63, 65, 4097, 300_007, (1 << 22) + 4321, (1 << 24) + 4321):
         out = []
         for variant in (1, 17, 0) if n < 4_000_000 else (1, 17):
             ctx.set_kernel_variant(variant)
