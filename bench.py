@@ -442,6 +442,9 @@ def main() -> int:
         p = p or {}
         vi, ni = p.get("valu_instructions_per_launch"), p.get("intersections_per_launch")
         return {"valu_busy": p.get("valu_busy_frac"), "valu_lane_utilisation": p.get("valu_lane_utilisation"),
+                # (SQ_ACTIVE_INST_VALU x 4 cycles / SIMD cycles: a wave64 fp32 instruction occupies its SIMD for fewer than
+                # the 4 cycles of an fp64 one, so the fp32 leg reads above 1)
+                "valu_busy_unit": "4-cycle issue slots per SIMD cycle/4",
                 "valu_instr_per_intersection": vi * 64.0 / ni if vi and ni else None,
                 "instruction_classes_per_launch": {k: p[k] for k in ("fma_f32", "mul_f32", "add_f32", "trans_f32", "int32", "fma_f64",
                                                                        "mul_f64", "add_f64", "trans_f64") if k in p} or None}

@@ -14,11 +14,49 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def host_waves(n):
+    """scatter_waves() of ort_hip.hip"""
+    forced = int(os.environ.get("ORT_SCAT_WAVES", 0))
+    waves = forced if forced > 0 else min(max(n // 2730, 3072), 6144)
+    return min(waves, (n + 127) // 128)
+
+
+def summarise(out, rays):
+    """out[wave] = (start, last emission, end, passes) in s_memtime ticks.  The counter is not common to the chip: waves
+    are grouped by CU through their start times (the waves a CU holds at launch start within ~2e3 ticks of each other)."""
+    t = out[:, :3].astype(np.int64)
+    live = out[:, 3] > 1
+    life, drain = (t[:, 2] - t[:, 0])[live] / 1e3, (t[:, 2] - t[:, 1])[live] / 1e3
+    q = lambda x: " ".join(f"{v:9.1f}" for v in np.percentile(x, [0, 10, 50, 90, 100]))
+    print(f"rays {rays} waves {len(out)}   (kilo-ticks of s_memtime; percentiles 0 10 50 90 100)")
+    print("life (end-start) ", q(life))
+    print("drain (end-emit) ", q(drain))
+    print("passes           ", q(out[live, 3].astype(np.float64)))
+    print(f"longest life {life.max():.1f}   mean life {life.mean():.1f}   mean drain {drain.mean():.1f}")
+    order = np.argsort(t[:, 0])
+    s = t[order, 0]
+    cuts = [0] + list(np.nonzero(np.diff(s) > 5_000_000)[0] + 1) + [len(s)]
+    shown = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ii = order[a:b]
+        ii = ii[out[ii, 3] > 1]
+        if 8 <= len(ii) <= 13 and (t[ii, 0].max() - t[ii, 0].min()) < 3000:      # one CU, all of its waves resident from the start
+            ends = np.sort((t[ii, 2] - t[ii, 0].min()) / 1e3)
+            print(f"one CU, {len(ii)} waves, end (kilo-ticks after the first start): " + " ".join(f"{e:.0f}" for e in ends))
+            shown += 1
+            if shown == 3:
+                break
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=int, default=1 << 22)
     ap.add_argument("--bottle", default="scatterBottle-both.params")
+    ap.add_argument("--from-file", default=None, help="summarise a saved gpurun_out/scat_times_<rays>_<waves>.npy")
     args = ap.parse_args()
+    if args.from_file:
+        summarise(np.load(args.from_file), args.rays)
+        return
     import torch  # noqa: F401
     from opticalraytrace_amd import capi
     from opticalraytrace_amd.params import Settings, resource_dir
@@ -31,24 +69,13 @@ def main():
         c.set_kernel_variant(1)
         for _ in range(3):
             c.reset(); c.trace(2, 0, args.rays, 123456789); c.synchronize()
-        waves = min(int(os.environ.get("ORT_SCAT_WAVES", 3584)), (args.rays + 127) // 128)
+        waves = host_waves(args.rays)
         out = np.zeros((waves, 4), dtype=np.uint64)
         rc = lib.ort_debug_scat_times(out.ctypes.data_as(C.c_void_p), C.c_int(waves))
         assert rc == 0, rc
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.save(os.path.join(ROOT, "gpurun_out", f"scat_times_{args.rays}_{waves}.npy"), out)
-    t = out[:, :3].astype(np.int64)
-    t0 = t[:, 0].min()
-    start, emit, end = (t[:, 0] - t0) / 1e3, (t[:, 1] - t0) / 1e3, (t[:, 2] - t0) / 1e3
-    q = lambda x: " ".join(f"{v:9.1f}" for v in np.percentile(x, [0, 10, 50, 90, 100]))
-    print(f"rays {args.rays} waves {waves}   (kilo-ticks of s_memtime; percentiles 0 10 50 90 100)")
-    print("start            ", q(start))
-    print("last emission    ", q(emit))
-    print("end              ", q(end))
-    print("life (end-start) ", q(end - start))
-    print("drain (end-emit) ", q(end - emit))
-    print("passes           ", q(out[:, 3].astype(np.float64)))
-    print(f"kernel span {end.max():.1f}   mean life {np.mean(end - start):.1f}   mean drain {np.mean(end - emit):.1f}")
+    summarise(out, args.rays)
 
 
 if __name__ == "__main__":
