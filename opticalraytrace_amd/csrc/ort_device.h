@@ -928,9 +928,10 @@ template <class T> __device__ inline SinCosT<T> sincos_v(T x);
 
 // one leg: optical depth tau = -log(u) against the distance to the cylinder wall.
 // ok = false is the reference's `error stop "no intersection"`.
-template <class T, class D>
+// FILT (scatter_front_kernel): the distance from the filtered quadratic — the same bits, or `rare` (the ray is re-run)
+template <class T, class D, bool FILT = false>
 __device__ inline void tauint(const RayT<T> &r, T mua, T mus, T cy, T cz, T radius, bool on, D &draws,
-                              T &dist, bool &at_wall, bool &ok, int &nis)
+                              T &dist, bool &at_wall, bool &ok, int &nis, bool *rare = nullptr)
 {
     const T mu_tot = mua + mus;
     const T u = draws.template peek_as<T>();
@@ -939,7 +940,8 @@ __device__ inline void tauint(const RayT<T> &r, T mua, T mus, T cy, T cz, T radi
     T d;
     bool hit;
     bool unused = false;
-    intersect_quadric<false, T>(r, T(0.), cy, cz, radius, T(0.), true, on, d, hit, unused);
+    if constexpr (FILT) intersect_quadric<true, T>(r, T(0.), cy, cz, radius, radius * radius, true, on, d, hit, *rare);
+    else intersect_quadric<false, T>(r, T(0.), cy, cz, radius, T(0.), true, on, d, hit, unused);
     nis += on ? 1 : 0;
     const T tauradius = d * mu_tot;
     const bool inside = tau < tauradius;

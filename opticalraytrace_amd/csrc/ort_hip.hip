@@ -314,7 +314,7 @@ __device__ inline SurfAuxT<T> load_aux(typename ConstPtrs<T>::aux_t p)
 // back to back: -8 % kernel time.  The host selects a program only when the staged system
 // matches it field for field (match_program); everything else runs the generic walk.
 enum { PROG_GENERIC = 0, PROG_POINT, PROG_RING, PROG_POINT_IRIS_B, PROG_POINT_IRIS_A, PROG_RING_IRIS_B, PROG_RING_IRIS_A,
-       PROG_POINT_BARE, PROG_POINT_ELLIPSE, PROG_CRS, PROG_ISORS, PROG_IMAGE };
+       PROG_POINT_BARE, PROG_POINT_ELLIPSE, PROG_CRS, PROG_ISORS, PROG_IMAGE, PROG_POINT_WALKED };
 // every program of the default emitters (ring / point): X(name) — instantiated fused and resident, in every arithmetic
 #define ORT_PROGRAMS(X) X(PROG_POINT) X(PROG_RING) X(PROG_POINT_IRIS_B) X(PROG_POINT_IRIS_A) X(PROG_RING_IRIS_B) X(PROG_RING_IRIS_A) \
     X(PROG_POINT_BARE) X(PROG_POINT_ELLIPSE)
@@ -397,6 +397,10 @@ template <> struct Prog<PROG_POINT_ELLIPSE> {
 template <> struct Prog<PROG_CRS> : Prog<PROG_RING> { static constexpr int emitter = ORT_EMIT_CRS; };
 template <> struct Prog<PROG_ISORS> : Prog<PROG_RING> { static constexpr int emitter = ORT_EMIT_ISORS; };
 template <> struct Prog<PROG_IMAGE> : Prog<PROG_POINT> { static constexpr int emitter = ORT_EMIT_IMAGE; };
+// the point loop's list behind a scattering bottle (trace_queue_kernel<MODE_CONTINUE>: rays handed over by scatter_front_kernel,
+// each at its own draw; whatever source emitted them)
+constexpr int ORT_EMIT_HANDED_OVER = -2;
+template <> struct Prog<PROG_POINT_WALKED> : Prog<PROG_POINT> { static constexpr int emitter = ORT_EMIT_HANDED_OVER; };
 
 template <int P> constexpr bool prog_is_ring()             // phase-1 list (plano-convex first)
 {
@@ -453,7 +457,9 @@ template <int P> constexpr int draw_index(int K)
 // hash is at hand for the next odd draw (the walk starts behind the queue)
 // OPT: what every step may assume (ort_device.h OPT_*); a step's status carries its intersection count
 // (surface_step NISK) when kDietStatusCarriesStep
-template <int K> constexpr int nisk() { return kDietStatusCarriesStep ? K + 1 : -1; }
+// (OPT_COUNT_STEPS: the rays did not start at step 0 with a count of 0 — they are counted per step and lane)
+constexpr int OPT_COUNT_STEPS = 8;
+template <int K, int OPT = 0> constexpr int nisk() { return kDietStatusCarriesStep && !(OPT & OPT_COUNT_STEPS) ? K + 1 : -1; }
 
 template <bool FILT, class T, bool KEEP, int P, int K, int K1, bool FRESH, int OPT, class Sys, class D>
 __device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t surf, typename ConstPtrs<T>::aux_t aux, RayT<T> &r, D &draws,
@@ -472,13 +478,13 @@ __device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t su
                 // a refracting step with an aperture stop, in halves (surface_step PART): when the stop
                 // ends every ray of the wavefront — the doublet's first face does that to 9 of 10
                 // wavefronts of the ring loop — the normalisation and the Fresnel arithmetic are skipped
-                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 1, nisk<K>(), OPTK>(
+                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 1, nisk<K, OPT>(), OPTK>(
                     S, s, ax, r, draws, nis, st, xp, yp, rare);
                 if (wave_any_live(st))
-                    surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 2, nisk<K>(), OPTK>(
+                    surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 2, nisk<K, OPT>(), OPTK>(
                         S, s, ax, r, draws, nis, st, xp, yp, rare);
             } else {
-                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 0, nisk<K>(), OPTK>(
+                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 0, nisk<K, OPT>(), OPTK>(
                     S, s, ax, r, draws, nis, st, xp, yp, rare);
             }
 #ifdef ORT_ISA_MARKERS
@@ -501,7 +507,7 @@ __device__ inline void step_part(const Sys &S, typename ConstPtrs<T>::surf_t sur
 #ifdef ORT_ISA_MARKERS
         if (PART == 1) asm volatile("; ORT_STEP_BEGIN %0" ::"n"(K));
 #endif
-        surface_step<FILT, T, false, false, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), PART == 2, PART, nisk<K>(), (K == 0 ? OPT : (OPT & ~OPT_AXIAL_START))>(
+        surface_step<FILT, T, false, false, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), PART == 2, PART, nisk<K, OPT>(), (K == 0 ? OPT : (OPT & ~OPT_AXIAL_START))>(
             S, s, ax, r, draws, nis, st, xp, yp, rare);
 #ifdef ORT_ISA_MARKERS
         if (PART == 2) asm volatile("; ORT_STEP_END %0" ::"n"(K));
@@ -790,8 +796,9 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     // were emitted here), the lens spheres of every program are centred on the axis (host: matches<P>)
     // (axial start: exact fp64 only — fast fp64 contracts L.L into fmas that the constants of the host do not replay; fp32 keeps its literal steps)
     constexpr bool axial = MODE == MODE_FUSED && prog_starts_on_axis<PROG>() && FILT && std::is_same<T, double>::value;
-    constexpr int OPT = fixed ? ((MODE == MODE_FUSED ? OPT_UNIT_DIR : 0) | OPT_ON_AXIS | (axial ? OPT_AXIAL_START : 0)) : 0;
-    constexpr bool tagged = fixed && kDietStatusCarriesStep;     // st = ORT_ST_* | intersections << 8
+    constexpr int OPT = fixed ? ((MODE == MODE_FUSED ? OPT_UNIT_DIR : 0) | OPT_ON_AXIS | (axial ? OPT_AXIAL_START : 0) |
+                                 (MODE == MODE_CONTINUE ? OPT_COUNT_STEPS : 0)) : 0;
+    constexpr bool tagged = fixed && kDietStatusCarriesStep && MODE != MODE_CONTINUE;     // st = ORT_ST_* | intersections << 8
     unsigned int lost = 0, isect = 0, binned = 0, help3 = 0, culled = 0;
     auto finish = [&](int st_in, int nis_in, int xp, int yp) {
         const int st = tagged ? status_code(st_in) : st_in;
@@ -885,8 +892,10 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 r.dir = {T(a.cont_pos_dir[3 * ns_in + ic]), T(a.cont_pos_dir[4 * ns_in + ic]), T(a.cont_pos_dir[5 * ns_in + ic])};
                 // the rest of the step of surface k0 - 1, where the ray arrived after its walk (lens.f90:283-297, :334-348):
                 // back test, move, normal, Fresnel — surface_step's tail for a wall of the bottle (no aperture stop)
-                const typename SysTypes<T>::Surf &sw = surf[k0 - 1];
-                const SurfAuxT<T> &axw = AUX[k0 - 1];
+                typename SysTypes<T>::Surf sw;
+                SurfAuxT<T> axw;
+                if constexpr (fixed) { sw = load_surface<T>(csurf + (k0 - 1)); axw = load_aux<T>(caux + (k0 - 1)); }
+                else { sw = surf[k0 - 1]; axw = AUX[k0 - 1]; }
                 const unsigned wflags = (unsigned)__builtin_amdgcn_readfirstlane((int)sw.flags);
                 const int wlost = (wflags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE;
                 const bool back = act && (wflags & ORT_F_SCATTER) != 0 && r.dir.z < T(0.);
@@ -913,7 +922,12 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 else est = emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
                 st = est < 0 ? st : est;
             }
-            if constexpr (fixed) {
+            if constexpr (fixed && MODE == MODE_CONTINUE) {
+                // the list behind the bottle wall the rays were handed over at: its second wall first if only the contents scatter
+                if (k0 == 1) walk_fixed<FILT, T, false, PROG, 1, 2, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                walk_fixed<FILT, T, false, PROG, 2, queue_step<PROG, MODE>() - 1, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+                step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 1, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
+            } else if constexpr (fixed) {
                 walk_fixed<FILT, T, false, PROG, 0, queue_step<PROG, MODE>() - 1, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
                 step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 1, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
             } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, k0, split, r, d, nis, st, xp, yp, rare);
@@ -1180,8 +1194,10 @@ __global__ __launch_bounds__(kBlock, 4) void trace_pair_kernel(TraceArgs a)
 // Rays that survive are appended to the hand-over bundle in HBM (state, keyed draw counter, intersections so far)
 // and trace_queue_kernel<MODE_CONTINUE> walks the remaining surfaces at its own register budget.  Every
 // operation of a ray is the one the monolithic kernel (and the lockstep kernel) performs, in the same order with
-// the same draws — literal predicates throughout, nothing is deferred here — so rays, images and counters are
-// bit-identical to theirs (tests: the pipeline against the lockstep kernel; both against the CPU checker).
+// the same draws.  The quadratics of the walls and of every leg, and the normal + Fresnel step at an inner wall, are
+// evaluated in their filtered forms (ort_device.h: the same bits, or the ray is listed for the literal re-run); the walk
+// itself (stokes, log) is literal — so rays, images and counters are bit-identical to theirs (tests: the pipeline against
+// the lockstep kernel; both against the CPU checker).
 // One wavefront per workgroup: pool + rings + the staged system take 12 KB of LDS per wave (13 waves per CU; the
 // kernel's 160 VGPRs allow 12).
 // ---------------------------------------------------------------------------
@@ -1198,16 +1214,19 @@ struct ScatPool {
 };
 constexpr int RING_WALK = 0, RING_ARRIVED = 1, RING_FREE = 2;
 
-// ENTER surface k (per lane) for the lanes `on`: src/lens.f90:255-261 / :303-311 up to the first tauint
+// ENTER surface k (per lane) for the lanes `on`: src/lens.f90:255-261 / :303-311 up to the first tauint.
+// Circular walls: the two quadratics in their filtered forms (ort_device.h: the same bits, or the lane raises `rare`);
+// a lane that did is left exactly as it came (`ended` untouched, neither walking nor arrived): the caller defers it.
 __device__ inline void scat_enter(const ort_surface *surf, int k, int kind0, bool on, const Ray &r, KeyedDraws &d,
-                                  int &nis, double &t, bool &walking, bool &arrived, int &ended)
+                                  int &nis, double &t, bool &walking, bool &arrived, int &ended, bool &rare)
 {
     const ort_surface &s = surf[k];
+    const int ended0 = ended;
     nis += on ? 1 : 0;
     double tt;
     bool hit, unused = false;
     if (kind0 == ORT_SURF_ELLIPSE) intersect_ellipse<false, double>(r, s.cy, s.cz, s.radius, s.radius_b, 0., 0., on, tt, hit, unused);
-    else intersect_quadric<false, double>(r, s.cx, s.cy, s.cz, s.radius, 0., true, on, tt, hit, unused);
+    else intersect_quadric<true, double>(r, s.cx, s.cy, s.cz, s.radius, s.radius * s.radius, true, on, tt, hit, rare);
     const unsigned flags = s.flags;
     const int lost = (flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE;
     ended = (on && !hit) ? ((flags & ORT_F_MISS_IS_HELP3) ? ORT_ST_HELP3 : lost) : ended;
@@ -1215,12 +1234,15 @@ __device__ inline void scat_enter(const ort_surface *surf, int k, int kind0, boo
     const bool scat = (flags & ORT_F_SCATTER) != 0;
     double dist;
     bool at_wall, ok;
-    tauint<double>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, go && scat, d, dist, at_wall, ok, nis);
+    tauint<double, KeyedDraws, true>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, go && scat, d, dist, at_wall, ok, nis, &rare);
     ended = (go && scat && !ok) ? ORT_ST_NO_INTERSECTION : ended;
     t = go ? (scat ? dist : tt) : t;
     const bool alive = go && (!scat || ok);
-    walking = alive && scat && !at_wall;
-    arrived = alive && !walking;
+    const bool bad = on && rare;
+    walking = alive && scat && !at_wall && !bad;
+    arrived = alive && !(alive && scat && !at_wall) && !bad;
+    ended = bad ? ended0 : ended;
+    rare = bad;
 }
 
 #ifdef ORT_SCAT_TIMING
@@ -1228,7 +1250,7 @@ __device__ unsigned long long g_scat_times[4 * 16384];     // dev builds: start,
 #endif
 // ANYSRC = false: the point source only (the default of the loop the bottle belongs to, src/main.f90:136)
 template <bool ANYSRC>
-__global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void scatter_front_kernel(TraceArgs a)
 {
     __shared__ ort_system S;
     __shared__ ScatPool P;
@@ -1316,6 +1338,11 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
     const unsigned long long t_start = __builtin_readcyclecounter();
     unsigned long long t_emit = t_start, n_pass = 0;
 #endif
+    // a ray that raised `rare` leaves the pipeline without a trace (it has not ended, nothing of it was counted) and is
+    // listed for the literal re-run from its emission, like the deferred rays of trace_queue_kernel
+    auto defer = [&](bool cond, const KeyedDraws &d) {
+        if (cond) a.redo_list[atomicAdd(&a.redo_ctl[0], 1u)] = (uint32_t)(a.defer_base + ((d.c >> 24) - a.first_ray));
+    };
     uint64_t next = lo;
     for (;;) {
         const bool have_new = next < hi;
@@ -1348,14 +1375,17 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             walking = walking && !absorbed;
             stokes_hg<double>(r.dir, s.hgg, S.twopi, walking, d);
             double dist;
-            bool at_wall, ok;
-            tauint<double>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, walking, d, dist, at_wall, ok, nis);
+            bool at_wall, ok, rare = false;
+            tauint<double, KeyedDraws, true>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, walking, d, dist, at_wall, ok, nis, &rare);
+            const bool bad = walking && rare;
+            walking = walking && !rare;
             const bool lostw = walking && !ok;
             ended = lostw ? ORT_ST_NO_INTERSECTION : ended;
             t = (walking && ok) ? dist : t;
             const bool out = sqrt(r.pos.x * r.pos.x + r.pos.z * r.pos.z) >= s.scat_radius;        // sic: x, z
             const bool still = walking && ok && !out && !at_wall;
             const bool arrived = walking && ok && !still;
+            defer(bad, d);
             route(act, slot, still, arrived && k < klast, r, t, d, nis, k);
             hand_over(arrived && k >= klast, r, t, d, nis);
             if (act && ended >= 0) end_ray(ended, nis);
@@ -1378,17 +1408,21 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             const bool live = act && !back;
             r.pos = vselect(live, vadd(r.pos, vscale(r.dir, t)), r.pos);
             const Vec Nraw = {0.0, s.cy - r.pos.y, s.cz - r.pos.z};                      // lens.f90:288-290
-            const Vec N = vnormalise(Nraw);
+            // normal and Fresnel step in their filtered forms (a ray that left its walk by the `out` test is not on the wall:
+            // no estimate of |N| holds, hence vnormalise_f)
+            bool rare = false;
+            const Vec N = vnormalise_f<true, double>(Nraw, live, rare, true);
             const double u = d.peek();
             d.advance(live);
-            bool unused = false;
-            const bool reflected = reflect_refract<false, true, double>(r.dir, N, s.n1, s.n2, s.eta, 0., u, live, unused);
-            const bool dies = live && reflected && (flags & ORT_F_SKIP_ON_REFLECT) != 0;
+            const bool reflected = reflect_refract<true, true, double>(r.dir, N, s.n1, s.n2, s.eta, s.eta * s.eta, u, live, rare);
+            const bool bad1 = live && rare;
+            const bool dies = live && !rare && reflected && (flags & ORT_F_SKIP_ON_REFLECT) != 0;
             ended = dies ? ((flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE) : ended;
-            const bool enter = live && !dies;           // (rays arriving at the LAST wall never come here: handed over)
-            bool walking = false, arrived = false;
+            const bool enter = live && !rare && !dies;  // (rays arriving at the LAST wall never come here: handed over)
+            bool walking = false, arrived = false, rare2 = false;
             const int k1 = enter ? k + 1 : k;
-            scat_enter(surf, k1, kind0, enter, r, d, nis, t, walking, arrived, ended);
+            scat_enter(surf, k1, kind0, enter, r, d, nis, t, walking, arrived, ended, rare2);
+            defer(bad1 || rare2, d);
             route(act, slot, walking, arrived && k1 < klast, r, t, d, nis, k1);
             hand_over(arrived && k1 >= klast, r, t, d, nis);
             if (act && ended >= 0) end_ray(ended, nis);
@@ -1405,8 +1439,9 @@ __global__ __launch_bounds__(64) void scatter_front_kernel(TraceArgs a)
             int ended = emit<double, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf);
             int nis = 0;
             double t = 0.;
-            bool walking, arrived;
-            scat_enter(surf, 0, kind0, act && ended < 0, r, d, nis, t, walking, arrived, ended);
+            bool walking, arrived, rare = false;
+            scat_enter(surf, 0, kind0, act && ended < 0, r, d, nis, t, walking, arrived, ended, rare);
+            defer(rare, d);
             bool held;
             int slot;
             take(RING_FREE, fcount, fhead, held, slot);      // 64 of them: at most 64 rays are in flight (may_emit)
@@ -1585,6 +1620,7 @@ struct ort_ctx {
     int emitter[2];              // host copy of ort_system.emitter
     bool scatter[2];             // per phase: some surface of its list carries ORT_F_SCATTER
     int prog[2];                 // per phase: PROG_* the staged system matches (match_program)
+    bool cont_prog[2];           // per phase: the surfaces from scat_k0 - 1 on are PROG_POINT_WALKED's (matches_behind)
     int scat_k0[2];              // per phase: > 0: the scattering pipeline applies, its continuation starts at this surface
     double *d_cont_pos_dir;      // hand-over bundle of the scattering pipeline (scatter_front_kernel), cont_cap entries
     double *d_cont_t;
@@ -1642,6 +1678,25 @@ static void ring_cull_threshold(const ort_system *sys, bool is_ring_program, dou
     *cullf = (float)(s0.aperture * s0.aperture * (1.0 + 1e-3));
 }
 
+// the continuation of the scattering pipeline as a surface program: the list from surface k0 - 1 on (the wall the rays are
+// handed over at, whose step the continuation finishes) equals P's — kinds, aperture presence, queue point, flags other than
+// the tracker's and ORT_F_SCATTER — with k0 = 1 or 2 (the bottle's walls are steps 0 and 1 of the point loop)
+template <int P>
+static bool matches_behind(const ort_system *sys, int k0)
+{
+    const int p = Prog<P>::phase - 1;
+    if (k0 < 1 || k0 > 2 || sys->n_surfaces[p] != Prog<P>::n || sys->split[p] != Prog<P>::split) return false;
+    for (int k = k0 - 1; k < Prog<P>::n; ++k) {
+        const ort_surface &s = sys->surfaces[p][k];
+        if (s.kind != Prog<P>::kind[k] || (int)(s.flags & ~(ORT_F_TRACK | ORT_F_SCATTER)) != Prog<P>::flags[k] ||
+            (s.aperture >= 0.0) != (Prog<P>::ap[k] != 0))
+            return false;
+        if (k >= k0 && (s.flags & ORT_F_SCATTER)) return false;
+        if (s.kind == ORT_SURF_SPHERE && !(s.cx == 0.0 && s.cy == 0.0 && !std::signbit(s.cx) && !std::signbit(s.cy))) return false;
+    }
+    return true;
+}
+
 static void note_system(ort_ctx *c, const ort_system *sys)
 {
     c->emitter[0] = sys->emitter[0]; c->emitter[1] = sys->emitter[1];
@@ -1662,7 +1717,9 @@ static void note_system(ort_ctx *c, const ort_system *sys)
             ok = (s.kind == ORT_SURF_CYLINDER || s.kind == ORT_SURF_ELLIPSE) && s.kind == sys->surfaces[p][0].kind && !(s.aperture >= 0.0);
         }
         c->scat_k0[p] = ok ? last + 1 : 0;
+        c->cont_prog[p] = false;
     }
+    c->cont_prog[1] = c->scat_k0[1] > 0 && matches_behind<PROG_POINT_WALKED>(sys, c->scat_k0[1]) && !getenv("ORT_NO_PROGRAMS");
     c->prog[0] = c->prog[1] = PROG_GENERIC;
 #define ORT_MATCH(P) if (matches<P>(sys)) c->prog[Prog<P>::phase - 1] = P;
     ORT_PROGRAMS(ORT_MATCH)
@@ -2122,8 +2179,12 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
             if (anysrc_emitter) hipLaunchKernelGGL(scatter_front_kernel<true>, dim3(waves), dim3(64), 0, c->stream, a);
             else hipLaunchKernelGGL(scatter_front_kernel<false>, dim3(waves), dim3(64), 0, c->stream, a);
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL((trace_queue_kernel<MODE_CONTINUE, true, false, double, PROG_GENERIC, false>), dim3(grid), dim3(kBlock), 0,
-                               c->stream, a);
+            if (c->cont_prog[a.phase - 1])
+                hipLaunchKernelGGL((trace_queue_kernel<MODE_CONTINUE, true, false, double, PROG_POINT_WALKED, false>), dim3(grid), dim3(kBlock), 0,
+                                   c->stream, a);
+            else
+                hipLaunchKernelGGL((trace_queue_kernel<MODE_CONTINUE, true, false, double, PROG_GENERIC, false>), dim3(grid), dim3(kBlock), 0,
+                                   c->stream, a);
         } else
         launch_one(c, mode, a, grid, queued, filt, anysrc);
         c->launch_ev[0] = c->launch_ev[1] = nullptr;

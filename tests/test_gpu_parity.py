@@ -587,6 +587,34 @@ def test_scattering_pipeline_equals_monolithic_and_lockstep_kernels(ctxs, name):
     assert int(out[0][1][5]) > 100_000                      # rays do get through
 
 
+def test_scattering_front_kernel_defers_like_the_lean_kernel(hip_library):
+    """scatter_front_kernel evaluates the wall quadratics, every leg's quadratic and the inner wall's normal + Fresnel step in
+    their filtered forms; a ray on a decision boundary is listed for the literal re-run from its emission.  Random rays almost
+    never are (7 of 4e7); the `spot` source's are ALL axial: every ray that reaches the inner wall unscattered meets it at
+    normal incidence (costt == 1, `rare`), so the front kernel's deferrals run by the thousand here — and image and
+    counters still equal the monolithic and the lockstep kernels', bit for bit."""
+    from opticalraytrace_amd.capi import Context
+    from opticalraytrace_amd.params import Settings, resource_dir
+    from opticalraytrace_amd.system import OpticalSystem
+    from conftest import res_dir_with_image
+    res = res_dir_with_image(resource_dir())
+    n = 300_011
+    osys = OpticalSystem.from_settings(Settings(nphotons=n, make_images=True, bottle_file="scatterBottle-both.params", light_source="spot"), res)
+    with Context(osys) as ctx:
+        out, deferred = [], []
+        for variant in (1, 17, 0):
+            ctx.set_kernel_variant(variant)
+            ctx.reset()
+            ctx.trace(2, 7, n, SEED)
+            ctx.trace(1, 0, 50_000, SEED)
+            out.append(ctx.read())
+            deferred.append(ctx.work_counters()[1])
+    for v in (1, 2):
+        assert np.array_equal(out[0][0], out[v][0]) and np.array_equal(out[0][1], out[v][1]), v
+    assert deferred[0] > 1_000, deferred                     # the pipeline's own deferrals (2 083: the rays that reach the inner wall unscattered)
+    assert int(out[0][1][3]) > n
+
+
 @pytest.mark.parametrize("name", ["small_scatter_c", "small_scatter_bc"])
 def test_uniform_zero_in_the_walk_and_the_fresnel_steps(ctxs, name):
     """ORT-RNG-v2 uniforms carry 32 bits (u = w 2^-32): an exact u == 0 occurs ~5 times per 1e9-ray layer (the
