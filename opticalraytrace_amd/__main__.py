@@ -14,8 +14,8 @@ Exit status: 0, or non-zero with a message on stderr where the reference would `
 (unreadable / truncated input files, an unknown light source, ...) — which is what
 `runner.py:47` (`subprocess.run(..., check=True)`) relies on.  Started under
 `torch.distributed.run` (WORLD_SIZE > 1) every rank traces its shard of the rays, the image is
-summed over RCCL and rank 0 writes the files.  There is no CPU fallback: without a HIP device
-the run fails (exit status 3)."""
+summed over RCCL and rank 0 writes the files; a process on its own does not load torch at all (ORT_NO_TORCH=0
+makes it).  There is no CPU fallback: without a HIP device the run fails (exit status 3)."""
 from __future__ import annotations
 
 import argparse
@@ -61,8 +61,12 @@ def main(argv=None) -> int:
         print(f"raytrace: {e}", file=sys.stderr)
         return 1
     try:
+        if world == 1:
+            # a process of its own for ONE simulation (runner.py:26-47): no torch — its import is ~1 s of such a
+            # process — the library's own accumulators (tracer.LocalTracer)
+            os.environ.setdefault("ORT_NO_TORCH", "1")
         from .capi import OrtError
-        from .tracer import (RayTracer, append_stats, output_basename, write_images,
+        from .tracer import (LocalTracer, RayTracer, append_stats, output_basename, write_images,
                              write_tracker_files)
         group = None
         if world > 1:
@@ -77,7 +81,10 @@ def main(argv=None) -> int:
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
             else:
                 dist.init_process_group(backend, rank=rank, world_size=world)
-        tracer = RayTracer(system, device=device, rank=rank, world=world, process_group=group)
+        if world == 1 and os.environ.get("ORT_NO_TORCH") == "1":
+            tracer = LocalTracer(system, device=device)
+        else:
+            tracer = RayTracer(system, device=device, rank=rank, world=world, process_group=group)
         try:
             res = tracer.run()
             folder = os.path.join(data_dir, settings.data_folder)

@@ -159,14 +159,17 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if _LIB is not None and path is None:
         return _LIB
     p = path or library_path()
-    try:
-        # PyTorch-ROCm bundles its own HIP/HSA runtime.  It must be the first one loaded into
-        # the process: libort_hip.so then binds to that same runtime (same SONAME), and torch
-        # tensors, streams and RCCL share one device context with the kernels.  Loading
-        # /opt/rocm's runtime first leaves torch with "No HIP GPUs are available".
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    if os.environ.get("ORT_NO_TORCH") != "1":
+        try:
+            # PyTorch-ROCm bundles its own HIP/HSA runtime.  It must be the first one loaded into
+            # the process: libort_hip.so then binds to that same runtime (same SONAME), and torch
+            # tensors, streams and RCCL share one device context with the kernels.  Loading
+            # /opt/rocm's runtime first leaves torch with "No HIP GPUs are available".
+            # (ORT_NO_TORCH=1: a process that will never import torch — the single-GPU process entry, whose start-up
+            # would otherwise be mostly that import — lets the library bind to /opt/rocm's runtime.)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(p):
         raise OrtError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; "
                        "g.build()'` — there is no CPU fallback for the trace path")

@@ -213,6 +213,28 @@ class RayTracer(ShardedRun):
         self.ctx.attach_buffers(self.image.data_ptr(), self.counters.data_ptr())
 
 
+class LocalTracer:
+    """One process, one GPU, no torch: both loops into the library's own accumulators, read back by ort_read.  This is
+    what `python -m opticalraytrace_amd` uses when it is not started under torch.distributed.run — runner.py's model is
+    one PROCESS per simulation (:26-47), and importing torch is most of such a process's life.  Same calls, same
+    results as RayTracer with world == 1 (tests/test_gpu_host.py).  No CPU fallback."""
+
+    def __init__(self, system: OpticalSystem, device: int = 0):
+        self.system = system
+        self.ctx = Context(system, device=device)
+
+    def close(self) -> None:
+        self.ctx.close()
+
+    def run(self, nphotons: Optional[int] = None, seed: int = DEFAULT_SEED, phases=(1, 2)) -> RunResult:
+        n = self.system.settings.nphotons if nphotons is None else nphotons
+        self.ctx.reset()
+        for phase in phases:
+            self.ctx.trace(phase, 0, n, seed)
+        image, counters = self.ctx.read()
+        return RunResult(image, counters.astype(np.uint64), n)
+
+
 # ---------------------------------------------------------------------------
 # output side of the boundary: src/main.f90:45-48, :168-185; src/imageMod.f90:93-114
 # ---------------------------------------------------------------------------
@@ -294,7 +316,7 @@ def format_paths(path: np.ndarray, npath: np.ndarray, status: np.ndarray) -> str
     return "".join(out)
 
 
-def write_tracker_files(tracer: "RayTracer", system: OpticalSystem, folder: str,
+def write_tracker_files(tracer, system: OpticalSystem, folder: str,
                         seed: int = DEFAULT_SEED) -> Tuple[str, str]:
     """`use_tracker`: dump the paths of the run's rays (at most 1e4, setupMod.f90:75)."""
     n = system.settings.nphotons

@@ -81,6 +81,19 @@ def test_entry_point_writes_what_run_settings_writes(tmp_path, hip_library):
     p = _run(str(tmp_path), "res/test_0.params", "--data", "data2", "--quiet")
     assert p.returncode == 0 and p.stdout == ""
     assert sorted(f for f in os.listdir(tmp_path / "data2" / "images") if "image" in f) == names
+    # a process on its own never loads torch (tracer.LocalTracer: runner.py starts one process per simulation, and the
+    # import would be most of its life) ...
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    code = ("import sys; from opticalraytrace_amd.__main__ import main; rc = main(['res/test_0.params', '--data', 'data3', '--quiet']); "
+            "print('torch' in sys.modules); sys.exit(rc)")
+    p = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip() == "False", (p.stdout, p.stderr[-1000:])
+    # ... and with torch (ORT_NO_TORCH=0: RayTracer, the tracer of the multi-rank run) writes the same bytes
+    p = subprocess.run([sys.executable, "-c", code.replace("data3", "data4")], cwd=str(tmp_path), env=dict(env, ORT_NO_TORCH="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip() == "True", (p.stdout, p.stderr[-1000:])
+    for n in names:
+        assert np.array_equal(np.fromfile(tmp_path / "data3" / "images" / n), np.fromfile(tmp_path / "data4" / "images" / n)), n
 
 
 @pytest.mark.gpu
