@@ -587,6 +587,48 @@ def test_scattering_pipeline_equals_monolithic_and_lockstep_kernels(ctxs, name):
     assert int(out[0][1][5]) > 100_000                      # rays do get through
 
 
+def test_scattering_pipeline_over_random_media_and_systems(hip_library, tmp_path):
+    """The pipeline == the monolithic kernel == the lockstep kernel, bit for bit, over random scattering media (wall only,
+    contents only, both; thin to thick), both bottle sizes, every lens pair and the iris in its three positions — i.e. with
+    the continuation as a surface program (the point loop's list behind the wall the rays are handed over at, from its
+    second wall on or from the plano-convex lens on) and as the generic walk (any list with an iris in it)."""
+    import shutil
+    from opticalraytrace_amd.capi import Context
+    from opticalraytrace_amd.params import Settings, resource_dir
+    from opticalraytrace_amd.system import OpticalSystem
+    from conftest import res_dir_with_image
+    res = str(tmp_path / "res")
+    shutil.copytree(res_dir_with_image(resource_dir()), res)
+    rng = np.random.default_rng(20260)
+    l2 = sorted(f for f in os.listdir(res) if f.startswith("planoConvex-f"))
+    l3 = sorted(f for f in os.listdir(res) if f.startswith("achromaticDoublet-f"))
+    n, binned = 60_011, 0
+    for case in range(36):
+        base = open(os.path.join(res, ("clearBottle-small.params", "clearBottle-large.params")[case % 2])).read().splitlines()[:12]
+        kind = case % 3                                     # wall only / contents only / both
+        wall = [rng.uniform(0., 50.), rng.uniform(50., 700.)] if kind != 1 else [0., 0.]
+        cont = [rng.uniform(0., 40.), rng.uniform(15., 400.)] if kind != 0 else [0., 0.]
+        name = f"scatter-random-{case}.params"
+        with open(os.path.join(res, name), "w") as f:
+            f.write("\n".join(base + [repr(float(m)) for m in wall + cont]) + "\n")
+        iris = ("none", "none", "before", "after")[case % 4]
+        s = Settings(nphotons=n, make_images=True, bottle_file=name, iris=iris, iris_size=float(rng.uniform(0.5, 1.0)),
+                     L2_file=l2[int(rng.integers(len(l2)))], L3_file=l3[int(rng.integers(len(l3)))])
+        osys = OpticalSystem.from_settings(s, res)
+        with Context(osys) as ctx:
+            out = []
+            for variant in (1, 17, 0):
+                ctx.set_kernel_variant(variant)
+                ctx.reset()
+                ctx.trace(2, 1000 * case, n, SEED + case)
+                out.append(ctx.read())
+        for v in (1, 2):
+            assert np.array_equal(out[0][0], out[v][0]) and np.array_equal(out[0][1], out[v][1]), (case, kind, iris, v, out[0][1], out[v][1])
+        assert int(out[0][1][3]) > n, (case, out[0][1])     # the walk ran
+        binned += int(out[0][1][5])
+    assert binned > 30_000
+
+
 def test_scattering_front_kernel_defers_like_the_lean_kernel(hip_library):
     """scatter_front_kernel evaluates the wall quadratics, every leg's quadratic and the inner wall's normal + Fresnel step in
     their filtered forms; a ray on a decision boundary is listed for the literal re-run from its emission.  Random rays almost
