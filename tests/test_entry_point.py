@@ -97,6 +97,24 @@ def test_entry_point_writes_what_run_settings_writes(tmp_path, hip_library):
 
 
 @pytest.mark.gpu
+def test_entry_point_with_the_tracker_on(tmp_path, hip_library):
+    """use_tracker (src/main.f90:72-74, :121-124, :183): the two path dumps are written, the images are not, the stats
+    record is — by the torch-free process and by run_settings alike, byte for byte."""
+    from opticalraytrace_amd.tracer import run_settings
+    s = _tree(tmp_path, nphotons=2000, use_tracker=True, light_source="spot", bottle_file="clearBottle-small.params")
+    p = _run(str(tmp_path / "bin"), "test_0.params")
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = tmp_path / "data" / "images"
+    names = sorted(os.listdir(got))
+    dumps = [n for n in names if n.endswith("trace.dat")]
+    assert len(dumps) == 2 and not [n for n in names if "_image" in n] and "trans-stats.dat" in names, names
+    run_settings(s, str(tmp_path / "res"), str(tmp_path / "want"), verbose=False)
+    for n in dumps + ["trans-stats.dat"]:
+        assert open(got / n).read() == open(tmp_path / "want" / "images" / n).read(), n
+    assert os.path.getsize(got / dumps[0]) > 1000
+
+
+@pytest.mark.gpu
 def test_entry_point_under_a_two_rank_launcher(tmp_path, hip_library):
     """`torch.distributed.run --nproc-per-node 2 -m opticalraytrace_amd <settings>`: every rank traces its shard, the
     image is summed over the ranks, rank 0 alone writes — the same three image files and stats record as the one-process
