@@ -1199,8 +1199,9 @@ __device__ inline void emit_spot(const Sys &S, RayT<T> &r, uint64_t ray)
 // point_on_bottle, src/sourceMod.f90:50-89 (the "crs" source of phase 1): cone direction as
 // `point`, start position = a Gaussian spot (rang, src/random_mod.f90:59-85: polar Box-Muller,
 // a variable number of draws) dropped along -z onto the cylinder radiusa + thickness.
-template <class T, class Sys, class D>
-__device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws)
+// FILT (the crs program): the drop onto the cylinder through the filtered quadratic — the same bits, or `rare`
+template <class T, bool FILT = false, class Sys, class D>
+__device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws, bool &rare)
 {
     T phi = S.twopi * draws.template next_as<T>();
     T sinp, cosp;
@@ -1226,8 +1227,8 @@ __device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws)
     RayT<T> drop = {{tmp1, tmp2, T(1.0)}, {T(0.), T(0.), T(-1.)}};
     T t;
     bool hit;
-    bool unused = false;
-    intersect_quadric<false, T>(drop, T(0.), S.crs_cy, S.crs_cz, S.crs_radius, T(0.), true, true, t, hit, unused);
+    if constexpr (FILT) intersect_quadric<true, T>(drop, T(0.), T(S.crs_cy), T(S.crs_cz), T(S.crs_radius), T(S.crs_radius) * T(S.crs_radius), true, true, t, hit, rare);
+    else { bool unused = false; intersect_quadric<false, T>(drop, T(0.), S.crs_cy, S.crs_cz, S.crs_radius, T(0.), true, true, t, hit, unused); }
     t = hit ? t : T(0.);                                   // the reference leaves t undefined on a miss
     r.pos = vadd(drop.pos, vscale(drop.dir, t));
     r.dir = {sint * cosp, sint * sinp, cost};
@@ -1260,9 +1261,11 @@ __device__ inline void rang(D &draws, T sigma, T &gx, T &gy)
 // and brought to its inner wall; then aimed at a uniform point of the lens disc.  Returns false
 // where the reference aborts (`error stop "no intersection with bottle!"`, :216-218: the beam
 // reflected at the axicon and flies away from the bottle): the ray ends as ORT_ST_NO_INTERSECTION
-// with no further draw.  Literal arithmetic throughout (intersect_cone = src/surfaces.f90:179-224).
-template <class T, class Sys, class D>
-__device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws)
+// with no further draw.  Literal arithmetic throughout (intersect_cone = src/surfaces.f90:179-224) — except FILT (the
+// isors program): the cone's normal, the Fresnel step at it, the bottle quadratic and the aim at the lens in their
+// filtered forms (the same bits, or `rare`); the cone's own quadratic has a < 0 and stays literal.
+template <class T, bool FILT = false, class Sys, class D>
+__device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws, bool &rare)
 {
     T gx, gy;
     rang<T>(draws, T(S.isors_sigma), gx, gy);
@@ -1281,11 +1284,13 @@ __device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws)
     {
         const VecT<T> hitp = vadd(pos, vscale(dir, t));
         VecT<T> N = {ORT_DIV(T(2.) * (hitp.x - T(0.)), k), ORT_DIV(T(2.) * (hitp.y - T(0.)), k), -(T(2.) * (hitp.z - T(0.))) + T(2.) * height};
-        N = vnormalise(vscale(N, T(-1.)));
+        if constexpr (FILT) N = vnormalise_f<true, T>(vscale(N, T(-1.)), cone, rare);
+        else N = vnormalise(vscale(N, T(-1.)));
         const T u = draws.template peek_as<T>();
         draws.advance(cone);
         VecT<T> d2 = dir;
-        (void)reflect_refract<false, true, T>(d2, N, T(1.4), T(1.), T(1.4) / T(1.), T(0.), u, true, unused);
+        if constexpr (FILT) (void)reflect_refract<true, true, T>(d2, N, T(1.4), T(1.), T(1.4) / T(1.), (T(1.4) / T(1.)) * (T(1.4) / T(1.)), u, cone, rare);
+        else (void)reflect_refract<false, true, T>(d2, N, T(1.4), T(1.), T(1.4) / T(1.), T(0.), u, true, unused);
         const T tt = ORT_DIV(T(S.isors_base_pos), d2.z);
         VecT<T> p2 = vadd(hitp, vscale(d2, tt));
         p2.z = T(S.isors_z);
@@ -1295,6 +1300,8 @@ __device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws)
         bool hitb;
         if (__builtin_amdgcn_readfirstlane(S.ring_ellipse))
             intersect_ellipse<false, T>(probe, T(S.isors_cy), T(S.isors_cz), T(S.isors_rad1), T(S.isors_rad2), T(0.), T(0.), true, tb, hitb, unused);
+        else if constexpr (FILT)
+            intersect_quadric<true, T>(probe, T(0.), T(S.isors_cy), T(S.isors_cz), T(S.isors_rad1), T(S.isors_rad1) * T(S.isors_rad1), true, cone, tb, hitb, rare);
         else
             intersect_quadric<false, T>(probe, T(0.), T(S.isors_cy), T(S.isors_cz), T(S.isors_rad1), T(0.), true, true, tb, hitb, unused);
         ok = !cone || hitb;
@@ -1310,8 +1317,15 @@ __device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws)
     { const SinCosT<T> sc_ = sincos_v<T>(theta); st = sc_.s; ct = sc_.c; }
     T sq = ORT_SQRT(rr);
     T ex = sq * ct - pos.x, ey = sq * st - pos.y, ez = T(S.isors_lens_z) - pos.z;
-    T dist = ORT_SQRT(ex * ex + ey * ey + ez * ez);
-    const VecT<T> aimed = vnormalise(div3(VecT<T>{ex, ey, ez}, dist));
+    VecT<T> aimed;
+    if constexpr (FILT) {
+        // (as emit_ring: the second normalisation acts on a unit vector)
+        const T dist = sqrt_f<true, T>(ex * ex + ey * ey + ez * ez, ok, rare);
+        aimed = vnormalise_est<true, T>(div3_f<true, T>(VecT<T>{ex, ey, ez}, dist, ok, rare), T(1.), T(0.5), T(0.25), T(0x1p-32), ok, rare);
+    } else {
+        const T dist = ORT_SQRT(ex * ex + ey * ey + ez * ez);
+        aimed = vnormalise(div3(VecT<T>{ex, ey, ez}, dist));
+    }
     r.pos = pos;
     r.dir = vselect(ok, aimed, dir);
     return ok;
@@ -1389,12 +1403,12 @@ __device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64
                            int *img_hint = nullptr)
 {
     if constexpr (EMITTER >= 0) {
-        bool unused = false;                              // the emitters other than ring / point are literal throughout
+        bool unused = false;                              // spot and image are literal throughout
         if constexpr (EMITTER == ORT_EMIT_RING) emit_ring<T, FILT>(S, r, draws, rare);
         else if constexpr (EMITTER == ORT_EMIT_POINT) emit_point<T, FILT>(S, r, draws, rare);
         else if constexpr (EMITTER == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray);
-        else if constexpr (EMITTER == ORT_EMIT_CRS) emit_crs<T>(S, r, draws);
-        else if constexpr (EMITTER == ORT_EMIT_ISORS) return emit_isors<T>(S, r, draws) ? -1 : ORT_ST_NO_INTERSECTION;
+        else if constexpr (EMITTER == ORT_EMIT_CRS) emit_crs<T, FILT>(S, r, draws, rare);
+        else if constexpr (EMITTER == ORT_EMIT_ISORS) return emit_isors<T, FILT>(S, r, draws, rare) ? -1 : ORT_ST_NO_INTERSECTION;
         else return emit_image<T>(S, cdf, r, draws, ray, img_hint) ? -1 : ORT_ST_LOST_TELESCOPE;
         (void)unused;
         return -1;
@@ -1409,8 +1423,8 @@ __device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64
     if (e == ORT_EMIT_RING) emit_ring<T>(S, r, draws, unused);
     else if (e == ORT_EMIT_POINT) emit_point<T>(S, r, draws, unused);
     else if (e == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray);
-    else if (e == ORT_EMIT_CRS) emit_crs<T>(S, r, draws);
-    else if (e == ORT_EMIT_ISORS) return emit_isors<T>(S, r, draws) ? -1 : ORT_ST_NO_INTERSECTION;
+    else if (e == ORT_EMIT_CRS) emit_crs<T>(S, r, draws, unused);
+    else if (e == ORT_EMIT_ISORS) return emit_isors<T>(S, r, draws, unused) ? -1 : ORT_ST_NO_INTERSECTION;
     else return emit_image<T>(S, cdf, r, draws, ray) ? -1 : ORT_ST_LOST_TELESCOPE;
     return -1;
 }

@@ -1262,6 +1262,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sc
     const int lane = threadIdx.x;
     const int ph = a.phase - 1;
     const ort_surface *surf = S.surfaces[ph];
+    // albedo of every surface's medium (lens.f90:266, :317), the division done once per wave instead of once per event
+    __shared__ double ALB[ORT_MAX_SURFACES];
+    if (lane < ORT_MAX_SURFACES) ALB[lane] = surf[lane].mus / (surf[lane].mus + surf[lane].mua);
+    __syncthreads();
     const int kind0 = __builtin_amdgcn_readfirstlane(surf[0].kind);      // host: the same for every surface in front of cont_k0
     const int klast = a.cont_k0 - 1;
     // this wave's contiguous range of ray indices (equal ranges: the walk lengths average out over a range)
@@ -1367,7 +1371,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sc
             int ended = -1;
             bool walking = act;
             r.pos = vselect(walking, vadd(r.pos, vscale(r.dir, t)), r.pos);
-            const double albedo = s.mus / (s.mus + s.mua);
+            const double albedo = ALB[k];
             const double u = d.peek();
             d.advance(walking);
             const bool absorbed = walking && !(u < albedo);

@@ -501,12 +501,15 @@ def test_launches_are_cut_at_the_rerun_list_capacity(ctxs):
     assert np.array_equal(img_a, img_c) and np.array_equal(cnt_a, cnt_c)
 
 
-@pytest.mark.parametrize("name", ["large", "small", "large_iris_before", "small_iris_after", "small_f60_nobottle", "ellipse", "small_spot"])
+@pytest.mark.parametrize("name", ["large", "small", "large_iris_before", "small_iris_after", "small_f60_nobottle", "ellipse", "small_spot",
+                                  "large_crs", "small_isors"])
 def test_program_kernels_equal_the_generic_walk(name, hip_library):
     """The queued kernel is specialised for the default surface programs and their iris variants
     (kinds, flags and aperture presence as template constants) when the staged system matches
     one; ORT_NO_PROGRAMS forces the generic walk.  Same image, same counters — also for a system
-    that matches no program (the spot source), where both contexts run the generic kernel."""
+    that matches no program (the spot source), where both contexts run the generic kernel, and for the crs and isors
+    programs, whose emitters run filtered forms (the drop onto the bottle, the axicon's normal + Fresnel step, the bottle
+    quadratic, the aim at the lens) where the generic walk's and the lockstep kernel's are literal."""
     from opticalraytrace_amd.capi import Context
     _, osys = make_system(name)
     n = 300000
