@@ -1,0 +1,480 @@
+// ort_libm.h — the reference's transcendental functions, bit for bit.
+//
+// The reference (Fortran, all `real` fp64) calls sin / cos / log / atan2 / acos of the platform's libm:
+// built with flang or gfortran on x86-64 Linux these resolve to glibc.  glibc's double-precision functions
+// are NOT correctly rounded (documented errors 0.50 - 0.56 ulp), so "the reference's result" is whatever
+// glibc's own algorithm produces, and neither a correctly rounded function nor another good libm (the ROCm
+// device library: <= 1 - 2 ulp) reproduces it: the in-bottle scattering walk (src/stokes.f90:7-166,
+// src/surfaces.f90:13-50) amplifies a last-bit difference in atan2 / sin / cos of the azimuth to 1e-10 in
+// 2e-5 of its rays.  This file therefore RESTATES glibc's algorithms, operation for operation, so that the
+// device returns glibc's bits.
+//
+// Third-party dependency restated: GNU C Library 2.35 (Ubuntu GLIBC 2.35-0ubuntu3.11), x86-64, the variants
+// its ifunc resolvers select on a CPU with FMA + AVX2 (every x86-64 server CPU since 2013/2015; the test
+// session checks the host's libm against known answers and says so if it is another one):
+//   sin, cos         sysdeps/ieee754/dbl-64/s_sin.c      built with -mfma -mavx2  (__sin_fma, __cos_fma)
+//   sincos           sysdeps/ieee754/dbl-64/s_sincos.c   NO multiarch variant in 2.35: built without FMA
+//   log              sysdeps/ieee754/dbl-64/e_log.c      (__ieee754_log_fma)
+//   atan2            sysdeps/ieee754/dbl-64/e_atan2.c    (__ieee754_atan2_fma)
+//   acos             sysdeps/ieee754/dbl-64/e_asin.c     (__ieee754_acos_fma)
+// Which products the compiler fused into FMAs decides the last bit, so the operation sequences below were
+// taken from the machine code of /lib/x86_64-linux-gnu/libm-2.35.a (objdump of s_sin-fma.o, e_log-fma.o,
+// e_atan2-fma.o, e_asin-fma.o, s_sincos.o), the tables from the same archive (tools/make_libm_tables.py ->
+// ort_libm_tables.h).  Every fused operation is an explicit __builtin_fma; everything else relies on
+// -ffp-contract=off (the build's setting).  tests/csrc/check_libm_host.cpp compiles THIS header for the host
+// and compares every function with the host's libm over 1e8+ arguments (bit for bit);
+// tests/csrc/check_libm_gpu.hip does the same for the device code.
+//
+// Domain: what the tracer passes — finite arguments, |x| < 1.05e8 for sin / cos / sincos, x >= 0 for log,
+// |x| <= 1 for acos, finite atan2 operands.  Anything else (NaN, infinities, huge angles, subnormals where
+// glibc takes a special path) goes to ORT_LIBM_FALLBACK, the platform's own function: never reached by a ray.
+#pragma once
+#include <stdint.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ORT_LIBM_FN __host__ __device__ inline
+#define ORT_LIBM_TABLE __device__ __constant__ const
+#define ORT_LIBM_HOST_TABLE 0
+#else
+#include <math.h>
+#define ORT_LIBM_FN static inline
+#define ORT_LIBM_TABLE static const
+#define ORT_LIBM_HOST_TABLE 1
+#endif
+#include "ort_libm_tables.h"
+
+namespace ort {
+namespace glibc {
+
+ORT_LIBM_FN uint64_t bits(double x) { return __builtin_bit_cast(uint64_t, x); }
+ORT_LIBM_FN double dbl(uint64_t b) { return __builtin_bit_cast(double, b); }
+ORT_LIBM_FN double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+ORT_LIBM_FN double abs_(double x) { return dbl(bits(x) & 0x7fffffffffffffffull); }
+ORT_LIBM_FN double copysign_(double x, double s) { return dbl((bits(x) & 0x7fffffffffffffffull) | (bits(s) & 0x8000000000000000ull)); }
+ORT_LIBM_FN int32_t hi_word(double x) { return (int32_t)(bits(x) >> 32); }
+ORT_LIBM_FN uint32_t lo_word(double x) { return (uint32_t)bits(x); }
+#define ORT_LM(b) (::ort::glibc::dbl(b##ull))
+
+// table element i as a double (host code reads the host copy of the table; a __constant__ array is the
+// device's)
+#if defined(__HIP_DEVICE_COMPILE__) || ORT_LIBM_HOST_TABLE
+#define ORT_LIBM_TAB(t, i) (::ort::glibc::dbl((t)[i]))
+#else
+#define ORT_LIBM_TAB(t, i) (0.0)     /* host pass of hipcc: these functions are only ever called on the device */
+#endif
+
+struct SinCos { double s, c; };
+
+// ---------------------------------------------------------------------------------------------------------
+// sin / cos / sincos: s_sin.c.  x is cut into X = a multiple of 1/128 (table: sin X, cos X as double-double
+// sn + ssn, cs + ccs) and a remainder |x - X| <= 1/256 with short Taylor polynomials; |x| < 0.126 uses a
+// Taylor polynomial alone; 0.855 <= |x| < 2.43 goes through pi/2 - |x|; beyond that a Cody-Waite reduction
+// by pi/2 in four pieces (mp1, mp2, pp3, pp4).
+// ---------------------------------------------------------------------------------------------------------
+namespace sc {
+constexpr uint64_t BIG = 0x42c8000000000000, SN3 = 0xbfc5555555555515, SN5 = 0x3f811110e829872f, CS2 = 0x3fe0000000000000,
+                   CS4 = 0xbfa5555555555535, CS6 = 0x3f56c16bedd9e239, S1 = 0xbfc5555555555555, S2 = 0x3f81111111110ece,
+                   S3 = 0xbf2a01a019db08b8, S4 = 0x3ec71de27b9a7ed9, S5 = 0xbe5addffc2fcdf59, HP0 = 0x3ff921fb54442d18,
+                   HP1 = 0x3c91a62633145c07, HPINV = 0x3fe45f306dc9c883, TOINT = 0x4338000000000000, MP1 = 0x3ff921fb58000000,
+                   MP2 = 0xbe4dde973c000000, PP3 = 0xbc8cb3b398000000, PP4 = 0xbacd747f23e32ed7, T126 = 0x3fc020c49ba5e354;
+}
+#define ORT_SCK(n) (::ort::glibc::dbl(::ort::glibc::sc::n))
+
+// SINCOS_TABLE_LOOKUP: u = big + |x|; its low word counts 1/128ths
+ORT_LIBM_FN void sincos_lookup(double u, double &sn, double &ssn, double &cs, double &ccs)
+{
+    const int k = (int)(lo_word(u) << 2);
+    sn = ORT_LIBM_TAB(kGlibcSinCosTab, k); ssn = ORT_LIBM_TAB(kGlibcSinCosTab, k + 1);
+    cs = ORT_LIBM_TAB(kGlibcSinCosTab, k + 2); ccs = ORT_LIBM_TAB(kGlibcSinCosTab, k + 3);
+}
+
+// FMA = true: the contraction of s_sin-fma.o (sin, cos); false: the separately rounded operations of s_sincos.o
+template <bool FMA> ORT_LIBM_FN double taylor_sin(double x, double dx)       // TAYLOR_SIN(x*x, x, dx), |x| < 0.126
+{
+    const double xx = x * x;
+    if (FMA) {
+        const double p = fma_(xx, fma_(xx, fma_(xx, fma_(xx, ORT_SCK(S5), ORT_SCK(S4)), ORT_SCK(S3)), ORT_SCK(S2)), ORT_SCK(S1));
+        const double t = fma_(xx, fma_(p, x, -(0.5 * dx)), dx);
+        return x + t;
+    }
+    const double p = ((((ORT_SCK(S5) * xx + ORT_SCK(S4)) * xx + ORT_SCK(S3)) * xx + ORT_SCK(S2)) * xx) + ORT_SCK(S1);
+    const double t = ((p * x - 0.5 * dx) * xx + dx);
+    return x + t;
+}
+
+template <bool FMA> ORT_LIBM_FN double do_sin_big(double x, double dx)       // do_sin for |x| >= 0.126
+{
+    const double xold = x;
+    if (x <= 0) dx = -dx;
+    const double ax = abs_(x), u = ORT_SCK(BIG) + ax;
+    x = ax - (u - ORT_SCK(BIG));
+    double sn, ssn, cs, ccs;
+    sincos_lookup(u, sn, ssn, cs, ccs);
+    const double xx = x * x;
+    double cor;
+    if (FMA) {
+        const double s = x + fma_(x * xx, fma_(xx, ORT_SCK(SN5), ORT_SCK(SN3)), dx);
+        const double c = fma_(x, dx, xx * fma_(xx, fma_(xx, ORT_SCK(CS6), ORT_SCK(CS4)), ORT_SCK(CS2)));
+        cor = fma_(s, cs, fma_(-c, sn, fma_(s, ccs, ssn)));
+    } else {
+        const double s = x + (dx + x * xx * (ORT_SCK(SN3) + xx * ORT_SCK(SN5)));
+        const double c = x * dx + xx * (ORT_SCK(CS2) + xx * (ORT_SCK(CS4) + xx * ORT_SCK(CS6)));
+        cor = (ssn + s * ccs - sn * c) + cs * s;
+    }
+    return copysign_(sn + cor, xold);
+}
+template <bool FMA> ORT_LIBM_FN double do_sin(double x, double dx)
+{
+    if (abs_(x) < ORT_SCK(T126)) return taylor_sin<FMA>(x, dx);
+    return do_sin_big<FMA>(x, dx);
+}
+
+template <bool FMA> ORT_LIBM_FN double do_cos(double x, double dx)
+{
+    if (x < 0) dx = -dx;
+    const double ax = abs_(x), u = ORT_SCK(BIG) + ax;
+    x = ax - (u - ORT_SCK(BIG)) + dx;
+    double sn, ssn, cs, ccs;
+    sincos_lookup(u, sn, ssn, cs, ccs);
+    const double xx = x * x;
+    double cor;
+    if (FMA) {
+        const double s = fma_(x * xx, fma_(xx, ORT_SCK(SN5), ORT_SCK(SN3)), x);
+        const double c = xx * fma_(xx, fma_(xx, ORT_SCK(CS6), ORT_SCK(CS4)), ORT_SCK(CS2));
+        cor = fma_(-s, sn, fma_(-c, cs, fma_(-s, ssn, ccs)));
+    } else {
+        const double s = x + x * xx * (ORT_SCK(SN3) + xx * ORT_SCK(SN5));
+        const double c = xx * (ORT_SCK(CS2) + xx * (ORT_SCK(CS4) + xx * ORT_SCK(CS6)));
+        cor = (ccs - s * ssn - cs * c) - sn * s;
+    }
+    return cs + cor;
+}
+
+// reduce_sincos: x = n pi/2 + (a + da), 2.426265 <= |x| < 105414350
+template <bool FMA> ORT_LIBM_FN int reduce_sincos(double x, double &a, double &da)
+{
+    double t, xn, y, t2, db, b;
+    if (FMA) {
+        t = fma_(x, ORT_SCK(HPINV), ORT_SCK(TOINT));
+        xn = t - ORT_SCK(TOINT);
+        y = fma_(-xn, ORT_SCK(MP2), fma_(-xn, ORT_SCK(MP1), x));
+        t2 = fma_(-xn, ORT_SCK(PP3), y);
+        db = fma_(-ORT_SCK(PP3), xn, y - t2);
+        b = fma_(-xn, ORT_SCK(PP4), t2);
+        db = db + fma_(-xn, ORT_SCK(PP4), t2 - b);
+    } else {
+        t = (x * ORT_SCK(HPINV) + ORT_SCK(TOINT));
+        xn = t - ORT_SCK(TOINT);
+        y = (x - xn * ORT_SCK(MP1)) - xn * ORT_SCK(MP2);
+        double t1 = xn * ORT_SCK(PP3);
+        t2 = y - t1;
+        db = (y - t2) - t1;
+        t1 = xn * ORT_SCK(PP4);
+        b = t2 - t1;
+        db += (t2 - b) - t1;
+    }
+    a = b; da = db;
+    return (int)(lo_word(t) & 3u);
+}
+
+template <bool FMA> ORT_LIBM_FN double do_sincos(double a, double da, int n)
+{
+    double r = (n & 1) ? do_cos<FMA>(a, da) : do_sin<FMA>(a, da);
+    return (n & 2) ? -r : r;
+}
+
+#ifndef ORT_LIBM_FALLBACK_SIN
+#define ORT_LIBM_FALLBACK_SIN(x) ::sin(x)
+#define ORT_LIBM_FALLBACK_COS(x) ::cos(x)
+#define ORT_LIBM_FALLBACK_LOG(x) ::log(x)
+#define ORT_LIBM_FALLBACK_ATAN2(y, x) ::atan2(y, x)
+#define ORT_LIBM_FALLBACK_ACOS(x) ::acos(x)
+#endif
+
+// __sin (s_sin.c), FMA build
+ORT_LIBM_FN double sin(double x)
+{
+    const int32_t k = hi_word(x) & 0x7fffffff;
+    if (k < 0x3e500000) return x;                                    // |x| < 2^-26
+    if (k < 0x3feb6000) return do_sin<true>(x, 0.0);                 // |x| < 0.855469
+    if (k < 0x400368fd) {                                            // |x| < 2.426265
+        const double t = ORT_SCK(HP0) - abs_(x);
+        return copysign_(do_cos<true>(t, ORT_SCK(HP1)), x);
+    }
+    if (k < 0x419921FB) {                                            // |x| < 105414350
+        double a, da;
+        const int n = reduce_sincos<true>(x, a, da);
+        return do_sincos<true>(a, da, n);
+    }
+    return ORT_LIBM_FALLBACK_SIN(x);
+}
+
+// __cos (s_sin.c), FMA build
+ORT_LIBM_FN double cos(double x)
+{
+    const int32_t k = hi_word(x) & 0x7fffffff;
+    if (k < 0x3e400000) return 1.0;                                  // |x| < 2^-27
+    if (k < 0x3feb6000) return do_cos<true>(x, 0.0);
+    if (k < 0x400368fd) {
+        const double y = ORT_SCK(HP0) - abs_(x);
+        const double a = y + ORT_SCK(HP1);
+        const double da = (y - a) + ORT_SCK(HP1);
+        return do_sin<true>(a, da);
+    }
+    if (k < 0x419921FB) {
+        double a, da;
+        const int n = reduce_sincos<true>(x, a, da);
+        return do_sincos<true>(a, da, n + 1);
+    }
+    return ORT_LIBM_FALLBACK_COS(x);
+}
+
+// __sincos (s_sincos.c): the same pieces built WITHOUT fused multiply-adds (glibc 2.35 has no multiarch
+// variant of the double sincos), and with its own split of the middle range — so sincos(x) differs from
+// (sin(x), cos(x)) in the last bit for ~0.1 % of the arguments.  The reference's compilers turn most of
+// its sin/cos pairs into ONE sincos call (which ones: ort_device.h at each call site).
+ORT_LIBM_FN SinCos sincos(double x)
+{
+    const int32_t k = hi_word(x) & 0x7fffffff;
+    if (k < 0x400368fd) {
+        if (k < 0x3e400000) return {x, 1.0};
+        if (k < 0x3feb6000) return {do_sin<false>(x, 0.0), do_cos<false>(x, 0.0)};
+        const double y = ORT_SCK(HP0) - abs_(x);
+        const double a = y + ORT_SCK(HP1);
+        const double da = (y - a) + ORT_SCK(HP1);
+        return {copysign_(do_cos<false>(a, da), x), do_sin<false>(a, da)};
+    }
+    if (k < 0x419921FB) {
+        double a, da;
+        const int n = reduce_sincos<false>(x, a, da);
+        return {do_sincos<false>(a, da, n), do_sincos<false>(a, da, n + 1)};
+    }
+    return {ORT_LIBM_FALLBACK_SIN(x), ORT_LIBM_FALLBACK_COS(x)};
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// log: e_log.c (Szabolcs Nagy's), FMA build.  x = 2^k z, z in [0x1.6p-1, 0x1.6p0); table of 128 (1/c, log c)
+// with c near the centre of each subinterval; r = z/c - 1 exactly by FMA; degree-5 polynomial.  Near 1
+// (1 - 2^-4 <= x < 1 + 0x1.09p-4) a degree-11 polynomial in r = x - 1 with a split r*r.
+// ---------------------------------------------------------------------------------------------------------
+ORT_LIBM_FN double log(double x)
+{
+    const uint64_t ix = bits(x);
+    const uint32_t top = (uint32_t)(ix >> 48);
+#define ORT_LOGD(i) ORT_LIBM_TAB(kGlibcLogData, i)
+    if (ix - 0x3fee000000000000ull < 0x3090000000000ull) {
+        if (ix == 0x3ff0000000000000ull) return 0.0;
+        const double r = x - 1.0;
+        const double r2 = r * r, r3 = r * r2;
+        // B[j] = poly1[j] = data[7 + j]
+        const double p1 = fma_(r2, ORT_LOGD(10), fma_(r, ORT_LOGD(9), ORT_LOGD(8)));            // B1 + r B2 + r2 B3
+        const double p2 = fma_(r2, ORT_LOGD(13), fma_(r, ORT_LOGD(12), ORT_LOGD(11)));          // B4 + r B5 + r2 B6
+        double p3 = fma_(r2, ORT_LOGD(16), fma_(r, ORT_LOGD(15), ORT_LOGD(14)));                // B7 + r B8 + r2 B9
+        p3 = fma_(r3, ORT_LOGD(17), p3);                                                        // + r3 B10
+        const double P = fma_(fma_(p3, r3, p2), r3, p1);
+        const double t = fma_(r, 0x1p27, r);
+        const double rhi = fma_(-0x1p27, r, t);
+        const double rlo = r - rhi;
+        const double rhi2 = rhi * rhi;
+        const double B0 = ORT_LOGD(7);                                                          // -0.5
+        const double hi = fma_(rhi2, B0, r);
+        double lo = fma_(rhi2, B0, r - hi);
+        lo = fma_(B0 * rlo, rhi + r, lo);
+        const double y = fma_(P, r3, lo);
+        return hi + y;
+    }
+    if (top - 0x0010u >= 0x7ff0u - 0x0010u) {
+        if (ix * 2 == 0) return -__builtin_huge_val();               // log(+-0) = -inf
+        return ORT_LIBM_FALLBACK_LOG(x);                             // negative, NaN, inf, subnormal
+    }
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const int i = (int)((tmp >> 45) & 127u);
+    const int k = (int)((int64_t)tmp >> 52);
+    const uint64_t iz = ix - (tmp & 0xfff0000000000000ull);
+    const double invc = ORT_LOGD(18 + 2 * i), logc = ORT_LOGD(18 + 2 * i + 1);
+    const double z = dbl(iz);
+    const double r = fma_(z, invc, -1.0);
+    const double kd = (double)k;
+    const double w = fma_(kd, ORT_LOGD(0), logc);                    // kd Ln2hi + logc
+    const double hi = r + w;
+    double lo = fma_(kd, ORT_LOGD(1), (w - hi) + r);                 // + kd Ln2lo
+    const double r2 = r * r;
+    // A[j] = poly[j] = data[2 + j]
+    lo = fma_(r2, ORT_LOGD(2), lo);
+    const double q = fma_(fma_(r, ORT_LOGD(6), ORT_LOGD(5)), r2, fma_(r, ORT_LOGD(4), ORT_LOGD(3)));
+    return fma_(r * r2, q, lo) + hi;
+#undef ORT_LOGD
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// atan2: e_atan2.c (IBM Accurate Mathematical Library, slow paths removed in glibc 2.28), FMA build.
+// u = min(|x|,|y|) / max(|x|,|y|) with its rounding error du (EMULV by FMA); u < 1/16: odd polynomial; else
+// table cij[i] = {u_i, atan u_i, 5 polynomial coefficients} at i = round(256 u) - 16; the four quadrant
+// combinations add / subtract pi/2 or pi as double-doubles.
+// ---------------------------------------------------------------------------------------------------------
+namespace at {
+constexpr uint64_t D3 = 0xbfd5555555555555, D5 = 0x3fc99999999997fd, D7 = 0xbfc24924923f7603, D9 = 0x3fbc71c6e5129a3b,
+                   D11 = 0xbfb7458022b13c25, D13 = 0x3fb375f08b31cbce, HPI = 0x3ff921fb54442d18, HPI1 = 0x3c91a62633145c07,
+                   OPI = 0x400921fb54442d18, OPI1 = 0x3ca1a62633145c07;
+}
+#define ORT_ATK(n) (::ort::glibc::dbl(::ort::glibc::at::n))
+
+ORT_LIBM_FN double atan2(double y, double x)
+{
+    const uint64_t bx = bits(x), by = bits(y);
+    const int32_t ux = (int32_t)(bx >> 32), uy = (int32_t)(by >> 32);
+    const uint32_t dx = (uint32_t)bx, dy = (uint32_t)by;
+    if ((ux & 0x7ff00000) == 0x7ff00000 || (uy & 0x7ff00000) == 0x7ff00000) return ORT_LIBM_FALLBACK_ATAN2(y, x);   // NaN, inf
+    if (uy == 0 && dy == 0) return (ux < 0) ? ORT_ATK(OPI) : 0.0;                                // y = +0
+    if ((uint32_t)uy == 0x80000000u && dy == 0) return (ux < 0) ? -ORT_ATK(OPI) : -0.0;          // y = -0
+    if (x == 0.0) return (uy < 0) ? -ORT_ATK(HPI) : ORT_ATK(HPI);                                // x = +-0
+    double ax = (x < 0) ? -x : x, ay = (y < 0) ? -y : y;
+    const int de = (uy & 0x7ff00000) - (ux & 0x7ff00000);
+    if (de >= 59768832) return (y > 0) ? ORT_ATK(HPI) : -ORT_ATK(HPI);
+    if (de <= -59768832) {
+        if (x > 0) {
+            const double z = ay / ax;
+            if (z < 0x1p-1022) return ORT_LIBM_FALLBACK_ATAN2(y, x);
+            return copysign_(z, y);
+        }
+        return (y > 0) ? ORT_ATK(OPI) : -ORT_ATK(OPI);
+    }
+    if (ax < 0x1p-500 || ay < 0x1p-500) { ax *= 0x1p500; ay *= 0x1p500; }
+    if (ax > 0x1p500 || ay > 0x1p500) { ax *= 0x1p-500; ay *= 0x1p-500; }
+    double u, du;
+    const bool y_small = ay < ax;              // (i) / (iv): u = ay/ax; else u = ax/ay
+    const bool x_small = ax < ay;              // x <= 0: (iii) if |x| < |y|, else (iv) — |x| = |y| is (iv) with u = 1
+    {
+        const double num = y_small ? ay : ax, den = y_small ? ax : ay;
+        u = num / den;
+        const double v = den * u;
+        const double vv = fma_(den, u, -v);
+        du = ((num - v) - vv) / den;
+    }
+    const bool small = u < 0.0625;
+    double z;
+    if (small) {
+        const double v = u * u;
+        const double p = fma_(v, fma_(v, fma_(v, fma_(v, fma_(v, ORT_ATK(D13), ORT_ATK(D11)), ORT_ATK(D9)), ORT_ATK(D7)), ORT_ATK(D5)), ORT_ATK(D3));
+        if (x > 0 && y_small) {                          // (i) atan(ay/ax)
+            const double zz = fma_(u * v, p, du);
+            z = u + zz;
+        } else {
+            const double zz = (u * v) * p;
+            // (ii) pi/2 - u, (iii) pi/2 + u, (iv) pi - u: ESUB / EADD of the constant and u, then the low parts
+            const bool plus = !(x > 0) && x_small;       // (iii)
+            const bool pi = !(x > 0) && !x_small;        // (iv)
+            const double C = pi ? ORT_ATK(OPI) : ORT_ATK(HPI), C1 = pi ? ORT_ATK(OPI1) : ORT_ATK(HPI1);
+            if (plus) {
+                const double t2 = u + C;                                     // EADD(hpi, u, t2, cor)
+                const double cor = (C > abs_(u)) ? (C - t2) + u : (u - t2) + C;
+                const double t3 = ((C1 + cor) + du) + zz;
+                z = t2 + t3;
+            } else {
+                const double t2 = C - u;                                     // ESUB(C, u, t2, cor)
+                const double cor = (C > abs_(u)) ? (C - t2) - u : C - (u + t2);
+                const double t3 = ((C1 + cor) - du) - zz;
+                z = t2 + t3;
+            }
+        }
+    } else {
+        const int i = (int)(fma_(u, 256.0, 0x1p52) - 0x1p52) - 16;
+#define ORT_CIJ(j) ORT_LIBM_TAB(kGlibcAtanCij, 7 * i + (j))
+        if (x > 0 && y_small) {                          // (i)
+            const double t3 = u - ORT_CIJ(0);
+            const double v = t3 + du;                                        // EADD(t3, du, v, dv)
+            const double dv = (abs_(t3) > abs_(du)) ? (t3 - v) + du : (du - v) + t3;
+            const double t1 = ORT_CIJ(1), t2 = ORT_CIJ(2);
+            const double q = fma_(v, fma_(v, fma_(v, ORT_CIJ(6), ORT_CIJ(5)), ORT_CIJ(4)), ORT_CIJ(3));
+            const double zz = fma_(v, t2, fma_(dv, t2, (v * v) * q));
+            z = t1 + zz;
+        } else {
+            const double v = (u - ORT_CIJ(0)) + du;
+            const double q = fma_(v, fma_(v, fma_(v, fma_(v, ORT_CIJ(6), ORT_CIJ(5)), ORT_CIJ(4)), ORT_CIJ(3)), ORT_CIJ(2));
+            if (x > 0) {                                 // (ii) pi/2 - atan(ax/ay)
+                const double zz = fma_(-v, q, ORT_ATK(HPI1));
+                z = (ORT_ATK(HPI) - ORT_CIJ(1)) + zz;
+            } else if (x_small) {                        // (iii) pi/2 + atan(ax/ay)
+                const double zz = fma_(v, q, ORT_ATK(HPI1));
+                z = (ORT_ATK(HPI) + ORT_CIJ(1)) + zz;
+            } else {                                     // (iv) pi - atan(ay/ax)
+                const double zz = fma_(-v, q, ORT_ATK(OPI1));
+                z = (ORT_ATK(OPI) - ORT_CIJ(1)) + zz;
+            }
+        }
+#undef ORT_CIJ
+    }
+    return copysign_(z, y);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// acos: e_asin.c (IBM), FMA build.  |x| < 1/8: pi/2 - x - x^3 P(x^2); 1/8 <= |x| < 0.96875: six ranges of
+// table-driven polynomials around grid points (asncs: blocks of 11 - 15 doubles); 0.96875 <= |x| < 1:
+// 2 asin(sqrt((1 - |x|)/2)) with an inline square root (inroot / powtwo seeds + one correction).
+// ---------------------------------------------------------------------------------------------------------
+namespace ac {
+constexpr uint64_t F1 = 0x3fc55555555554f9, F2 = 0x3fb333333336127d, F3 = 0x3fa6db6dae42c0e4, F4 = 0x3f9f1c7e04f4ad99,
+                   F5 = 0x3f96e442c822d419, F6 = 0x3f9292d80f453c72, RT0 = 0x3fefffffffecc1dd, RT1 = 0x3fdfffffff757304,
+                   RT2 = 0x3fd800496769c91a, RT3 = 0x3fd4006318d1dab9, HP0 = 0x3ff921fb54442d18, HP1 = 0x3c91a62633145c07,
+                   PI = 0x400921fb54442d18;
+}
+#define ORT_ACK(n) (::ort::glibc::dbl(::ort::glibc::ac::n))
+
+ORT_LIBM_FN double acos(double x)
+{
+    const int32_t m = hi_word(x), k = m & 0x7fffffff;
+    if (k < 0x3c880000) return ORT_ACK(HP0);
+    if (k < 0x3fc00000) {
+        const double x2 = x * x;
+        const double p = fma_(x2, fma_(x2, fma_(x2, fma_(x2, fma_(x2, ORT_ACK(F6), ORT_ACK(F5)), ORT_ACK(F4)), ORT_ACK(F3)), ORT_ACK(F2)), ORT_ACK(F1));
+        const double r = ORT_ACK(HP0) - x;
+        const double cor = fma_(-p, x * x2, ((ORT_ACK(HP0) - r) - x) + ORT_ACK(HP1));
+        return r + cor;
+    }
+    if (k < 0x3fef0000) {
+        // block n of asncs: [0] grid point, [1] first-order coefficient, [2 .. top] higher coefficients,
+        // [top + 1] low part of the constant, [top + 2] the constant
+        int n, top;
+        if (k < 0x3fd00000) { n = 11 * ((k & 0x000fffff) >> 15); top = 6; }
+        else if (k < 0x3fe00000) { n = 11 * ((k & 0x000fffff) >> 14) + 352; top = 6; }
+        else if (k < 0x3fe80000) { n = 1056 + ((k & 0x000fe000) >> 11) * 3; top = 7; }
+        else if (k < 0x3fed8000) { n = 992 + ((k & 0x000fe000) >> 13) * 13; top = 8; }
+        else if (k < 0x3fee8000) { n = 884 + ((k & 0x000fe000) >> 13) * 14; top = 9; }
+        else { n = 768 + ((k & 0x000fe000) >> 13) * 15; top = 10; }
+#define ORT_ASN(j) ORT_LIBM_TAB(kGlibcAcosAsncs, n + (j))
+        const double xs = (m > 0) ? x : -x;
+        const double xx = xs - ORT_ASN(0);
+        double q = ORT_ASN(top);
+        for (int j = top - 1; j >= 2; --j) q = fma_(xx, q, ORT_ASN(j));
+        double t = fma_(xx * xx, q, ORT_ASN(top + 1));
+        t = fma_(xx, ORT_ASN(1), t);
+        const double c = ORT_ASN(top + 2);
+#undef ORT_ASN
+        if (m > 0) return (ORT_ACK(HP1) - t) + (ORT_ACK(HP0) - c);
+        return (t + ORT_ACK(HP1)) + (c + ORT_ACK(HP0));
+    }
+    if (k < 0x3ff00000) {
+        const double z = ((m > 0) ? (1.0 - x) : (x + 1.0)) * 0.5;
+        const int32_t kz = hi_word(z);
+        double t = ORT_LIBM_TAB(kGlibcAcosInroot, (kz >> 14) & 0x7f) * ORT_LIBM_TAB(kGlibcAcosPowtwo, 511 - (kz >> 21));
+        const double r = fma_(-(t * t), z, 1.0);
+        t = fma_(r, fma_(r, fma_(r, ORT_ACK(RT3), ORT_ACK(RT2)), ORT_ACK(RT1)), ORT_ACK(RT0)) * t;
+        const double c = z * t;
+        const double h = fma_(-c, t * 0.5, 1.5);                    // 1.5 - 0.5 t c
+        const double y = fma_(-0x1p27, c, fma_(c, 0x1p27, c));      // c rounded to 26 bits
+        const double cc = fma_(-y, y, z) / fma_(h, c, y);
+        const double p = fma_(z, fma_(z, fma_(z, fma_(z, fma_(z, ORT_ACK(F6), ORT_ACK(F5)), ORT_ACK(F4)), ORT_ACK(F3)), ORT_ACK(F2)), ORT_ACK(F1)) * z;
+        const double e = p * (y + cc);
+        if (m >= 0) {
+            const double res = (cc + e) + y;
+            return res + res;
+        }
+        const double res = ((ORT_ACK(HP1) - cc) - e) + (ORT_ACK(HP0) - y);
+        return res + res;
+    }
+    if (k == 0x3ff00000 && lo_word(x) == 0) return (m > 0) ? 0.0 : ORT_ACK(PI);
+    return ORT_LIBM_FALLBACK_ACOS(x);
+}
+
+}  // namespace glibc
+}  // namespace ort
