@@ -304,7 +304,13 @@ int ort_set_precision(ort_ctx *ctx, int precision);
  * compiled into the surface walk), clear (default) = the scattering pipeline (walk stages on full wavefronts in
  * front of the lean walk); bit 5 set = the fp32 surface programs trace two rays per lane with packed fp32
  * arithmetic (measured slower on gfx950: csrc/ort_pair.h), clear (default) = one ray per lane.  All
- * combinations produce bit-identical rays, images and counters.  Default 1. */
+ * combinations of bits 0-5 produce bit-identical rays, images and counters.
+ * Bit 6 set = STRICT LIBM EMITTERS (exact fp64 only): the light sources evaluate sin / cos through glibc 2.35's own
+ * algorithms (csrc/ort_libm.h), entry by entry as the reference's compiled code calls them, so an emitted ray — and with it
+ * every ray state, image and counter — equals the CPU checker's bit for bit; the surface-program kernels
+ * stand aside for the generic walk (~1.4 x the time).  Clear (default): the emitters' own sin / cos (within an ulp of
+ * glibc's: emitted rays agree to 1e-12, discrete outcomes are identical).  The scattering walk, rang's log and everything
+ * behind the emitters are glibc-exact / IEEE-exact in either setting.  Default 1. */
 int ort_set_kernel_variant(ort_ctx *ctx, int variant);
 
 #ifdef __cplusplus

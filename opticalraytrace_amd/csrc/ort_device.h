@@ -23,6 +23,7 @@
 #include <type_traits>
 #include "../../include/ort.h"
 #include "ort_fastd.h"
+#include "ort_libm.h"
 
 // ORT_DIET (development, A/B builds): mask of the round-3 optimisations compiled in (see OPT_* below); the build
 // uses all of them.  Bit 6: instruction selection by hand (inline asm) in neg_unless / neg_if / vnormalise_est.
@@ -926,6 +927,31 @@ __device__ inline bool outside_aperture(T x, T y, T A, T A2, T A2tol, T A2lo, T 
 template <class T> struct SinCosT { T s, c; };
 template <class T> __device__ inline SinCosT<T> sincos_v(T x);
 
+// The libm calls of the scattering walk (tauint: log; stokes: atan2, sincos twice, acos) and of rang (log).
+// T = double: the reference's OWN results — glibc's, whose algorithms ort_libm.h restates operation for operation
+// (they are not correctly rounded, so no other accurate implementation returns the same bits, and the walk
+// amplifies a last-bit difference of the azimuth to 1e-10 in 2e-5 of its rays).  The reference's compilers turn
+// both sin/cos pairs of stokes into sincos() calls (flang: stokes.o imports atan2, acos, sincos only), i.e.
+// glibc's non-FMA build of the algorithm.  fast fp64 and fp32 have no bit-exact contract: device library / own.
+__device__ inline double log_ref(double x) { return glibc::log_p(x); }
+__device__ inline fastd log_ref(fastd x) { return fastd(::log(x.v)); }
+__device__ inline float log_ref(float x) { return ::logf(x); }
+// TB: where glibc's lookup tables are read (ort_libm.h: TabGlobal = constant memory, TabLds = the workgroup's LDS copy
+// — the scattering pipeline's kernel, whose walk is otherwise bound by the table gathers)
+template <class TB> __device__ inline double atan2_ref(const TB &tb, double y, double x) { return glibc::atan2_p(tb, y, x); }
+template <class TB> __device__ inline fastd atan2_ref(const TB &, fastd y, fastd x) { return fastd(::atan2(y.v, x.v)); }
+template <class TB> __device__ inline float atan2_ref(const TB &, float y, float x) { return ::atan2f(y, x); }
+template <class TB> __device__ inline double acos_ref(const TB &tb, double x) { return glibc::acos_p(tb, x); }
+template <class TB> __device__ inline fastd acos_ref(const TB &, fastd x) { return fastd(::acos(x.v)); }
+template <class TB> __device__ inline float acos_ref(const TB &, float x) { return ::acosf(x); }
+template <class TB> __device__ inline SinCosT<double> sincos_ref(const TB &tb, double x)
+{
+    const glibc::SinCos r = glibc::sincos_p<false>(tb, x);
+    return {r.s, r.c};
+}
+template <class TB> __device__ inline SinCosT<fastd> sincos_ref(const TB &, fastd x) { return sincos_v<fastd>(x); }
+template <class TB> __device__ inline SinCosT<float> sincos_ref(const TB &, float x) { return sincos_v<float>(x); }
+
 // one leg: optical depth tau = -log(u) against the distance to the cylinder wall.
 // ok = false is the reference's `error stop "no intersection"`.
 // FILT (scatter_front_kernel): the distance from the filtered quadratic — the same bits, or `rare` (the ray is re-run)
@@ -936,7 +962,7 @@ __device__ inline void tauint(const RayT<T> &r, T mua, T mus, T cy, T cz, T radi
     const T mu_tot = mua + mus;
     const T u = draws.template peek_as<T>();
     draws.advance(on);
-    const T tau = -log(u);
+    const T tau = -log_ref(u);
     T d;
     bool hit;
     bool unused = false;
@@ -950,14 +976,20 @@ __device__ inline void tauint(const RayT<T> &r, T mua, T mus, T cy, T cz, T radi
     ok = hit;
 }
 
-template <class T, class D>
-__device__ inline void stokes_hg(VecT<T> &dir, T hgg, T twopi, bool on, D &draws)
+template <class T, class D, class TB = glibc::TabGlobal>
+__device__ inline void stokes_hg(VecT<T> &dir, T hgg, T twopi, bool on, D &draws, const TB &tb = TB{})
 {
     const T pi = twopi * T(0.5);
     const T costp = dir.z;
     const T sintp = ORT_SQRT(T(1.) - costp * costp);
     const T g2 = hgg * hgg;
-    const T phip = atan2(dir.y, dir.x);
+#ifdef ORT_ISA_MARKERS
+    asm volatile("; ORT_FN_BEGIN atan2");
+#endif
+    const T phip = atan2_ref(tb, dir.y, dir.x);
+#ifdef ORT_ISA_MARKERS
+    asm volatile("; ORT_FN_END atan2");
+#endif
     const T u1 = draws.template peek_as<T>();
     draws.advance(on);
     const T w = ORT_DIV(T(1.) - g2, T(1.) - hgg + T(2.) * hgg * u1);
@@ -973,7 +1005,13 @@ __device__ inline void stokes_hg(VecT<T> &dir, T hgg, T twopi, bool on, D &draws
     const bool upper = ri1 > pi;                         // :75 — the two branches mirror each other
     const T ang = upper ? twopi - ri1 : ri1;
     T sa, ca;
-    { const SinCosT<T> sc_ = sincos_v<T>(ang); sa = sc_.s; ca = sc_.c; }
+#ifdef ORT_ISA_MARKERS
+    asm volatile("; ORT_FN_BEGIN sincos1");
+#endif
+    { const SinCosT<T> sc_ = sincos_ref(tb, ang); sa = sc_.s; ca = sc_.c; }
+#ifdef ORT_ISA_MARKERS
+    asm volatile("; ORT_FN_END sincos1");
+#endif
     const bool keep = (bmu == T(1.)) || (bmu == T(-1.));   // goto 100: direction unchanged
     T cost = costp * bmu + sintp * sinbt * ca;
     const bool mid = fabs(cost) < T(1.);
@@ -984,12 +1022,18 @@ __device__ inline void stokes_hg(VecT<T> &dir, T hgg, T twopi, bool on, D &draws
     const T cosi2 = mid ? ORT_DIV(costp, bott) - ORT_DIV(cost * bmu, bott) : (cost >= T(1.) ? T(-1.) : T(1.));
     T cosdph = -cosi2 * ca + sini2 * sa * bmu;
     cosdph = fabs(cosdph) > T(1.) ? (cosdph > T(1.) ? T(1.) : T(-1.)) : cosdph;
-    const T ac = acos(cosdph);
+#ifdef ORT_ISA_MARKERS
+    asm volatile("; ORT_FN_BEGIN acos");
+#endif
+    const T ac = acos_ref(tb, cosdph);
+#ifdef ORT_ISA_MARKERS
+    asm volatile("; ORT_FN_END acos");
+#endif
     T phi = upper ? phip + ac : phip - ac;
     phi = phi > twopi ? phi - twopi : phi;
     phi = phi < T(0.) ? phi + twopi : phi;
     T sp, cp;
-    { const SinCosT<T> sc_ = sincos_v<T>(phi); sp = sc_.s; cp = sc_.c; }
+    { const SinCosT<T> sc_ = sincos_ref(tb, phi); sp = sc_.s; cp = sc_.c; }
     const VecT<T> nd = {sint * cp, sint * sp, cost};
     dir = vselect(on && !keep, nd, dir);
 }
@@ -1133,6 +1177,26 @@ template <> __device__ inline SinCosT<fastd> sincos_v<fastd>(fastd x)
 }
 template <> __device__ inline SinCosT<float> sincos_v<float>(float x) { return sincos_small_f32(x); }
 
+// sin / cos of the EMITTERS.  Default: sincos_small (35 instructions, within an ulp of glibc's: emitted rays agree with the
+// reference's to 1e-12, outcomes are identical — the bulk loops are emitter-bound, and glibc's own algorithm costs 130).
+// strict (kernel variant bit 6, wave-uniform; exact fp64 only): glibc's results bit for bit (ort_libm.h), through the very
+// entry the reference's compiled code calls at that site — sincos() (the non-FMA build) for every pair the compilers merge,
+// the separate sin() and cos() (FMA builds) for the first pair of `ring` and the polar angle of `create_spot`
+// (the reference's sourceMod.o imports sin, cos, sincos; the CPU checker of the tests mirrors it call by call).  Then an
+// emitted ray equals the checker's in every bit, and with it everything downstream.
+template <class T> __device__ inline SinCosT<T> sincos_em(bool, T x) { return sincos_v<T>(x); }
+template <> __device__ inline SinCosT<double> sincos_em<double>(bool strict, double x)
+{
+    if (strict) { const glibc::SinCos r = glibc::sincos_p<false>(x); return {r.s, r.c}; }
+    return sincos_small(x);
+}
+template <class T> __device__ inline SinCosT<T> sin_cos_em(bool, T x) { return sincos_v<T>(x); }      // sin(x), cos(x) as two calls
+template <> __device__ inline SinCosT<double> sin_cos_em<double>(bool strict, double x)
+{
+    if (strict) { const glibc::SinCos r = glibc::sincos_p<true>(x); return {r.s, r.c}; }
+    return sincos_small(x);
+}
+
 // ----------------------------------------------------------------------------
 // emitters (straight-line)
 // ----------------------------------------------------------------------------
@@ -1140,11 +1204,11 @@ template <> __device__ inline SinCosT<float> sincos_v<float>(float x) { return s
 // kernels): square roots and normalisations in their range-guarded exact forms (sqrt_f, div3_f),
 // a ray outside their ranges raises `rare` and is emitted and traced literally afterwards.
 template <class T, bool FILT = false, class Sys, class D>
-__device__ inline void emit_point(const Sys &S, RayT<T> &r, D &draws, bool &rare)
+__device__ inline void emit_point(const Sys &S, RayT<T> &r, D &draws, bool &rare, bool strict = false)
 {
     T phi = S.twopi * draws.template next_as<T>();
     T sinp, cosp;
-    { const SinCosT<T> sc_ = sincos_v<T>(phi); sinp = sc_.s; cosp = sc_.c; }
+    { const SinCosT<T> sc_ = sincos_em<T>(strict, phi); sinp = sc_.s; cosp = sc_.c; }
     T ran = draws.template next_as<T>();
     T cost = (T(1.0) - ran) + ran * S.cos_theta_max;
     T sint = sqrt_f<FILT, T>(T(1.0) - cost * cost, true, rare);
@@ -1156,12 +1220,12 @@ __device__ inline void emit_point(const Sys &S, RayT<T> &r, D &draws, bool &rare
 
 // ring, src/sourceMod.f90:250-300
 template <class T, bool FILT = false, class Sys, class D>
-__device__ inline void emit_ring(const Sys &S, RayT<T> &r, D &draws, bool &rare)
+__device__ inline void emit_ring(const Sys &S, RayT<T> &r, D &draws, bool &rare, bool strict = false)
 {
     T rr = S.ring_r1 + draws.template next_as<T>() * (S.ring_r2 - S.ring_r1);     // ranu(r1, r2)
     T theta = draws.template next_as<T>() * S.twopi;
     T st, ct;
-    { const SinCosT<T> sc_ = sincos_v<T>(theta); st = sc_.s; ct = sc_.c; }
+    { const SinCosT<T> sc_ = sin_cos_em<T>(strict, theta); st = sc_.s; ct = sc_.c; }      // :272-273: cos(theta), sin(theta) stay two calls
     T sq = sqrt_f<FILT, T>(rr, true, rare);
     T posx = sq * ct;
     T posy = sq * st;
@@ -1170,7 +1234,7 @@ __device__ inline void emit_ring(const Sys &S, RayT<T> &r, D &draws, bool &rare)
     T posz = S.ring_bottle_z + sqrt_f<FILT, T>(Ra * Ra - q * q, true, rare);
     rr = T(0.) + draws.template next_as<T>() * (S.ring_lens_r2 - T(0.));           // ranu(0., (radius+10e-3)**2)
     theta = draws.template next_as<T>() * S.twopi;
-    { const SinCosT<T> sc_ = sincos_v<T>(theta); st = sc_.s; ct = sc_.c; }
+    { const SinCosT<T> sc_ = sincos_em<T>(strict, theta); st = sc_.s; ct = sc_.c; }        // :287-288: merged into sincos()
     sq = sqrt_f<FILT, T>(rr, true, rare);
     T ex = sq * ct - posx;
     T ey = sq * st - posy;
@@ -1183,14 +1247,14 @@ __device__ inline void emit_ring(const Sys &S, RayT<T> &r, D &draws, bool &rare)
 
 // create_spot, src/sourceMod.f90:122-159: deterministic fan, no draws; n = 1-based loop index
 template <class T, class Sys>
-__device__ inline void emit_spot(const Sys &S, RayT<T> &r, uint64_t ray)
+__device__ inline void emit_spot(const Sys &S, RayT<T> &r, uint64_t ray, bool strict = false)
 {
     const int n = (int)(ray + 1);
     T phi = S.spot_dphi * (T)(n % 10);
     T theta = S.spot_dtheta * (T)(n / 10);
     T sinp, cosp, sint_unused, cost;
-    { const SinCosT<T> sc_ = sincos_v<T>(phi); sinp = sc_.s; cosp = sc_.c; }
-    { const SinCosT<T> sc_ = sincos_v<T>(theta); sint_unused = sc_.s; cost = sc_.c; }
+    { const SinCosT<T> sc_ = sincos_em<T>(strict, phi); sinp = sc_.s; cosp = sc_.c; }
+    { const SinCosT<T> sc_ = sin_cos_em<T>(strict, theta); sint_unused = sc_.s; cost = sc_.c; }      // cos(theta) alone: the cos() entry
     T sint = ORT_SQRT(T(1.) - cost * cost);
     r.pos = {T(0.), T(0.), T(0.)};
     r.dir = {sint * cosp, sint * sinp, cost};
@@ -1201,11 +1265,11 @@ __device__ inline void emit_spot(const Sys &S, RayT<T> &r, uint64_t ray)
 // a variable number of draws) dropped along -z onto the cylinder radiusa + thickness.
 // FILT (the crs program): the drop onto the cylinder through the filtered quadratic — the same bits, or `rare`
 template <class T, bool FILT = false, class Sys, class D>
-__device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws, bool &rare)
+__device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws, bool &rare, bool strict = false)
 {
     T phi = S.twopi * draws.template next_as<T>();
     T sinp, cosp;
-    { const SinCosT<T> sc_ = sincos_v<T>(phi); sinp = sc_.s; cosp = sc_.c; }
+    { const SinCosT<T> sc_ = sincos_em<T>(strict, phi); sinp = sc_.s; cosp = sc_.c; }
     T ran = draws.template next_as<T>();
     T cost = (T(1.0) - ran) + ran * S.cos_theta_max;
     T sint = ORT_SQRT(T(1.0) - cost * cost);
@@ -1221,7 +1285,7 @@ __device__ inline void emit_crs(const Sys &S, RayT<T> &r, D &draws, bool &rare)
         s = more ? y * y + x * x : s;
         more = more && (s >= T(1.));
     }
-    T cst = ORT_SQRT(ORT_DIV(T(-2.) * log(s), s));
+    T cst = ORT_SQRT(ORT_DIV(T(-2.) * log_ref(s), s));
     T tmp1 = T(0.) + S.crs_sigma * (x * cst);
     T tmp2 = T(0.) + S.crs_sigma * (y * cst);
     RayT<T> drop = {{tmp1, tmp2, T(1.0)}, {T(0.), T(0.), T(-1.)}};
@@ -1250,7 +1314,7 @@ __device__ inline void rang(D &draws, T sigma, T &gx, T &gy)
         s = more ? y * y + x * x : s;
         more = more && (s >= T(1.));
     }
-    T cst = ORT_SQRT(ORT_DIV(T(-2.) * log(s), s));
+    T cst = ORT_SQRT(ORT_DIV(T(-2.) * log_ref(s), s));
     gx = T(0.) + sigma * (x * cst);
     gy = T(0.) + sigma * (y * cst);
 }
@@ -1265,7 +1329,7 @@ __device__ inline void rang(D &draws, T sigma, T &gx, T &gy)
 // isors program): the cone's normal, the Fresnel step at it, the bottle quadratic and the aim at the lens in their
 // filtered forms (the same bits, or `rare`); the cone's own quadratic has a < 0 and stays literal.
 template <class T, bool FILT = false, class Sys, class D>
-__device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws, bool &rare)
+__device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws, bool &rare, bool strict = false)
 {
     T gx, gy;
     rang<T>(draws, T(S.isors_sigma), gx, gy);
@@ -1314,7 +1378,7 @@ __device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws, bool &rare
     T theta = draws.template peek_as<T>() * S.twopi;
     draws.advance(ok);
     T st, ct;
-    { const SinCosT<T> sc_ = sincos_v<T>(theta); st = sc_.s; ct = sc_.c; }
+    { const SinCosT<T> sc_ = sincos_em<T>(strict, theta); st = sc_.s; ct = sc_.c; }
     T sq = ORT_SQRT(rr);
     T ex = sq * ct - pos.x, ey = sq * st - pos.y, ez = T(S.isors_lens_z) - pos.z;
     VecT<T> aimed;
@@ -1340,7 +1404,7 @@ __device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws, bool &rare
 // 2^18 cells): a galloping search from the hint takes ~6 dependent loads instead of 18.  Same cell either way:
 // the largest s with cdf[s] <= ray.
 template <class T, class Sys, class D>
-__device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r, D &draws, uint64_t ray, int *hint = nullptr)
+__device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r, D &draws, uint64_t ray, int *hint = nullptr, bool strict = false)
 {
     const long long key = (long long)ray;
     const bool have = cdf != nullptr && key < cdf[ORT_IMAGE_SOURCE_CELLS];
@@ -1382,7 +1446,7 @@ __device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r
     T rr = T(0.) + draws.template next_as<T>() * (S.img_lens_r2 - T(0.));
     T theta = draws.template next_as<T>() * S.twopi;
     T st, ct;
-    { const SinCosT<T> sc_ = sincos_v<T>(theta); st = sc_.s; ct = sc_.c; }
+    { const SinCosT<T> sc_ = sincos_em<T>(strict, theta); st = sc_.s; ct = sc_.c; }
     T sq = ORT_SQRT(rr);
     T ex = sq * ct - x, ey = sq * st - y, ez = S.img_lens_z - T(0.);
     T dist = ORT_SQRT(ex * ex + ey * ey + ez * ez);
@@ -1400,7 +1464,7 @@ __device__ inline bool emit_image(const Sys &S, const long long *cdf, RayT<T> &r
 // EMITTER >= 0 (surface programs): the emitter is the compile-time constant ORT_EMIT_* of the program.
 template <class T, bool ANYSRC, bool FILT = false, int EMITTER = -1, class Sys, class D>
 __device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf, bool &rare,
-                           int *img_hint = nullptr)
+                           int *img_hint = nullptr, bool strict = false)
 {
     if constexpr (EMITTER >= 0) {
         bool unused = false;                              // spot and image are literal throughout
@@ -1414,25 +1478,25 @@ __device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64
         return -1;
     }
     if (!ANYSRC) {
-        if (phase == 1) emit_ring<T, FILT>(S, r, draws, rare);
-        else emit_point<T, FILT>(S, r, draws, rare);
+        if (phase == 1) emit_ring<T, FILT>(S, r, draws, rare, strict);
+        else emit_point<T, FILT>(S, r, draws, rare, strict);
         return -1;
     }
     const int e = __builtin_amdgcn_readfirstlane(S.emitter[phase - 1]);
     bool unused = false;                                  // the other emitters are literal throughout
-    if (e == ORT_EMIT_RING) emit_ring<T>(S, r, draws, unused);
-    else if (e == ORT_EMIT_POINT) emit_point<T>(S, r, draws, unused);
-    else if (e == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray);
-    else if (e == ORT_EMIT_CRS) emit_crs<T>(S, r, draws, unused);
-    else if (e == ORT_EMIT_ISORS) return emit_isors<T>(S, r, draws, unused) ? -1 : ORT_ST_NO_INTERSECTION;
-    else return emit_image<T>(S, cdf, r, draws, ray) ? -1 : ORT_ST_LOST_TELESCOPE;
+    if (e == ORT_EMIT_RING) emit_ring<T>(S, r, draws, unused, strict);
+    else if (e == ORT_EMIT_POINT) emit_point<T>(S, r, draws, unused, strict);
+    else if (e == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray, strict);
+    else if (e == ORT_EMIT_CRS) emit_crs<T>(S, r, draws, unused, strict);
+    else if (e == ORT_EMIT_ISORS) return emit_isors<T>(S, r, draws, unused, strict) ? -1 : ORT_ST_NO_INTERSECTION;
+    else return emit_image<T>(S, cdf, r, draws, ray, nullptr, strict) ? -1 : ORT_ST_LOST_TELESCOPE;
     return -1;
 }
 template <class T, bool ANYSRC, class Sys, class D>
-__device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf)
+__device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64_t ray, const long long *cdf, bool strict = false)
 {
     bool unused = false;
-    return emit<T, ANYSRC, false>(S, phase, r, draws, ray, cdf, unused);
+    return emit<T, ANYSRC, false>(S, phase, r, draws, ray, cdf, unused, nullptr, strict);
 }
 
 // ----------------------------------------------------------------------------

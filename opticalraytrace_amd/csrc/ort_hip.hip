@@ -91,6 +91,7 @@ struct TraceArgs {
     // being emitted; +inf: nothing is culled (host: ring_cull_threshold)
     double cull;
     float cullf;
+    int strict;                  // kernel variant bit 6: the emitters call glibc's own sin / cos / sincos (ort_device.h: sincos_em)
     uint64_t defer_base;         // queued kernel: list entry of ray i of this launch = defer_base + i (the entries of all
                                  // launches of a group are relative to the group's first ray, see close_group)
     int listed;                  // trace_kernel: iterate redo_list instead of [0, n_rays)
@@ -115,6 +116,12 @@ struct TraceArgs {
     int32_t *cont_nis;
     uint64_t cont_cap;
     int cont_k0;                 // first surface of the continuation (= last scattering surface + 1)
+    // work distribution of scatter_front_kernel (kScatCtlWords words, zero before every launch): eight heads, one per
+    // XCD (head x hands out the rays [x scat_share, (x + 1) scat_share) of the launch, scat_grab at a time), and the
+    // count of hand-over slots allocated so far (what the continuation walks)
+    unsigned long long *scat_ctl;
+    uint64_t scat_share;
+    uint32_t scat_grab;
     const long long *img_cdf;    // image-source table or null
     double *path;                // [n][ORT_MAX_PATH][3] or null (tracker)
     int32_t *npath;
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
             if (!have_in) {
                 const Draws d_none = d;
-                const int est = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf);
+                const int est = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf, a.strict != 0);
                 st = est < 0 ? st : est;
                 const bool exhausted = est == ORT_ST_LOST_TELESCOPE;
                 d.take(exhausted, d_none);               // an exhausted image source emits nothing and draws nothing
@@ -638,7 +645,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             KeyedDraws d;
             d.init_keyed(a.rng_base, a.first_ray + ic, have_in ? a.draw_base : 0);
             if (!have_in) {
-                const int est = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf);
+                const int est = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf, a.strict != 0);
                 st = est < 0 ? st : est;
             }
             const RayT<T> r0 = r;
@@ -704,6 +711,10 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
 // With filtered predicates the kernel holds no literal formula at all: see `defer` below.
 // ---------------------------------------------------------------------------
 constexpr uint64_t kNoRay = ~0ull;   // hand-over bundle of the scattering pipeline: a slot without a ray
+// control words of the scattering pipeline (TraceArgs.scat_ctl), each on a 128-byte line of its own
+constexpr int kScatCtlStride = 16, kScatHeads = 8, kScatSlotsWord = kScatHeads * kScatCtlStride, kScatCtlWords = (kScatHeads + 1) * kScatCtlStride;
+constexpr int kScatWaves = 12;              // wavefronts per workgroup of scatter_front_kernel = per CU (LDS and 168 VGPRs allow no more)
+constexpr unsigned kHandChunk = 256;        // hand-over slots a wave allocates at a time
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kQueueCap = 128;      // >= 63 leftover + 64 new survivors
 constexpr int kQueueFields = 6;     // px py pz dx dy dz (+ the draw state: its own array)
@@ -778,19 +789,32 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     }
     int32_t *layer = hist_layer(a);
     // MODE_CONTINUE: the slots of the hand-over bundle, one per ray of the launch, some of them empty
-    const uint64_t n = a.n_rays;
+    // MODE_CONTINUE: the hand-over slots the front kernel allocated (a count it left on the device), some of them empty
+    uint64_t n = a.n_rays;
+    if (MODE == MODE_CONTINUE) {
+        const uint64_t used = (uint64_t)a.scat_ctl[kScatSlotsWord];
+        n = used < a.cont_cap ? used : a.cont_cap;
+    }
     const uint64_t ns_in = MODE == MODE_CONTINUE ? a.cont_cap : a.in_stride;
     const int k0 = MODE == MODE_CONTINUE ? a.cont_k0 : 0;     // first surface walked here
     if (MODE == MODE_CONTINUE && split <= k0) split = ns;     // no queue point behind the start: one segment
 
     // contiguous, 64-aligned range of ray indices for this wave: long ranges for the workgroups of
     // the first rounds, short ones for the last workgroups (plan_ranges), so that the chip drains evenly
-    const bool head = blockIdx.x < a.head_blocks;
-    const uint64_t wid = (uint64_t)(head ? blockIdx.x : blockIdx.x - a.head_blocks) * kWavesPerBlock + wave;
-    const uint64_t chunk = head ? a.head_chunk : a.tail_chunk;
-    const uint64_t end = head ? a.head_rays : n;
-    uint64_t lo = (head ? 0 : a.head_rays) + wid * chunk; if (lo > end) lo = end;
-    uint64_t hi = lo + chunk;  if (hi > end) hi = end;
+    uint64_t lo, hi;
+    if (MODE == MODE_CONTINUE) {                            // the slot count is only known here: equal ranges over the grid
+        const uint64_t nw = (uint64_t)gridDim.x * kWavesPerBlock, wid = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+        const uint64_t chunk = (((n + nw - 1) / nw) + 63) & ~63ull;
+        lo = wid * chunk; if (lo > n) lo = n;
+        hi = lo + chunk;  if (hi > n) hi = n;
+    } else {
+        const bool head = blockIdx.x < a.head_blocks;
+        const uint64_t wid = (uint64_t)(head ? blockIdx.x : blockIdx.x - a.head_blocks) * kWavesPerBlock + wave;
+        const uint64_t chunk = head ? a.head_chunk : a.tail_chunk;
+        const uint64_t end = head ? a.head_rays : n;
+        lo = (head ? 0 : a.head_rays) + wid * chunk; if (lo > end) lo = end;
+        hi = lo + chunk;  if (hi > end) hi = end;
+    }
 
     // what the steps of a program kernel may assume (ort_device.h): fused rays have unit directions (they
     // were emitted here), the lens spheres of every program are centred on the axis (host: matches<P>)
@@ -919,7 +943,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 else d.init_keyed(a.rng_base, a.first_ray + ic, 0);
                 int est;
                 if constexpr (fixed) est = emit<T, false, FILT, Prog<PROG>::emitter>(*csys, phase, r, d, a.first_ray + ic, a.img_cdf, rare, &img_hint);
-                else est = emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare);
+                else est = emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare, nullptr, a.strict != 0);
                 st = est < 0 ? st : est;
             }
             if constexpr (fixed && MODE == MODE_CONTINUE) {
@@ -1198,14 +1222,23 @@ __global__ __launch_bounds__(kBlock, 4) void trace_pair_kernel(TraceArgs a)
 // evaluated in their filtered forms (ort_device.h: the same bits, or the ray is listed for the literal re-run); the walk
 // itself (stokes, log) is literal — so rays, images and counters are bit-identical to theirs (tests: the pipeline against
 // the lockstep kernel; both against the CPU checker).
-// One wavefront per workgroup: pool + rings + the staged system take 12 KB of LDS per wave (13 waves per CU; the
-// kernel's 160 VGPRs allow 12).
+// The transcendental functions of the walk are glibc's own algorithms (ort_libm.h: the reference's results bit for
+// bit); their lookup tables (sin/cos, atan2, acos: 38 KB) are staged ONCE per workgroup into LDS — gathered from
+// constant memory they cost the vector cache ~50 cycles per wavefront-wide load and bound the walk (tools/ubench_libm.hip).
+// One workgroup of kScatWaves = 12 wavefronts per CU (151 KB of LDS: tables + 12 pools of 9 KB + the staged system; the
+// kernel's 168 VGPRs allow 3 waves per SIMD), every wave an independent worker: no barrier after the staging.
+// Work distribution: PERSISTENT waves pull batches of rays from eight heads, one per XCD (HW_REG_XCC_ID; head x hands
+// out an eighth of the launch's ray range, scat_grab rays per returning atomic), and steal from the next head when
+// theirs is dry; a wave ends when all eight are.  With static ranges the 12 waves of a CU ended at 0.51 / 0.81 / 1.13 M
+// cycles (a SIMD serves its oldest wave first) and the last third of every launch ran at one wave per SIMD
+// (profiles/r03/scatbench.log).  Keyed draws make the result independent of which wave traces which ray.
+// Hand-over slots are allocated kHandChunk at a time from one counter (scat_ctl[kScatSlotsWord]); a wave fills its
+// chunk from the bottom and marks what is left empty when it ends, so every allocated slot is written and the
+// continuation walks exactly the allocated count.
 // ---------------------------------------------------------------------------
 constexpr int kSQCap = 128;        // at most 128 rays in flight per wave: stage E runs only while <= 64 are (a power of two)
 // ONE pool of ray slots per wave and three rings of slot numbers over it — walking, arrived, free: a ray keeps its
-// slot from stage to stage, only its number moves between the rings (two queues of 128 full slots each were 17 KB
-// per wave: 7 waves per CU, and the kernel is latency-bound at that — profiles/r03/scatbench.log: 1 / 1.75 / 3
-// waves per SIMD)
+// slot from stage to stage, only its number moves between the rings
 struct ScatPool {
     double f[7][kSQCap];           // px py pz dx dy dz t (length of the next leg)
     uint64_t c[kSQCap];            // keyed draw counter
@@ -1213,6 +1246,7 @@ struct ScatPool {
     uint8_t ring[3][kSQCap];       // slot numbers: RING_WALK, RING_ARRIVED, RING_FREE
 };
 constexpr int RING_WALK = 0, RING_ARRIVED = 1, RING_FREE = 2;
+static_assert(sizeof(ScatPool) * kScatWaves + glibc::kLdsTableWords * 8 + sizeof(ort_system) + 256 <= 160 * 1024, "scatter_front_kernel: LDS of one CU");
 
 // ENTER surface k (per lane) for the lanes `on`: src/lens.f90:255-261 / :303-311 up to the first tauint.
 // Circular walls: the two quadratics in their filtered forms (ort_device.h: the same bits, or the lane raises `rare`);
@@ -1248,30 +1282,34 @@ __device__ inline void scat_enter(const ort_surface *surf, int k, int kind0, boo
 #ifdef ORT_SCAT_TIMING
 __device__ unsigned long long g_scat_times[4 * 16384];     // dev builds: start, last emission, end, passes per wave
 #endif
+__device__ inline uint64_t uniform64(uint64_t v)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
 // ANYSRC = false: the point source only (the default of the loop the bottle belongs to, src/main.f90:136)
 template <bool ANYSRC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void scatter_front_kernel(TraceArgs a)
+__global__ __launch_bounds__(64 * kScatWaves) void scatter_front_kernel(TraceArgs a)
 {
     __shared__ ort_system S;
-    __shared__ ScatPool P;
+    __shared__ ScatPool POOLS[kScatWaves];
+    __shared__ uint64_t LT[glibc::kLdsTableWords];       // glibc's sin/cos, atan2 and acos tables (ort_libm.h: TabLds)
+    __shared__ double ALB[ORT_MAX_SURFACES];
     __shared__ unsigned int blk[4];
     stage_system(S, a.sys);
+    glibc::stage_tables(LT, (int)threadIdx.x, (int)blockDim.x);
     if (threadIdx.x < 4) blk[threadIdx.x] = 0;
-    for (int j = threadIdx.x; j < kSQCap; j += 64) P.ring[RING_FREE][j] = (uint8_t)j;      // every slot starts free
-    __syncthreads();
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    ScatPool &P = POOLS[wave];
+    for (int j = lane; j < kSQCap; j += 64) P.ring[RING_FREE][j] = (uint8_t)j;      // every slot starts free
     const int ph = a.phase - 1;
     const ort_surface *surf = S.surfaces[ph];
-    // albedo of every surface's medium (lens.f90:266, :317), the division done once per wave instead of once per event
-    __shared__ double ALB[ORT_MAX_SURFACES];
-    if (lane < ORT_MAX_SURFACES) ALB[lane] = surf[lane].mus / (surf[lane].mus + surf[lane].mua);
+    // albedo of every surface's medium (lens.f90:266, :317), the division done once per workgroup instead of once per event
+    if (threadIdx.x < ORT_MAX_SURFACES) ALB[threadIdx.x] = surf[threadIdx.x].mus / (surf[threadIdx.x].mus + surf[threadIdx.x].mua);
     __syncthreads();
+    const glibc::TabLds tabs = {(const __attribute__((address_space(3))) uint64_t *)LT};
     const int kind0 = __builtin_amdgcn_readfirstlane(surf[0].kind);      // host: the same for every surface in front of cont_k0
     const int klast = a.cont_k0 - 1;
-    // this wave's contiguous range of ray indices (equal ranges: the walk lengths average out over a range)
-    const uint64_t per = ((a.n_rays + gridDim.x - 1) / gridDim.x + 63) & ~63ull;
-    uint64_t lo = (uint64_t)blockIdx.x * per;  if (lo > a.n_rays) lo = a.n_rays;
-    uint64_t hi = lo + per;                     if (hi > a.n_rays) hi = a.n_rays;
 
     unsigned int lost = 0, isect = 0, help3 = 0;
     auto end_ray = [&](int st, int nis) {                 // a ray that ends inside the bottle (nothing is binned here)
@@ -1323,19 +1361,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sc
         give(RING_ARRIVED, acount, ahead, to_arrived, slot);
         give(RING_FREE, fcount, fhead, held && !to_walk && !to_arrived, slot);
     };
-    // behind the last scattering surface: the next free slots of this wave's part of the hand-over bundle
-    uint64_t handed = 0;
+    // behind the last scattering surface: the next free slots of this wave's current chunk of the hand-over bundle; a
+    // full chunk is followed by a new one from the launch-wide counter (one returning atomic per kHandChunk rays)
+    uint64_t hbase = 0;
+    unsigned hused = kHandChunk;                          // no chunk yet
+    auto new_chunk = [&]() {
+        unsigned long long v = 0;
+        if (lane == 0) v = atomicAdd(&a.scat_ctl[kScatSlotsWord], (unsigned long long)kHandChunk);
+        return uniform64(v);
+    };
     auto hand_over = [&](bool cond, const Ray &r, double t, const KeyedDraws &d, int nis) {
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(cond);
+        const unsigned cnt = (unsigned)__popcll(mask);
+        if (cnt == 0) return;                             // (wave-uniform)
+        uint64_t hnext = hbase;
+        if (hused + cnt > kHandChunk) hnext = new_chunk();        // the batch spills into a new chunk
         if (cond) {
-            const uint64_t j = lo + handed + (uint64_t)lane_prefix(mask), cap = a.cont_cap;
-            a.cont_pos_dir[0 * cap + j] = r.pos.x; a.cont_pos_dir[1 * cap + j] = r.pos.y; a.cont_pos_dir[2 * cap + j] = r.pos.z;
-            a.cont_pos_dir[3 * cap + j] = r.dir.x; a.cont_pos_dir[4 * cap + j] = r.dir.y; a.cont_pos_dir[5 * cap + j] = r.dir.z;
-            a.cont_t[j] = t;
-            a.cont_draw[j] = d.c;
-            a.cont_nis[j] = nis;
+            const unsigned pos = hused + (unsigned)lane_prefix(mask);
+            const uint64_t j = pos < kHandChunk ? hbase + pos : hnext + (pos - kHandChunk), cap = a.cont_cap;
+            if (j < cap) {                                // (always: the host sizes the bundle for every chunk a launch can take)
+                a.cont_pos_dir[0 * cap + j] = r.pos.x; a.cont_pos_dir[1 * cap + j] = r.pos.y; a.cont_pos_dir[2 * cap + j] = r.pos.z;
+                a.cont_pos_dir[3 * cap + j] = r.dir.x; a.cont_pos_dir[4 * cap + j] = r.dir.y; a.cont_pos_dir[5 * cap + j] = r.dir.z;
+                a.cont_t[j] = t;
+                a.cont_draw[j] = d.c;
+                a.cont_nis[j] = nis;
+            }
         }
-        handed += (uint64_t)__popcll(mask);
+        hused += cnt;
+        if (hused > kHandChunk) { hbase = hnext; hused -= kHandChunk; }
     };
 
 #ifdef ORT_SCAT_TIMING
@@ -1347,9 +1400,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sc
     auto defer = [&](bool cond, const KeyedDraws &d) {
         if (cond) a.redo_list[atomicAdd(&a.redo_ctl[0], 1u)] = (uint32_t)(a.defer_base + ((d.c >> 24) - a.first_ray));
     };
-    uint64_t next = lo;
+    // the rays this wave has pulled and not yet emitted, the head it pulls from, and whether all eight heads are dry
+    uint64_t bnext = 0, bhi = 0;
+    int hx = xcc_id() & (kScatHeads - 1), tried = 0;
+    bool dry = false;
     for (;;) {
-        const bool have_new = next < hi;
+        while (bnext >= bhi && !dry) {                    // (wave-uniform) pull: at most eight failures in a wave's life
+            const uint64_t base = (uint64_t)hx * a.scat_share;
+            uint64_t end = base + a.scat_share;  if (end > a.n_rays) end = a.n_rays;
+            unsigned long long v = 0;
+            if (lane == 0 && base < end) v = atomicAdd(&a.scat_ctl[hx * kScatCtlStride], (unsigned long long)a.scat_grab);
+            const uint64_t got = base + uniform64(v);
+            if (base < end && got < end) {
+                bnext = got;
+                bhi = got + a.scat_grab < end ? got + a.scat_grab : end;
+                tried = 0;
+            } else {
+                hx = (hx + 1) & (kScatHeads - 1);
+                dry = ++tried >= kScatHeads;
+            }
+        }
+        const bool have_new = bnext < bhi;
 #ifdef ORT_SCAT_TIMING
         n_pass++;
         if (have_new) t_emit = __builtin_readcyclecounter();
@@ -1367,6 +1438,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sc
             int slot;
             take(RING_WALK, wcount, whead, act, slot);
             load(act, slot, r, t, d, nis, k);
+#ifdef ORT_ISA_MARKERS
+            asm volatile("; ORT_STAGE_BEGIN W");
+#endif
             const ort_surface &s = surf[k];
             int ended = -1;
             bool walking = act;
@@ -1377,7 +1451,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sc
             const bool absorbed = walking && !(u < albedo);
             ended = absorbed ? ORT_ST_LOST_BOTTLE : ended;
             walking = walking && !absorbed;
-            stokes_hg<double>(r.dir, s.hgg, S.twopi, walking, d);
+            stokes_hg<double>(r.dir, s.hgg, S.twopi, walking, d, tabs);
             double dist;
             bool at_wall, ok, rare = false;
             tauint<double, KeyedDraws, true>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, walking, d, dist, at_wall, ok, nis, &rare);
@@ -1389,6 +1463,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sc
             const bool out = sqrt(r.pos.x * r.pos.x + r.pos.z * r.pos.z) >= s.scat_radius;        // sic: x, z
             const bool still = walking && ok && !out && !at_wall;
             const bool arrived = walking && ok && !still;
+#ifdef ORT_ISA_MARKERS
+            asm volatile("; ORT_STAGE_END W");
+#endif
             defer(bad, d);
             route(act, slot, still, arrived && k < klast, r, t, d, nis, k);
             hand_over(arrived && k >= klast, r, t, d, nis);
@@ -1433,14 +1510,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sc
             __builtin_amdgcn_wave_barrier();
         } else if (may_emit) {
             // ---- E: 64 fresh rays
-            const uint64_t i = next + (uint64_t)lane;
-            const bool act = i < hi;
-            next += 64;
-            const uint64_t ic = act ? i : hi - 1;
+            const uint64_t i = bnext + (uint64_t)lane;
+            const bool act = i < bhi;
+            bnext += 64;
+            const uint64_t ic = act ? i : bhi - 1;
             Ray r;
             KeyedDraws d;
             d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-            int ended = emit<double, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf);
+            int ended = emit<double, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf, a.strict != 0);
             int nis = 0;
             double t = 0.;
             bool walking, arrived, rare = false;
@@ -1454,16 +1531,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sc
             if (act && ended >= 0) end_ray(ended, nis);
             __builtin_amdgcn_wave_barrier();
         } else {
-            break;
+            break;                                           // nothing in flight, every head dry
         }
     }
 #ifdef ORT_SCAT_TIMING
-    if (lane == 0 && blockIdx.x < 16384) {
-        g_scat_times[4 * blockIdx.x + 0] = t_start; g_scat_times[4 * blockIdx.x + 1] = t_emit;
-        g_scat_times[4 * blockIdx.x + 2] = __builtin_readcyclecounter(); g_scat_times[4 * blockIdx.x + 3] = n_pass;
+    {
+        const unsigned wid = blockIdx.x * kScatWaves + wave;
+        if (lane == 0 && wid < 16384) {
+            g_scat_times[4 * wid + 0] = t_start; g_scat_times[4 * wid + 1] = t_emit;
+            g_scat_times[4 * wid + 2] = __builtin_readcyclecounter(); g_scat_times[4 * wid + 3] = n_pass;
+        }
     }
 #endif
-    for (uint64_t j = lo + handed + (uint64_t)lane; j < hi; j += 64) a.cont_draw[j] = kNoRay;    // the slots left over
+    if (hused < kHandChunk)                                  // what is left of the wave's last chunk holds no ray
+        for (uint64_t j = hbase + hused + (uint64_t)lane; j < hbase + kHandChunk && j < a.cont_cap; j += 64) a.cont_draw[j] = kNoRay;
     atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect); atomicAdd(&blk[3], help3);
     __syncthreads();
     if (threadIdx.x < 4 && blk[threadIdx.x])
@@ -1472,7 +1553,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sc
 
 __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int phase,
                                                       uint64_t first_ray, uint64_t n, uint64_t rng_base,
-                                                      double *pos_dir, const long long *img_cdf)
+                                                      double *pos_dir, const long long *img_cdf, int strict)
 {
     __shared__ ort_system S;
     stage_system(S, sys);
@@ -1481,7 +1562,7 @@ __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int
         KeyedDraws d;
         d.init_keyed(rng_base, first_ray + i, 0);
         Ray r;
-        emit<double, true>(S, phase, r, d, first_ray + i, img_cdf);
+        emit<double, true>(S, phase, r, d, first_ray + i, img_cdf, strict != 0);
         pos_dir[0 * n + i] = (double)r.pos.x; pos_dir[1 * n + i] = (double)r.pos.y; pos_dir[2 * n + i] = (double)r.pos.z;
         pos_dir[3 * n + i] = (double)r.dir.x; pos_dir[4 * n + i] = (double)r.dir.y; pos_dir[5 * n + i] = (double)r.dir.z;
     }
@@ -1631,6 +1712,8 @@ struct ort_ctx {
     uint64_t *d_cont_draw;
     int32_t *d_cont_nis;
     uint64_t cont_cap;
+    unsigned long long *d_scat_ctl;      // kScatCtlWords: the pipeline's work heads and slot counter (TraceArgs.scat_ctl)
+    int n_cus;                   // compute units of the device (one workgroup of scatter_front_kernel each)
     double ring_cull;            // TraceArgs.cull of the staged system (ring_cull_threshold), +inf: no culling
     float ring_cullf;
     hipEvent_t ev[3][2];
@@ -1804,6 +1887,7 @@ static void launch_lean(ort_ctx *c, int mode, const TraceArgs &a, int grid)
     // draws in front of the first surface (resident bundles may come with another draw_base)
     int prog = c->prog[a.phase - 1];
     if (mode != MODE_FUSED && a.draw_base != (a.phase == 1 ? 4 : 2)) prog = PROG_GENERIC;
+    if (a.strict) prog = PROG_GENERIC;                   // strict libm emitters live in the generic kernels (variant bit 6)
     if constexpr (std::is_same<T, float>::value) {
         // variant bit 5: fp32, fused, a surface program with two rays per lane (ort_pair.h) — measured SLOWER than one
         // ray per lane on gfx950 (0.226 vs 0.217 ms per 1e7 point rays), see ort_pair.h: kept as the A/B that shows it
@@ -1865,6 +1949,9 @@ static int create_on_device(ort_ctx *c, const ort_system *sys)
     HIP_TRY(hipMemsetAsync(c->d_work, 0, ORT_NUM_WORK * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipMalloc(&c->d_redo_ctl, 2 * sizeof(unsigned int)));
     HIP_TRY(hipMemsetAsync(c->d_redo_ctl, 0, 2 * sizeof(unsigned int), c->stream));
+    HIP_TRY(hipMalloc(&c->d_scat_ctl, kScatCtlWords * sizeof(unsigned long long)));
+    HIP_TRY(hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, c->device));
+    if (c->n_cus < 1) c->n_cus = 1;
     c->d_image = c->own_image;
     c->d_counters = c->own_counters;
     for (int k = 0; k < 3; ++k) {
@@ -1930,6 +2017,7 @@ int ort_destroy(ort_ctx *c)
     (void)hipFree(c->d_sys_ring); (void)hipHostFree(c->h_sys_ring); (void)hipFree(c->own_image); (void)hipFree(c->own_counters); (void)hipFree(c->d_replicas); (void)hipFree(c->d_img_cdf);
     (void)hipFree(c->d_redo_list); (void)hipFree(c->d_redo_ctl); (void)hipFree(c->d_work);
     (void)hipFree(c->d_cont_pos_dir); (void)hipFree(c->d_cont_draw); (void)hipFree(c->d_cont_nis); (void)hipFree(c->d_cont_t);
+    (void)hipFree(c->d_scat_ctl);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ORT_OK;
@@ -2007,7 +2095,7 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
     } else if (mode == MODE_DEBUG) {
         if (filt) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, double, true>));
         else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, double, true>));
-    } else if (anysrc && filt && queued && mode == MODE_FUSED && !scat && c->prog[a.phase - 1] >= PROG_CRS) {
+    } else if (anysrc && filt && queued && mode == MODE_FUSED && !scat && c->prog[a.phase - 1] >= PROG_CRS && !a.strict) {
         // the other bulk light sources in front of a default surface list: their own program kernels
         switch (c->prog[a.phase - 1]) {
 #define ORT_CASE(P) case P: ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, double, P>)); break;
@@ -2060,34 +2148,40 @@ static int reserve_list(ort_ctx *c, uint64_t n_rays)
 }
 
 // Scratch of the scattering pipeline: one hand-over entry (68 bytes) per ray of a launch; launches of that path
-// cover at most 2^24 rays (1.1 GB of the 288 GB, allocated only as far as a trace needs it).  Every launch ends with
-// the longest random walks of its rays — one scattering event per pass of a wave, ~45 events for the longest of 4e6
-// rays, 0.18 ms that nothing else fills (profiles/r03/scatbench.log: time = 0.18 ms + 0.12..0.14 ms per 1e6 rays):
-// 2^22 rays per launch cost 20 % more per ray than 2^24.
-constexpr int kScatterChunkLog2 = 24;
+// cover at most 2^25 rays (ORT_MAX_RAYS_PER_LAUNCH; 2.3 GB of the 288 GB, allocated only as far as a trace needs it).
+// Every launch ends with the longest random walks of its rays — one scattering event per pass of a wave, ~45 events
+// for the longest of 4e6 rays, ~0.2 ms that nothing else fills: 4e7 rays cost 0.140 / 0.133 / 0.125 ms per 1e6 rays in
+// launches of 2^24 / 2^25 / 2^26 (gpurun_out r4 sweep; round 3's figure was taken at 2^24).
+constexpr int kScatterChunkLog2 = 25;
 static uint64_t scatter_chunk()
 {
     static const uint64_t chunk = 1ull << env_int("ORT_SCAT_CHUNK_LOG2", kScatterChunkLog2);     // development knob
     return chunk;
 }
-// Wavefronts (= workgroups) of scatter_front_kernel for a launch of n rays: 12 fit a CU, 3072 fill the chip, and a
-// SIMD needs two resident waves to stay busy (per-wave timelines, tools/scat_timing.py: one wave alone issues 61 % of
-// the cycles, two or three 92 %).  Fewer than 3072 are placed unevenly (2048: some SIMDs get three waves, others one —
-// the launch takes as long as the fullest SIMD); beyond that ~2700 rays per wave (at 2^24 rays: 6144 waves; 3072
-// +3.5 %, 12288 +5 %).
-static unsigned scatter_waves(uint64_t n)
+// Workgroups of scatter_front_kernel for a launch of n rays: one per CU (12 persistent wavefronts each), fewer when the
+// launch has fewer than 12 batches of 64 rays per CU.  What a wave takes per pull: 1/32 of its share of the launch, at
+// least one batch, at most four (the end of a launch is as ragged as one pull is long).
+static unsigned scatter_groups(const ort_ctx *c, uint64_t n)
 {
-    static const int forced = env_int("ORT_SCAT_WAVES", 0);                       // development knob
-    uint64_t waves = n / 2730;
-    if (waves < 3072) waves = 3072;
-    if (waves > 6144) waves = 6144;
-    if (forced > 0) waves = (uint64_t)forced;
-    const uint64_t most = (n + 127) / 128;
-    return (unsigned)(waves < most ? waves : most);
+    const uint64_t batches = (n + 63) / 64, want = (batches + kScatWaves - 1) / kScatWaves;
+    const uint64_t most = (uint64_t)env_int("ORT_SCAT_GROUPS", c->n_cus);         // development knob
+    return (unsigned)(want < most ? (want ? want : 1) : most);
+}
+static uint32_t scatter_grab(uint64_t n, unsigned groups)
+{
+    static const int forced = env_int("ORT_SCAT_GRAB", 0);                        // development knob (batches per pull)
+    const uint64_t per_wave = (n + 63) / 64 / ((uint64_t)groups * kScatWaves);
+    uint64_t g = per_wave / 32;
+    if (g < 1) g = 1;
+    if (g > 4) g = 4;
+    if (forced > 0) g = (uint64_t)forced;
+    return (uint32_t)(64 * g);
 }
 static int reserve_handover(ort_ctx *c, uint64_t n_rays)
 {
-    const uint64_t want = n_rays < scatter_chunk() ? n_rays : scatter_chunk();
+    // every ray of a launch can be handed over, and every wavefront leaves up to one chunk of slots partly used
+    const uint64_t rays = n_rays < scatter_chunk() ? n_rays : scatter_chunk();
+    const uint64_t want = rays + (uint64_t)scatter_groups(c, rays) * kScatWaves * kHandChunk;
     if (want <= c->cont_cap) return ORT_OK;
     { const int rc = close_group(c); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2111,6 +2205,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     a0.img_cdf = c->d_img_cdf;
     a0.in_stride = a0.n_rays;
     const bool culling = (c->variant & 8) == 0;                 // bit 3: A/B knob, ring rays are all emitted
+    a0.strict = ((c->variant & 64) != 0 && c->precision == 0) ? 1 : 0;
     a0.cull = culling ? c->ring_cull : HUGE_VAL;
     a0.cullf = culling ? c->ring_cullf : HUGE_VALF;
     if (a0.first_ray > ORT_MAX_RAY_INDEX || a0.n_rays > ORT_MAX_RAY_INDEX - a0.first_ray)
@@ -2134,6 +2229,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
         if (rc) return rc;
         a0.cont_pos_dir = c->d_cont_pos_dir; a0.cont_t = c->d_cont_t; a0.cont_draw = c->d_cont_draw; a0.cont_nis = c->d_cont_nis;
         a0.cont_cap = c->cont_cap; a0.cont_k0 = c->scat_k0[a0.phase - 1];
+        a0.scat_ctl = c->d_scat_ctl;
     }
     if (deferring) {
         const int rc = reserve_list(c, total);
@@ -2179,9 +2275,12 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
         }
         if (ext_timed) { c->launch_ev[0] = c->ring[slot][0]; c->launch_ev[1] = c->ring[slot][1]; }
         if (pipeline) {
-            const unsigned waves = scatter_waves(a.n_rays);       // one wavefront per workgroup
-            if (anysrc_emitter) hipLaunchKernelGGL(scatter_front_kernel<true>, dim3(waves), dim3(64), 0, c->stream, a);
-            else hipLaunchKernelGGL(scatter_front_kernel<false>, dim3(waves), dim3(64), 0, c->stream, a);
+            const unsigned groups = scatter_groups(c, a.n_rays);
+            a.scat_grab = scatter_grab(a.n_rays, groups);
+            a.scat_share = (((a.n_rays + kScatHeads - 1) / kScatHeads) + 63) & ~63ull;
+            HIP_TRY(hipMemsetAsync(c->d_scat_ctl, 0, kScatCtlWords * sizeof(unsigned long long), c->stream));
+            if (anysrc_emitter) hipLaunchKernelGGL(scatter_front_kernel<true>, dim3(groups), dim3(64 * kScatWaves), 0, c->stream, a);
+            else hipLaunchKernelGGL(scatter_front_kernel<false>, dim3(groups), dim3(64 * kScatWaves), 0, c->stream, a);
             HIP_TRY(hipGetLastError());
             if (c->cont_prog[a.phase - 1])
                 hipLaunchKernelGGL((trace_queue_kernel<MODE_CONTINUE, true, false, double, PROG_POINT_WALKED, false>), dim3(grid), dim3(kBlock), 0,
@@ -2255,7 +2354,7 @@ int ort_emit(ort_ctx *c, int phase, uint64_t first_ray, uint64_t n_rays, uint64_
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2][0], c->stream));
     hipLaunchKernelGGL(emit_kernel, dim3(grid_for(n_rays)), dim3(kBlock), 0, c->stream,
                        &c->d_sys->sys, phase, first_ray, n_rays, stream_base(seed, phase), d_pos_dir,
-                       (const long long *)c->d_img_cdf);
+                       (const long long *)c->d_img_cdf, ((c->variant & 64) != 0 && c->precision == 0) ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[2][1], c->stream)); c->ev_valid[2] = true; }
     return ORT_OK;
@@ -2503,7 +2602,7 @@ int ort_synchronize(ort_ctx *c)
 int ort_set_kernel_variant(ort_ctx *c, int variant)
 {
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
-    if (variant < 0 || variant > 63) return fail(ORT_E_INVALID, "variant must be in 0..63");
+    if (variant < 0 || variant > 127) return fail(ORT_E_INVALID, "variant must be in 0..127");
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = close_group(c); if (rc) return rc; }
     c->variant = variant;

@@ -73,9 +73,18 @@ static void rang(draws_t *d, double *x, double *y, double avg, double sigma)
 }
 
 static const double PI_F = 3.14159265358979323846;   /* 4.*atan(1.), src/constants.f90:5 */
-/* sin / cos of iSORS' lens-point angle (src/sourceMod.f90:229-230): separate calls, see emit_ring for
- * the one pair flang lowers to sincos() */
-#define ISORS_SINCOS(x, s, c) do { *(c) = cos(x); *(s) = sin(x); } while (0)
+/* WHICH libm entry a sin/cos pair goes through decides its last bit: glibc 2.35's sincos() is another build of the
+ * algorithm than its sin() and cos() (no fused multiply-adds, another split of the middle range), and
+ * sincos(x) != (sin(x), cos(x)) for ~0.1 % of x.  The reference's compiled code (flang -O2) merges every sin/cos pair
+ * of one argument into ONE sincos() call except the first pair of `ring` — sourceMod.o imports sin, cos, sincos;
+ * stokes.o imports atan2, acos, sincos only — and gcc -O2 happened to do the same to the plain C that used to stand
+ * here.  So that no optimiser's mood decides a bit, every site says which entry it means (tests/test_oracle_vs_ref.py
+ * holds the oracle against the compiled reference bit for bit; the device follows the same table, ort_device.h). */
+static double (*volatile libm_sin)(double) = sin;
+static double (*volatile libm_cos)(double) = cos;
+#define SIN_COS_TWO_CALLS(x, s, c) do { *(c) = libm_cos(x); *(s) = libm_sin(x); } while (0)
+#define SINCOS_ONE_CALL(x, s, c) sincos(x, s, c)
+#define ISORS_SINCOS(x, s, c) SINCOS_ONE_CALL(x, s, c)          /* src/sourceMod.f90:229-230 */
 
 /* ------------------------------------------------------- vector_class ---- */
 static inline orc_vec v(double x, double y, double z) { orc_vec r = {x, y, z}; return r; }
@@ -272,18 +281,14 @@ static double nudge(double y, int bit)
 #define M_LOG(x) nudge(log(x), 1)
 #define M_ATAN2(y, x) nudge(atan2(y, x), 2)
 #define M_ACOS(x) nudge(acos(x), 4)
-#define M_SIN1(x) nudge(sin(x), 8)
-#define M_COS1(x) nudge(cos(x), 8)
-#define M_SIN2(x) nudge(sin(x), 16)
-#define M_COS2(x) nudge(cos(x), 16)
+#define M_SINCOS1(x, s, c) do { sincos(x, s, c); *(s) = nudge(*(s), 8); *(c) = nudge(*(c), 8); } while (0)
+#define M_SINCOS2(x, s, c) do { sincos(x, s, c); *(s) = nudge(*(s), 16); *(c) = nudge(*(c), 16); } while (0)
 #else
 #define M_LOG(x) log(x)
 #define M_ATAN2(y, x) atan2(y, x)
 #define M_ACOS(x) acos(x)
-#define M_SIN1(x) sin(x)
-#define M_COS1(x) cos(x)
-#define M_SIN2(x) sin(x)
-#define M_COS2(x) cos(x)
+#define M_SINCOS1(x, s, c) SINCOS_ONE_CALL(x, s, c)
+#define M_SINCOS2(x, s, c) SINCOS_ONE_CALL(x, s, c)
 #endif
 
 /* tauint, src/surfaces.f90:13-50: optical depth to the next event inside the cylinder.
@@ -320,7 +325,7 @@ static void stokes(orc_vec *dir, double hgg, draws_t *d)
         sint = (1. - cost * cost);
         if (sint <= 0.) sint = 0.; else sint = sqrt(sint);
         phi = TWOPI * ran2(d);
-        sinp = sin(phi); cosp = cos(phi);
+        SINCOS_ONE_CALL(phi, &sinp, &cosp);
         nxp = sint * cosp; nyp = sint * sinp; nzp = cost;
     } else {
         double costp = cost, sintp = sint, phip = phi;
@@ -336,7 +341,8 @@ static void stokes(orc_vec *dir, double hgg, draws_t *d)
         double cosi2 = 0., sini2 = 0., cosdph;
         if (ri1 > PI) {
             double ri3 = TWOPI - ri1;
-            double cosi3 = M_COS1(ri3), sini3 = M_SIN1(ri3);
+            double cosi3, sini3;
+            M_SINCOS1(ri3, &sini3, &cosi3);
             if (bmu == 1. || bmu == -1.) goto done;
             cost = costp * bmu + sintp * sinbt * cosi3;
             if (fabs(cost) < 1.) {
@@ -355,7 +361,8 @@ static void stokes(orc_vec *dir, double hgg, draws_t *d)
             if (phi > TWOPI) phi = phi - TWOPI;
             if (phi < 0.) phi = phi + TWOPI;
         } else {
-            double cosi1 = M_COS1(ri1), sini1 = M_SIN1(ri1);
+            double cosi1, sini1;
+            M_SINCOS1(ri1, &sini1, &cosi1);
             if (bmu == 1. || bmu == -1.) goto done;
             cost = costp * bmu + sintp * sinbt * cosi1;
             if (fabs(cost) < 1.) {
@@ -374,7 +381,7 @@ static void stokes(orc_vec *dir, double hgg, draws_t *d)
             if (phi > TWOPI) phi = phi - TWOPI;
             if (phi < 0.) phi = phi + TWOPI;
         }
-        cosp = M_COS2(phi); sinp = M_SIN2(phi);
+        M_SINCOS2(phi, &sinp, &cosp);
         nxp = sint * cosp; nyp = sint * sinp; nzp = cost;
     }
 done:
@@ -556,8 +563,8 @@ static void emit_point(double cosThetaMax, double offset, orc_vec *pos, orc_vec 
 {
     const double twopi = 2. * PI_F;
     double phi = twopi * ran2(d);
-    double cosp = cos(phi);
-    double sinp = sin(phi);
+    double cosp, sinp;
+    SINCOS_ONE_CALL(phi, &sinp, &cosp);
     double ran = ran2(d);
     double cost = (1.0 - ran) + ran * cosThetaMax;
     double sint = sqrt(1.0 - cost * cost);
@@ -575,8 +582,9 @@ static void emit_spot(double cosThetaMax, int nrays, int n, orc_vec *pos, orc_ve
     double deltaTheta = thetaMax / nrays_sqrt;
     double phi = deltaPhi * (double)(n % 10);
     double theta = deltaTheta * (double)(n / 10);
-    double sinp = sin(phi), cosp = cos(phi);
-    double cost = cos(theta);
+    double sinp, cosp;
+    SINCOS_ONE_CALL(phi, &sinp, &cosp);
+    double cost = libm_cos(theta);                      /* cos alone: the cos() entry */
     double sint = sqrt(1. - cost * cost);
     *dir = v(sint * cosp, sint * sinp, cost);
     *pos = v(0., 0., 0.);
@@ -587,7 +595,8 @@ static void emit_crs(const orc_system *S, orc_vec *pos, orc_vec *dir, draws_t *d
 {
     const double twopi = 2. * PI_F;
     double phi = twopi * ran2(d);
-    double cosp = cos(phi), sinp = sin(phi);
+    double cosp, sinp;
+    SINCOS_ONE_CALL(phi, &sinp, &cosp);
     double ran = ran2(d);
     double cost = (1.0 - ran) + ran * S->cosThetaMax;
     double sint = sqrt(1.0 - cost * cost);
@@ -719,7 +728,7 @@ static void emit_cell(const orc_plano *lens, int i, int j, orc_vec *pos, orc_vec
     double r = ranu(d, 0., lens->radius * lens->radius);
     double theta = ran2(d) * twopi;
     double st, ct;
-    sincos(theta, &st, &ct);                            /* as flang lowers this pair, cf. emit_ring */
+    SINCOS_ONE_CALL(theta, &st, &ct);
     orc_vec lp = v(sqrt(r) * ct, sqrt(r) * st, lens->fb);
     double ex = lp.x - pos->x, ey = lp.y - pos->y, ez = lp.z - pos->z;
     double dist = sqrt(ex * ex + ey * ey + ez * ez);
@@ -762,8 +771,10 @@ static void emit_ring(const orc_system *S, orc_vec *pos, orc_vec *dir, draws_t *
     double Ra = S->bottle.radiusa, Rb = S->bottle.radiusb, off = S->bottle.centre.z;
     double r = ranu(d, S->r1, S->r2);
     double theta = ran2(d) * twopi;
-    double posx = sqrt(r) * cos(theta);
-    double posy = sqrt(r) * sin(theta);
+    double ct1, st1;
+    SIN_COS_TWO_CALLS(theta, &st1, &ct1);               /* :272-273: the one pair flang leaves as sin() and cos() */
+    double posx = sqrt(r) * ct1;
+    double posy = sqrt(r) * st1;
     double posz;
     if (S->bottle.ellipse) {
         double q = posy * Ra / Rb;
@@ -776,12 +787,8 @@ static void emit_ring(const orc_system *S, orc_vec *pos, orc_vec *dir, draws_t *
     double rl = lens->radius + 10e-3;
     r = ranu(d, 0., rl * rl);
     theta = ran2(d) * twopi;
-    /* flang 22 -O2 lowers THIS sin/cos pair (and only this one) to glibc sincos(),
-     * whose results differ from sin()/cos() by 1 ulp for ~0.1 % of arguments; it is
-     * used here so that the oracle equals oracle/_ref bit for bit on this image.
-     * Which libm entry a compiler picks is outside the reference's definition. */
     double st, ct;
-    sincos(theta, &st, &ct);
+    SINCOS_ONE_CALL(theta, &st, &ct);                   /* :287-288 */
     posx = sqrt(r) * ct;
     posy = sqrt(r) * st;
     orc_vec lp = v(posx, posy, lens->fb);
