@@ -146,6 +146,26 @@ def single_process(args, phases, rays_gpu, text) -> int:
     run(args.warmup, 0)
     elapsed, reduce_ms = run(args.steps, args.warmup)
     img, cnt8 = ctxs[0].read()                                  # the global sums (every context holds them)
+    # the reduce proves itself (outside the timed region): one extra step sharded over the devices and all-reduced ==
+    # the same global range traced by device 0 alone, image and all 8 counters (src/main.f90:88, src/imageMod.f90:55-56)
+    reduce_verified = None
+    if world > 1 or args.force_dist:
+        import numpy as np
+        kv = args.warmup + args.steps
+        for c in ctxs:
+            c.reset()
+        for c, (lo, cnt) in zip(ctxs, shards):
+            for ph in phases:
+                c.trace(ph, kv * total_rays + lo, cnt, DEFAULT_SEED)
+        capi.allreduce(ctxs)
+        sums = [c.read() for c in ctxs]
+        ctxs[0].reset()
+        for ph in phases:
+            ctxs[0].trace(ph, kv * total_rays, total_rays, DEFAULT_SEED)
+        alone = ctxs[0].read()
+        reduce_verified = all(np.array_equal(si, alone[0]) and np.array_equal(sc, alone[1]) for si, sc in sums)
+        if not reduce_verified:
+            sys.stderr.write("bench.py: the all-reduced image of the device shards differs from device 0's trace of the same rays\n")
     isect = sum(int(cnt8[C_ISECT_RING if ph == 1 else C_ISECT_POINT]) for ph in phases)
     for ph in phases:
         assert int(img[ph - 1].sum()) == int(cnt8[C_BINNED_RING if ph == 1 else C_BINNED_POINT]), "image and counter disagree"
@@ -163,6 +183,9 @@ def single_process(args, phases, rays_gpu, text) -> int:
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "value_executed": (isect - culled) / elapsed, "reduce_ms": reduce_ms,
+        "reduce_verified": reduce_verified, "ranks_seen": capi.allreduce_ranks() if (world > 1 or args.force_dist) else 1,
+        "kernel_ms_per_step_over_ranks": (lambda v: {"min": min(v), "max": max(v)})(
+            [sum(k) / len(k) * len(phases) for k in (c.kernel_times(min(args.steps * len(phases), 64)) for c in ctxs)]),
         "config": {"workload": text, "name": args.workload, "host": "single-process: one context per device, ort_allreduce",
                    "rays_per_layer_per_step": total_rays, "rays_per_gpu_per_launch": cnt0, "phases": list(phases),
                    "seed": DEFAULT_SEED, "intersections_per_step": isect / args.steps, "settle_launches": settle,
@@ -173,7 +196,7 @@ def single_process(args, phases, rays_gpu, text) -> int:
     }), flush=True)
     for c in ctxs:
         c.close()
-    return 0
+    return 3 if reduce_verified is False else 0
 
 
 def cpu_baseline(rays: int, program_runs: int = 0):
@@ -409,6 +432,43 @@ def main() -> int:
         legs[name] = (el, kms, r, timed_run.culled)
     ctx.set_precision(0)
 
+    # ---- N > 1 proves itself (outside every timed region): ONE extra step traced the way the timed steps are — every rank
+    # its shard, then the all-reduce — against the SAME global range traced by rank 0 alone.  Keyed draws make the two
+    # identical bin for bin if and only if the shards tile the range and the reduce sums every rank exactly once
+    # (reference: the shared image + reduction(+:rcount,pcount) of src/main.f90:88, src/imageMod.f90:55-56).
+    reduce_verified, per_rank_ms = None, None
+    if use_dist:
+        kv = args.warmup + args.steps                  # a step of the global index range no leg has traced
+        tracer.reset()
+        step(kv)
+        tracer.reduce(force=True)
+        fence()
+        summed = tracer.result(total_rays)
+        tracer.reset()
+        fence()
+        if rank == 0:
+            for ph in phases:
+                ctx.trace(ph, kv * total_rays, total_rays, DEFAULT_SEED)
+        alone = tracer.result(total_rays)              # (no reduce: what THIS rank traced)
+        ok = True
+        if rank == 0:
+            import numpy as np
+            ok = bool(np.array_equal(summed.image, alone.image) and np.array_equal(summed.counters, alone.counters))
+            if not ok:
+                sys.stderr.write(f"bench.py: the reduced image of {world} shards differs from the single-rank trace of the same rays "
+                                 f"(L1 {int(abs(summed.image.astype('int64') - alone.image.astype('int64')).sum())}; counters "
+                                 f"{summed.counters.tolist()} vs {alone.counters.tolist()})\n")
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        reduce_verified = bool(int(flag.item()))
+        tracer.reset()
+        # per-rank step time of the timed fp64 leg (mean launch x launches per step): min / max over the ranks
+        mine = torch.tensor([sum(kernel_ms) / len(kernel_ms) * len(phases)], dtype=torch.float64, device="cuda")
+        lo_t, hi_t = mine.clone(), mine.clone()
+        dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+        per_rank_ms = {"min": float(lo_t.item()), "max": float(hi_t.item())}
+
     # ---- roofline of the dominant kernel (the fused trace kernel), per launch = per rank per phase
     # of a step.  kernel_ms holds one entry per ort_trace call (queued kernel + its literal re-run
     # launch + fold_kernel, one event bracket); a step of a two-phase workload is two launches.
@@ -475,6 +535,10 @@ def main() -> int:
         # solve (segment 0 of the ring programs; 0 for the point loop), and the all-reduce on its own
         "value_executed": isect_exec_per_step * args.steps / elapsed,
         "reduce_ms": reduce_ms,
+        # N > 1 (or --force-dist): one extra sharded + reduced step == the same rays on rank 0 alone, image and 8 counters
+        "reduce_verified": reduce_verified,
+        "ranks_seen": (dist.get_world_size() if use_dist else 1),
+        "kernel_ms_per_step_over_ranks": per_rank_ms,
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
@@ -585,6 +649,8 @@ def main() -> int:
     tracer.close()
     if use_dist:
         dist.destroy_process_group()
+    if reduce_verified is False:
+        return 3                                    # a wrong sum is a failed run, whatever the throughput
     return 0
 
 

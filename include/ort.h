@@ -258,6 +258,9 @@ int ort_attach_buffers(ort_ctx *ctx, void *d_image, void *d_counters);
  * on first use (ORT_E_NOCOMM if absent).  A one-process-per-GPU host reduces the attached
  * buffers with its own communicator instead (torch.distributed: tracer.py). */
 int ort_allreduce(ort_ctx **ctxs, int n);
+/* The number of ranks of the communicator the last ort_allreduce of this process used, as RCCL reports it
+ * (ncclCommCount); 0 before the first one.  A multi-GPU run states it next to its figures (bench.py `ranks_seen`). */
+int ort_allreduce_ranks(int *n_ranks);
 int ort_device_image(ort_ctx *ctx, void **d_image);
 int ort_device_counters(ort_ctx *ctx, void **d_counters);
 int ort_synchronize(ort_ctx *ctx);

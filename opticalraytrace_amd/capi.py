@@ -179,6 +179,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ort_abi_version": (C.c_int, []),
         "ort_build_id": (C.c_char_p, []),
         "ort_allreduce": (C.c_int, [C.POINTER(vp), i32]),
+        "ort_allreduce_ranks": (C.c_int, [C.POINTER(C.c_int)]),
         "ort_last_error": (C.c_char_p, []),
         "ort_device_count": (C.c_int, [C.POINTER(C.c_int)]),
         "ort_create": (C.c_int, [C.POINTER(OrtSystem), i32, vp, C.POINTER(vp)]),
@@ -216,7 +217,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-EXPORTED_SYMBOLS = ["ort_abi_version", "ort_build_id", "ort_allreduce", "ort_last_error", "ort_device_count", "ort_create",
+EXPORTED_SYMBOLS = ["ort_abi_version", "ort_build_id", "ort_allreduce", "ort_allreduce_ranks", "ort_last_error", "ort_device_count", "ort_create",
                     "ort_destroy", "ort_set_system", "ort_set_image_source", "ort_reset", "ort_flush", "ort_trace", "ort_emit",
                     "ort_trace_resident", "ort_trace_rays", "ort_trace_paths", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
@@ -405,6 +406,14 @@ def allreduce(contexts) -> None:
     lib = load_library()
     arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
     _check(lib, lib.ort_allreduce(arr, len(contexts)), "ort_allreduce")
+
+
+def allreduce_ranks() -> int:
+    """Ranks of the communicator the last ort_allreduce used, as RCCL reports it (0 before the first)."""
+    lib = load_library()
+    n = C.c_int(0)
+    _check(lib, lib.ort_allreduce_ranks(C.byref(n)), "ort_allreduce_ranks")
+    return n.value
 
 
 def device_count() -> int:

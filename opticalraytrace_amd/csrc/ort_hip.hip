@@ -2483,6 +2483,7 @@ struct Rccl {
     void *lib;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
     ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);
     ncclResult_t (*GroupStart)();
     ncclResult_t (*GroupEnd)();
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
@@ -2503,6 +2504,7 @@ int rccl_load()
     if (!g_rccl.field) return fail(ORT_E_NOCOMM, "librccl.so.1 lacks " name)
     ORT_SYM(CommInitAll, "ncclCommInitAll");
     ORT_SYM(CommDestroy, "ncclCommDestroy");
+    ORT_SYM(CommCount, "ncclCommCount");
     ORT_SYM(GroupStart, "ncclGroupStart");
     ORT_SYM(GroupEnd, "ncclGroupEnd");
     ORT_SYM(AllReduce, "ncclAllReduce");
@@ -2553,12 +2555,33 @@ int ort_allreduce(ort_ctx **ctxs, int n)
         if (frc) return frc;
     }
     RCCL_TRY(g_rccl.GroupStart());
-    for (int i = 0; i < n; ++i) {
+    // The group is ENDED on every path: a call that fails inside it (RCCL records the error, ncclGroupEnd then drops what
+    // was queued and returns it) must not leave the process with an open group that swallows every later RCCL call.
+    // ORT_FAULT_ALLREDUCE (tests): the first collective is given an invalid datatype.
+    ncclResult_t bad = ncclSuccess;
+    const char *what = nullptr;
+    const bool fault = getenv("ORT_FAULT_ALLREDUCE") != nullptr;
+    for (int i = 0; i < n && bad == ncclSuccess; ++i) {
         ort_ctx *c = ctxs[i];
-        RCCL_TRY(g_rccl.AllReduce(c->d_image, c->d_image, ORT_IMAGE_BINS, ncclInt32, ncclSum, g_rccl.comms[i], c->stream));
-        RCCL_TRY(g_rccl.AllReduce(c->d_counters, c->d_counters, ORT_NUM_COUNTERS, ncclUint64, ncclSum, g_rccl.comms[i], c->stream));
+        bad = g_rccl.AllReduce(c->d_image, c->d_image, ORT_IMAGE_BINS, (fault && i == 0) ? (ncclDataType_t)99 : ncclInt32, ncclSum, g_rccl.comms[i], c->stream);
+        if (bad != ncclSuccess) { what = "ncclAllReduce(image)"; break; }
+        bad = g_rccl.AllReduce(c->d_counters, c->d_counters, ORT_NUM_COUNTERS, ncclUint64, ncclSum, g_rccl.comms[i], c->stream);
+        if (bad != ncclSuccess) what = "ncclAllReduce(counters)";
     }
-    RCCL_TRY(g_rccl.GroupEnd());
+    const ncclResult_t end = g_rccl.GroupEnd();
+    if (bad != ncclSuccess) return rccl_fail(what, bad);
+    if (end != ncclSuccess) return rccl_fail("ncclGroupEnd", end);
+    return ORT_OK;
+}
+
+int ort_allreduce_ranks(int *n_ranks)
+{
+    if (!n_ranks) return fail(ORT_E_INVALID, "NULL argument");
+    *n_ranks = 0;
+    if (!g_rccl.lib || g_rccl.n == 0) return ORT_OK;          // no ort_allreduce yet
+    int n = 0;
+    RCCL_TRY(g_rccl.CommCount(g_rccl.comms[0], &n));            // what RCCL itself says, not what it was asked for
+    *n_ranks = n;
     return ORT_OK;
 }
 

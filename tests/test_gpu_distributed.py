@@ -125,6 +125,31 @@ def test_c_abi_allreduce(plain):
     assert np.array_equal(cnt, want.counters)
 
 
+def test_c_abi_allreduce_ends_its_group_on_a_failed_collective(plain):
+    """A collective that fails INSIDE ncclGroupStart ... ncclGroupEnd (here: an invalid datatype planted by
+    ORT_FAULT_ALLREDUCE) is reported — and the group is ended all the same: the next ort_allreduce of the process works
+    and leaves the right sums.  (Round 3's ort_allreduce returned from inside the open group.)"""
+    import ctypes as C
+    from opticalraytrace_amd import capi
+    osys, want = plain
+    lib = capi.load_library()
+    with capi.Context(osys, device=0) as a:
+        a.reset()
+        for phase in (1, 2):
+            a.trace(phase, 0, N, SEED)
+        arr = (C.c_void_p * 1)(a._h)
+        os.environ["ORT_FAULT_ALLREDUCE"] = "1"
+        try:
+            rc = lib.ort_allreduce(arr, 1)
+        finally:
+            del os.environ["ORT_FAULT_ALLREDUCE"]
+        assert rc != 0 and b"ncclAllReduce" in lib.ort_last_error(), (rc, lib.ort_last_error())
+        capi.allreduce([a])                         # the group was ended: this one goes through
+        img, cnt = a.read()
+    assert np.array_equal(img, want.image)
+    assert np.array_equal(cnt, want.counters)
+
+
 def _bench(*flags, timeout=600):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
@@ -144,6 +169,7 @@ def test_bench_starts_its_own_ranks_or_fails_cleanly():
         assert p.returncode == 0, p.stderr[-2000:]
         line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["n_gpus"] == 2 and line["value"] > 0
+        assert line["reduce_verified"] is True and line["ranks_seen"] == 2
 
 
 def test_bench_one_rank_through_rccl():
@@ -156,6 +182,9 @@ def test_bench_one_rank_through_rccl():
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 1e9
     assert abs(line["config"]["intersections_per_step"] / 1e6 - 6.31) < 0.05      # 6.31 per point ray
     assert line["roofline"]["bound"] == "valu_fp64" and 0 < line["roofline"]["frac"] < 1
+    # the run proves its own reduce: one extra sharded + all-reduced step == the same rays traced by rank 0 alone
+    assert line["reduce_verified"] is True and line["ranks_seen"] == 1 and line["reduce_ms"] > 0
+    assert 0 < line["kernel_ms_per_step_over_ranks"]["min"] <= line["kernel_ms_per_step_over_ranks"]["max"]
 
 
 def test_bench_single_process_layout():
@@ -168,6 +197,8 @@ def test_bench_single_process_layout():
     assert line["n_gpus"] == 1 and line["value"] > 1e9 and "single-process" in line["config"]["host"]
     assert abs(line["config"]["intersections_per_step"] / 1e6 - 6.31) < 0.05
     assert line["reduce_ms"] > 0 and 0 < line["roofline"]["frac"] < 1
+    assert line["reduce_verified"] is True and line["ranks_seen"] == 1            # ncclCommCount of the library's communicator
+    assert 0 < line["kernel_ms_per_step_over_ranks"]["min"] <= line["kernel_ms_per_step_over_ranks"]["max"]
     import torch
     n = torch.cuda.device_count() + 1
     p = _bench("--gpus", str(n), "--single-process", "--steps", "3", "--warmup", "1")
@@ -248,3 +279,6 @@ def test_bench_two_rank_flow_rehearsed_on_one_gpu():
     assert line["config"]["rays_per_layer_per_step"] == 2_000_000 and line["config"]["rays_per_gpu_per_launch"] == 1_000_000
     assert abs(line["config"]["intersections_per_step"] / 2e6 - 6.31) < 0.05          # both shards counted
     assert line["value"] > 1e9 and line["reduce_ms"] > 0
+    # two REAL shards summed (gloo): the extra step of both ranks, reduced, equals rank 0's trace of the whole range
+    assert line["reduce_verified"] is True and line["ranks_seen"] == 2
+    assert 0 < line["kernel_ms_per_step_over_ranks"]["min"] <= line["kernel_ms_per_step_over_ranks"]["max"]
