@@ -7,9 +7,12 @@
  * `ran2()` (reference src/surfaces.f90:275, src/random_mod.f90:39-46), and
  * `ran2()` is the compiler runtime's `random_number`, whose stream depends on
  * the compiler and the thread count.  Two implementations can only be compared
- * ray by ray when they are fed the same draws, so the harness replaces module
- * `random` (and nothing else) by oracle/ref/ref_random.f90, which forwards to
- * the functions below.  Two modes:
+ * ray by ray when they are fed the same draws, so the harness defines the ONE
+ * runtime entry the reference's ran2() reaches — flang lowers
+ * `call random_number(ran2)` (src/random_mod.f90:44) to _FortranARandomNumber —
+ * here, in front of the Fortran runtime in the library's symbol order.  Module
+ * `random` itself (ran2, ranu, rang: the Box-Muller sampling of the crs and isors
+ * sources) is the reference's own source, compiled unmodified.  Two modes:
  *
  *   table mode  — the k-th draw of the current ray is u[k] from a caller table
  *   keyed mode  — the k-th draw of ray i of phase p is ORT-RNG-v2(seed,p,i,k)
@@ -67,3 +70,21 @@ double ortref_draw(void)
     uint32_t w = (c & 1ull) ? (uint32_t)h : (uint32_t)(h >> 32);
     return (double)w * 0x1.0p-32;
 }
+
+/* flang's lowering of `call random_number(x)`: the Fortran runtime's RandomNumber(harvest descriptor, source file, line).
+ * A descriptor (ISO_Fortran_binding CFI_cdesc_t) begins with the base address; the reference only ever draws one
+ * default real at a time (a real*8 under -fdefault-real-8): src/random_mod.f90:44. */
+void _FortranARandomNumber(void *harvest, const char *source, int line)
+{
+    (void)source; (void)line;
+    **(double **)harvest = ortref_draw();
+}
+/* init_rng (src/random_mod.f90:10-37; not called by the harness, whose draws are keyed per ray) reaches random_seed(size=)
+ * and random_seed(put=): the other two entries of the runtime's random.cpp object.  Defined here so that the static
+ * Fortran runtime's copy of that object — which would define RandomNumber a second time — is not linked at all. */
+void _FortranARandomSeedSize(void *size, const char *source, int line)
+{
+    (void)source; (void)line;
+    if (size && *(int **)size) **(int **)size = 1;
+}
+void _FortranARandomSeedPut(void *put, const char *source, int line) { (void)put; (void)source; (void)line; }
