@@ -183,7 +183,10 @@ int ort_set_system(ort_ctx *ctx, const ort_system *sys);
 /* Histogram of the `image` light source (reference imgin, src/sourceMod.f90:363-408) as its
  * cumulative sum in the order emit_image scans the cells (:313-321): cdf[0] = 0,
  * cdf[s+1] = cdf[s] + count of cell s, ORT_IMAGE_SOURCE_CELLS + 1 host values.  Ray i of the
- * point loop starts in the cell with cdf[s] <= i < cdf[s+1]. */
+ * point loop starts in the cell with cdf[s] <= i < cdf[s+1].
+ * SYNCHRONOUS, unlike ort_set_system: the context holds ONE table (2 MB), so the call waits for the traces already
+ * queued on the stream (they read the old table) before it returns — a batched sweep of `image`-source systems drains
+ * the queue once per simulation that brings a new table. */
 int ort_set_image_source(ort_ctx *ctx, const int64_t *cdf);
 int ort_reset(ort_ctx *ctx);                       /* image = 0, counters = 0 (src/main.f90:39-41) */
 /* ort_trace bins into per-XCD private copies of the image and adds them into the image when the

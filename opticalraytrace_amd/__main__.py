@@ -61,11 +61,14 @@ def main(argv=None) -> int:
         print(f"raytrace: {e}", file=sys.stderr)
         return 1
     try:
-        if world == 1:
-            # a process of its own for ONE simulation (runner.py:26-47): no torch — its import is ~1 s of such a
-            # process — the library's own accumulators (tracer.LocalTracer)
-            os.environ.setdefault("ORT_NO_TORCH", "1")
+        # a process of its own for ONE simulation (runner.py:26-47): no torch — its import is ~1 s of such a process — the
+        # library's own accumulators (tracer.LocalTracer).  Decided HERE, for this call: nothing is written to the
+        # environment (children would inherit it), and a process that already holds torch keeps it.
+        local = world == 1 and "torch" not in sys.modules and os.environ.get("ORT_NO_TORCH", "1") == "1"
+        from . import capi
         from .capi import OrtError
+        if local:
+            capi.load_library(no_torch=True)
         from .tracer import (LocalTracer, RayTracer, append_stats, output_basename, write_images,
                              write_tracker_files)
         group = None
@@ -81,7 +84,7 @@ def main(argv=None) -> int:
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
             else:
                 dist.init_process_group(backend, rank=rank, world_size=world)
-        if world == 1 and os.environ.get("ORT_NO_TORCH") == "1":
+        if local:
             tracer = LocalTracer(system, device=device)
         else:
             tracer = RayTracer(system, device=device, rank=rank, world=world, process_group=group)

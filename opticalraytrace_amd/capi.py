@@ -153,23 +153,31 @@ def source_build_id() -> str:
     return h.hexdigest()[:16]
 
 
-def load_library(path: Optional[str] = None) -> C.CDLL:
-    """Load libort_hip.so and declare every symbol of include/ort.h.  Raises if absent."""
-    global _LIB
+def load_library(path: Optional[str] = None, no_torch: Optional[bool] = None) -> C.CDLL:
+    """Load libort_hip.so and declare every symbol of include/ort.h.  Raises if absent.
+
+    PyTorch-ROCm bundles its own HIP/HSA runtime.  It must be the first one loaded into the process: libort_hip.so then
+    binds to that same runtime (same SONAME), and torch tensors, streams and RCCL share one device context with the
+    kernels; loading /opt/rocm's runtime first leaves a later `import torch` with "No HIP GPUs are available".  So torch
+    is imported here first — unless the caller says the process will never use it (`no_torch=True`: the single-GPU
+    process entry, whose start-up would otherwise be mostly that import; the library then binds to /opt/rocm's runtime).
+    ORT_NO_TORCH=1 in the environment is read as that same statement, as an override only: nothing here or in the process
+    entry writes it (a child process, or a later RayTracer in the same process, must not inherit the decision).  A process
+    that loaded the library without torch and imports torch afterwards is told so (`torch_safe()`)."""
+    global _LIB, _LOADED_WITHOUT_TORCH
     if _LIB is not None and path is None:
         return _LIB
     p = path or library_path()
-    if os.environ.get("ORT_NO_TORCH") != "1":
+    if no_torch is None:
+        no_torch = os.environ.get("ORT_NO_TORCH") == "1"
+    import sys as _sys
+    if not no_torch or "torch" in _sys.modules:
         try:
-            # PyTorch-ROCm bundles its own HIP/HSA runtime.  It must be the first one loaded into
-            # the process: libort_hip.so then binds to that same runtime (same SONAME), and torch
-            # tensors, streams and RCCL share one device context with the kernels.  Loading
-            # /opt/rocm's runtime first leaves torch with "No HIP GPUs are available".
-            # (ORT_NO_TORCH=1: a process that will never import torch — the single-GPU process entry, whose start-up
-            # would otherwise be mostly that import — lets the library bind to /opt/rocm's runtime.)
             import torch  # noqa: F401
         except ImportError:
             pass
+    elif path is None:
+        _LOADED_WITHOUT_TORCH = True
     if not os.path.exists(p):
         raise OrtError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; "
                        "g.build()'` — there is no CPU fallback for the trace path")
@@ -215,6 +223,15 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if path is None:
         _LIB = lib
     return lib
+
+
+_LOADED_WITHOUT_TORCH = False
+
+
+def torch_safe() -> bool:
+    """False when this process bound libort_hip.so to /opt/rocm's HIP runtime (load_library(no_torch=True)): importing
+    torch afterwards would bring a second runtime into the process."""
+    return not _LOADED_WITHOUT_TORCH
 
 
 EXPORTED_SYMBOLS = ["ort_abi_version", "ort_build_id", "ort_allreduce", "ort_allreduce_ranks", "ort_last_error", "ort_device_count", "ort_create",

@@ -34,14 +34,18 @@ def str_logical_array(a: Iterable[bool]) -> str:
 # ---------------------------------------------------------------------------
 # list-directed output (`write(u,*) ...`) as the compiler the reference is built with here (AMD flang
 # 22, ROCm 7.2) lays it out — what the stats row of src/main.f90:168-178 looks like in a file the
-# unmodified program wrote (tests/golden/refprog_*.npz hold two such files).  Reconstructed from them:
-#   * a REAL(8) is its shortest round-trip digits: `0.` for zero, F form (`49.250400000000006`, `100.`)
-#     for 0.1 <= |x| < 1e16, else `d.dddE+-XX` (`3.99E-02`, `5.E-02`, `-2.E-03`);
+# unmodified program wrote.  Pinned by two kinds of fixture: the reference program's own files
+# (tests/golden/refprog_*.npz) and tests/golden/flang_list_directed.json — 54 values printed by a flang-built
+# program in this container (make_list_directed_golden.py), covering every rule below and its edges:
+#   * a REAL(8) is its shortest round-trip digits: `0.` for zero; F form WITHOUT a leading zero (`49.250400000000006`,
+#     `100.`, `.5`, `-.25`) when the value ROUNDED TO ONE SIGNIFICANT DIGIT lies in [0.1, 1e15) — so `.0951` and
+#     `940000000000000.` but `9.49E-02` and `9.5E+14` —, else `d.dddE+-XX` (`3.99E-02`, `5.E-02`, `-2.E-03`, `1.E-300`);
 #   * numeric and logical items are preceded by one blank; a character item only when the item before it
 #     was not a character item;
 #   * a record holds at most 79 characters: an item that does not fit starts a new record — a character
 #     item then without its blank —, and a character item longer than a record is cut at 79 with the
 #     rest on the next record behind a blank.
+# (gfortran, the reference Makefile's compiler, pads differently and is not available here to pin.)
 # ---------------------------------------------------------------------------
 LIST_DIRECTED_WIDTH = 79
 
@@ -64,12 +68,15 @@ def list_directed_real(x: float) -> str:
         e10 = -(len(fp) - len(fp.lstrip("0")) + 1) + ex
     alld = alld.rstrip("0") or "0"
     sign = "-" if x < 0 else ""
-    if 0.1 <= abs(x) < 1e16:
+    # flang decides between the two forms on the value rounded to ONE significant digit: 0.0951 -> 0.1 (F), 9.5e14 -> 1e15 (E)
+    from decimal import Decimal, ROUND_HALF_EVEN
+    one = Decimal(abs(x)).scaleb(-e10).quantize(Decimal(1), rounding=ROUND_HALF_EVEN)
+    e1 = e10 + (1 if one >= 10 else 0)
+    if -1 <= e1 < 15:
         if e10 >= 0:
             body = alld[:e10 + 1].ljust(e10 + 1, "0") + "." + alld[e10 + 1:]
-        else:                                   # 0.1 <= |x| < 1
+        else:                                   # |x| < 1: no leading zero
             body = "." + "0" * (-e10 - 1) + alld
-            body = "0" + body
         return sign + body
     return f"{sign}{alld[0]}.{alld[1:]}E{'+' if e10 >= 0 else '-'}{abs(e10):02d}"
 

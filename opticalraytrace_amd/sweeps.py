@@ -8,7 +8,10 @@ and `iSORS_vs_Bessel` :267-320, which runner.py defines but wires to no flag: `-
 the simulations of an experiment are QUEUED on one reused GPU context — system re-staged asynchronously,
 one device array of images for the whole batch, one wait and one copy back at the end (RayTracer.run_many)
 — instead of one `./install.sh -n 32 -f <settings>` process each (runner.py:26-47); `--one-by-one` runs
-them one `run_settings` call at a time (same files, bit for bit).  `-b` needs the Bessel image
+them one `run_settings` call at a time (same files, bit for bit).  (Exception: a simulation that brings a new `image`
+source table waits for the queue — ort_set_image_source is synchronous, the context holds one table.)  A settings file
+that cannot be built into a system fails at the `run()` call that names it; if a batch fails on the device the queue is
+re-run one simulation at a time, so every simulation before the failing one still leaves its files.  `-b` needs the Bessel image
 `bessel-smear.dat` (bpm.py's output, not shipped by the reference) in the res directory and fails
 with a clear message without it.
 """
@@ -40,9 +43,18 @@ def _experiment(fn):
     @functools.wraps(fn)
     def wrapped(self, *a, **k):
         try:
-            return fn(self, *a, **k)
-        finally:
-            self.flush()
+            out = fn(self, *a, **k)
+        except BaseException:
+            # the experiment failed while queueing: what was queued before the failing call still runs — as runner.py
+            # would have left the outputs of every simulation before the bad one — but a failure of THAT must not
+            # replace the experiment's own exception
+            try:
+                self.flush()
+            except Exception:
+                pass
+            raise
+        self.flush()
+        return out
     return wrapped
 
 
@@ -57,13 +69,15 @@ class Sweep:
         self.batched = batched
         self.tracer: Optional[RayTracer] = None
         self.results: List[Tuple[str, Settings, RunResult]] = []
-        self._pending: List[Tuple[str, Settings]] = []
+        self._pending: List[Tuple[str, Settings, object]] = []     # (name, settings, the system built from them)
 
     def close(self) -> None:
-        self.flush()
-        if self.tracer is not None:
-            self.tracer.close()
-            self.tracer = None
+        try:
+            self.flush()
+        finally:
+            if self.tracer is not None:
+                self.tracer.close()
+                self.tracer = None
 
     def _tracer_for(self, s: Settings) -> RayTracer:
         if self.tracer is None:
@@ -85,20 +99,34 @@ class Sweep:
             res = run_settings(s, self.res_dir, self.data_dir, self.device, self.verbose, self._tracer_for(s))
             self.results.append((name, s, res))
             return res
-        self._pending.append((name, s))
+        # the system is built (lens / bottle files read and checked) HERE, so that a bad settings file fails at the call
+        # that names it, as the reference program would have — not later, inside a batch of 128
+        from .system import OpticalSystem
+        self._pending.append((name, s, OpticalSystem.from_settings(s, self.res_dir)))
         if len(self._pending) >= self.MAX_BATCH:
             self.flush()
         return None
 
     def flush(self) -> None:
-        """Run the queued simulations as one batch, then leave each one's files, in queue order."""
+        """Run the queued simulations as one batch, then leave each one's files, in queue order.  If the batch fails
+        (a device error in the middle of it) the queue is re-run one simulation at a time, so that — like runner.py,
+        which runs them one by one — every simulation before the failing one leaves its outputs; the error of the
+        failing one is raised after that."""
         if not self._pending:
             return
-        from .system import OpticalSystem
+        from .capi import OrtError
         pending, self._pending = self._pending, []
-        systems = [OpticalSystem.from_settings(s, self.res_dir) for _, s in pending]
-        results = self._tracer_for(pending[0][1]).run_many(systems)
-        for (name, s), system, res in zip(pending, systems, results):
+        tracer = self._tracer_for(pending[0][1])
+        try:
+            results = tracer.run_many([system for _, _, system in pending])
+        except (OrtError, RuntimeError):
+            for name, s, system in pending:
+                tracer.set_system(system)
+                res = tracer.run(s.nphotons)
+                write_outputs(system, res, self.data_dir, self.verbose)
+                self.results.append((name, s, res))
+            return
+        for (name, s, system), res in zip(pending, results):
             write_outputs(system, res, self.data_dir, self.verbose)
             self.results.append((name, s, res))
 

@@ -76,6 +76,11 @@ class ShardedRun:
     def _synchronize(self) -> None:
         pass
 
+    def _on_stream(self):
+        """Context manager: tensor operations issued inside run on the stream the traces run on (GPU tracer)."""
+        import contextlib
+        return contextlib.nullcontext()
+
     def _flush(self) -> None:
         """Everything traced so far is in `image` / `counters` (stream-ordered)."""
 
@@ -85,8 +90,9 @@ class ShardedRun:
 
     def reset(self) -> None:
         self._flush()
-        self.image.zero_()
-        self.counters.zero_()
+        with self._on_stream():
+            self.image.zero_()
+            self.counters.zero_()
 
     def trace_phase(self, phase: int, nphotons: int, seed: int = DEFAULT_SEED) -> None:
         """This rank's shard of one phase (asynchronous on the GPU path)."""
@@ -99,14 +105,16 @@ class ShardedRun:
         self._flush()
         if self.world > 1 or force:
             import torch.distributed as dist
-            dist.all_reduce(self.image, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(self.counters, op=dist.ReduceOp.SUM, group=self.group)
+            with self._on_stream():
+                dist.all_reduce(self.image, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(self.counters, op=dist.ReduceOp.SUM, group=self.group)
 
     def result(self, nphotons: int) -> RunResult:
         self._flush()
         self._synchronize()
-        return RunResult(self.image.cpu().numpy().copy(),
-                         self.counters.cpu().numpy().astype(np.uint64), nphotons)
+        with self._on_stream():
+            return RunResult(self.image.cpu().numpy().copy(),
+                             self.counters.cpu().numpy().astype(np.uint64), nphotons)
 
     def run(self, nphotons: int, seed: int = DEFAULT_SEED, phases=(1, 2)) -> RunResult:
         """Both loops of src/main.f90 + the reduction; returns the global result on every rank."""
@@ -136,7 +144,8 @@ class ShardedRun:
         n = len(systems)
         if n == 0:
             return []
-        images, counters = self._new_accumulators(n)
+        with self._on_stream():                 # zero-filled on the stream the traces into them run on
+            images, counters = self._new_accumulators(n)
         try:
             for i, system in enumerate(systems):
                 self._begin_simulation(system, images[i], counters[i])
@@ -145,13 +154,14 @@ class ShardedRun:
                     self._trace_shard(phase, lo, cnt, seed)
         finally:
             self._end_batch()
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(images, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=self.group)
-        self._synchronize()
-        h_img = images.cpu().numpy()
-        h_cnt = counters.cpu().numpy().astype(np.uint64)
+        with self._on_stream():
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(images, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=self.group)
+            self._synchronize()
+            h_img = images.cpu().numpy()
+            h_cnt = counters.cpu().numpy().astype(np.uint64)
         return [RunResult(h_img[i], h_cnt[i], s.settings.nphotons) for i, s in enumerate(systems)]
 
 
@@ -160,6 +170,10 @@ class RayTracer(ShardedRun):
 
     def __init__(self, system: OpticalSystem, device: int = 0, rank: int = 0, world: int = 1,
                  process_group=None):
+        from . import capi
+        if not capi.torch_safe():
+            raise RuntimeError("this process loaded libort_hip.so without torch (load_library(no_torch=True), the single-GPU "
+                               "process entry): a RayTracer needs torch's HIP runtime to be the one the library is bound to")
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("RayTracer needs a HIP device: the trace path has no CPU fallback")
@@ -171,9 +185,14 @@ class RayTracer(ShardedRun):
         image = torch.zeros((2, IMAGE_N, IMAGE_N), dtype=torch.int32, device=self.device)
         counters = torch.zeros(NUM_COUNTERS, dtype=torch.int64, device=self.device)
         super().__init__(image, counters, rank, world, process_group)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.ctx = Context(system, device=device, stream=stream)
+        # the context traces on the stream that is current NOW; everything this class allocates, zeroes, reduces or
+        # copies later is issued under that same stream (`_on_stream`), whatever stream the caller has made current by then
+        self.stream = torch.cuda.current_stream(self.device)
+        self.ctx = Context(system, device=device, stream=self.stream.cuda_stream)
         self.ctx.attach_buffers(self.image.data_ptr(), self.counters.data_ptr())
+
+    def _on_stream(self):
+        return self.torch.cuda.stream(self.stream)
 
     def close(self) -> None:
         self.ctx.close()

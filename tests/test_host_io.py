@@ -87,12 +87,19 @@ def test_bench_refuses_more_ranks_than_gpus_before_touching_a_gpu():
 
 
 def test_list_directed_reals_and_records():
-    """fstr.list_directed_*: the layout of flang's `write(u,*)` as reconstructed from the reference program's own
-    files (shortest round-trip digits; F form for 0.1 <= |x| < 1e16, else d.dddE+-XX; records of 79 columns)."""
+    """fstr.list_directed_*: the layout of flang's `write(u,*)` (shortest round-trip digits; F form without a leading zero
+    when the value rounded to one digit is in [0.1, 1e15), else d.dddE+-XX; records of 79 columns) — against 54 values a
+    flang-built program printed here (tests/golden/flang_list_directed.json) and the reference program's own files."""
+    import json
     R = fstr.list_directed_real
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flang_list_directed.json")))
+    assert len(gold["records"]) >= 50
+    for r in gold["records"]:
+        x = float.fromhex(r["value"])
+        assert R(x) == r["text"], (x, R(x), r["text"])
     for x, want in ((0.034800000000001496, "3.4800000000001496E-02"), (49.250400000000006, "49.250400000000006"),
                     (0.0399, "3.99E-02"), (0.05, "5.E-02"), (-2e-3, "-2.E-03"), (0.0, "0."), (60.07, "60.07"),
-                    (100.0, "100."), (0.5, "0.5"), (0.1, "0.1"), (1e-10, "1.E-10"), (1234.5, "1234.5"), (-0.25, "-0.25")):
+                    (100.0, "100."), (0.5, ".5"), (0.1, ".1"), (1e-10, "1.E-10"), (1234.5, "1234.5"), (-0.25, "-.25")):
         assert R(x) == want, (x, R(x), want)
         assert float(R(x).replace("E", "e")) == x
     rec = fstr.list_directed_record
@@ -100,5 +107,5 @@ def test_list_directed_reals_and_records():
     long = "x" * 100
     out = rec([long])
     assert out == " " + "x" * 78 + "\n " + "x" * 22 + "\n" and all(len(ln) <= 79 for ln in out.splitlines())
-    out = rec([1.0 / 3.0] * 6)                     # 6 x 19 characters: the fifth item starts a new record
-    assert [len(ln) for ln in out.splitlines()] == [76, 38]
+    out = rec([1.0 / 3.0] * 6)                     # 6 x 18 characters (" .3333333333333333"): the fifth item starts a new record
+    assert [len(ln) for ln in out.splitlines()] == [72, 36]
