@@ -308,9 +308,8 @@ int ort_set_precision(ort_ctx *ctx, int precision);
  * whose third draw already puts them outside the first aperture are counted without being emitted
  * (queued surface-program kernels); bit 4 set = scattering bottles run the monolithic kernel (the random walk
  * compiled into the surface walk), clear (default) = the scattering pipeline (walk stages on full wavefronts in
- * front of the lean walk); bit 5 set = the fp32 surface programs trace two rays per lane with packed fp32
- * arithmetic (measured slower on gfx950: csrc/ort_pair.h), clear (default) = one ray per lane.  All
- * combinations of bits 0-5 produce bit-identical rays, images and counters.
+ * front of the lean walk); bit 5: unused (round 3's two-rays-per-lane fp32 kernel, measured slower and removed:
+ * HISTORY.md).  All combinations of bits 0-4 produce bit-identical rays, images and counters.
  * Bit 6 set = STRICT LIBM EMITTERS (exact fp64 only): the light sources evaluate sin / cos through glibc 2.35's own
  * algorithms (csrc/ort_libm.h), entry by entry as the reference's compiled code calls them, so an emitted ray — and with it
  * every ray state, image and counter — equals the CPU checker's bit for bit; the surface-program kernels

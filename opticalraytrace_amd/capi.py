@@ -138,7 +138,7 @@ def library_path() -> str:
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libort_hip.so")
 
 
-KERNEL_SOURCES = ("ort_hip.hip", "ort_device.h", "ort_fastd.h", "ort_pair.h", "ort_libm.h", "ort_libm_tables.h", os.path.join("..", "..", "include", "ort.h"))
+KERNEL_SOURCES = ("ort_hip.hip", "ort_device.h", "ort_fastd.h", "ort_libm.h", "ort_libm_tables.h", os.path.join("..", "..", "include", "ort.h"))
 
 
 def source_build_id() -> str:

@@ -25,14 +25,6 @@
 #include "ort_fastd.h"
 #include "ort_libm.h"
 
-// ORT_DIET (development, A/B builds): mask of the round-3 optimisations compiled in (see OPT_* below); the build
-// uses all of them.  Bit 6: instruction selection by hand (inline asm) in neg_unless / neg_if / vnormalise_est.
-// Bit 7: the late items (OPT_AXIAL_START, the literal zero of a cylinder normal, wave_any_live, unconditional queue loads).
-#ifndef ORT_DIET
-#define ORT_DIET 0xff
-#endif
-#define ORT_DIET_ASM ((ORT_DIET & 64) != 0)
-#define ORT_DIET_LATE ((ORT_DIET & 128) != 0)
 
 namespace ort {
 
@@ -93,7 +85,7 @@ __device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) 
 // otherwise re-derives the test from the selects that produced st (one compare + mask logic per select)
 __device__ inline bool wave_any_live(int &st)
 {
-    if (ORT_DIET_LATE) asm("" : "+v"(st));
+    asm("" : "+v"(st));
     return __builtin_amdgcn_ballot_w64(st < 0) != 0ull;
 }
 
@@ -149,11 +141,7 @@ struct KeyedDraws {
     }
     __device__ inline uint32_t word() const
     {
-#ifdef ORT_ABL_NORNG
-        return 0xBAE147AEu;
-#else
         return draw_word(mix64(base + kGolden * ((c >> 1) + 1ull)), (c & 1ull) != 0);
-#endif
     }
     __device__ inline double peek() const { return bits_to_unit(word()); }
     __device__ inline void advance(bool cnd) { c += cnd ? 1ull : 0ull; }
@@ -213,12 +201,8 @@ struct ProgDraws {
     }
     template <class T, int K, bool FRESH> __device__ inline T at()
     {
-#ifdef ORT_ABL_NORNG
-        return T(0.73);
-#else
         if constexpr ((K & 1) == 0 || FRESH) h = mix64(zray + kGolden * (uint64_t)(K / 2 + 1));
         return unit_from<T>(draw_word(h, (K & 1) != 0));
-#endif
     }
     template <class T> __device__ inline T next_as()
     {
@@ -243,15 +227,9 @@ struct ProgDraws {
 //           (the reference is fp64 only, src/Makefile:2): hardware reciprocal + one correction step
 //           and hardware square root, each within ~1 ulp (fp32) — a third of the instructions of
 //           the correctly rounded fp32 expansions, which made the fp32 path slower than fp64
-// Development-only ablation switches (ORT_ABL_*) BREAK the numerics contract and exist to price
-// the IEEE expansions.  Never defined in the build.
 __device__ inline double div_t(double a, double b)
 {
-#ifdef ORT_ABL_FASTDIV
-    return a * __builtin_amdgcn_rcp(b);
-#else
     return a / b;
-#endif
 }
 __device__ inline fastd div_t(fastd a, fastd b) { return a / b; }
 __device__ inline float div_t(float a, float b)
@@ -262,11 +240,7 @@ __device__ inline float div_t(float a, float b)
 }
 __device__ inline double sqrt_t(double x)
 {
-#ifdef ORT_ABL_FASTSQRT
-    return __builtin_amdgcn_sqrt(x);
-#else
     return sqrt(x);
-#endif
 }
 __device__ inline fastd sqrt_t(fastd x) { return sqrt(x); }
 __device__ inline float sqrt_t(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -284,11 +258,7 @@ __device__ unsigned long long ort_dbg_rare[16];
 #define ORT_RARE(site, cond) do { rare = rare | (bool)(cond); } while (0)
 #endif
 // "does any lane need the literal formula": the guard of every rare path
-#ifdef ORT_ABL_NOFALLBACK
-__device__ inline bool wave_rare(bool) { return false; }
-#else
 __device__ inline bool wave_rare(bool p) { return wave_any(p); }
-#endif
 
 // sqrt(x) at the hot sites.  FILT (fp64): the compiler's own fp64 square-root expansion —
 // v_rsq_f64 seed, one coupled Goldschmidt step, two residual corrections — WITHOUT its input
@@ -299,7 +269,6 @@ __device__ inline bool wave_rare(bool p) { return wave_any(p); }
 template <bool FILT, class T>
 __device__ inline T sqrt_f(T x, bool need, bool &rare)
 {
-#if !defined(ORT_ABL_FASTSQRT)
     if constexpr (FILT && std::is_same<T, double>::value) {
         const double y = __builtin_amdgcn_rsq(x);
         double g = x * y;
@@ -315,7 +284,6 @@ __device__ inline T sqrt_f(T x, bool need, bool &rare)
         ORT_RARE(0, need & !plain);
         return g;
     }
-#endif
     return ORT_SQRT(x);
 }
 
@@ -376,9 +344,6 @@ __device__ inline VecT<fastd> div3(VecT<fastd> v, fastd t)
 }
 __device__ inline Vec div3(Vec v, double t)
 {
-#if defined(ORT_ABL_FASTDIV)
-    return {ORT_DIV(v.x, t), ORT_DIV(v.y, t), ORT_DIV(v.z, t)};
-#else
     bool shared;
     Vec q = div3_shared(v, t, shared);
     if (wave_any(!shared)) {
@@ -387,7 +352,6 @@ __device__ inline Vec div3(Vec v, double t)
         q.z = shared ? q.z : v.z / t;
     }
     return q;
-#endif
 }
 
 // magnitude_fn (:175-186): NORMALISES, by three divisions
@@ -420,7 +384,6 @@ template <> __device__ inline VecT<fastd> vnormalise<fastd>(VecT<fastd> a)
 template <bool FILT, class T>
 __device__ inline VecT<T> div3_f(VecT<T> a, T t, bool need, bool &rare, bool x_zero = false)
 {
-#if !defined(ORT_ABL_FASTDIV)
     if constexpr (FILT && std::is_same<T, double>::value) {
         double r = __builtin_amdgcn_rcp(t);
         double e = __builtin_fma(-t, r, 1.0);
@@ -436,7 +399,6 @@ __device__ inline VecT<T> div3_f(VecT<T> a, T t, bool need, bool &rare, bool x_z
         ORT_RARE(1, need & odd);
         return q;
     }
-#endif
     return div3(a, t);
 }
 
@@ -475,7 +437,6 @@ __device__ inline VecT<T> vnormalise_est(VecT<T> a, T t0, T h0, T k0, T s_tol, b
     if constexpr (FILT && std::is_same<T, double>::value) {
         const double s = a.x * a.x + a.y * a.y + a.z * a.z;
         const double e = __builtin_fma(-t0, t0, s);
-#if (ORT_DIET_ASM)
         // t0, h0, k0 are wave-uniform (SGPR pairs) and a vector instruction reads at most ONE scalar operand: left to
         // itself the compiler copies two of them into VGPRs (two v_mov_b64 per call).  h0 is the one both need.
         double vh0, g1, h1;
@@ -487,10 +448,6 @@ __device__ inline VecT<T> vnormalise_est(VecT<T> a, T t0, T h0, T k0, T s_tol, b
             asm("v_fma_f64 %0, %1, %2, %3" : "=v"(g1) : "v"(e), "v"(vh0), "s"(t0));
             asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(h1) : "v"(e), "s"(k0), "v"(vh0));
         }
-#else
-        const double g1 = __builtin_fma(e, h0, t0);
-        const double h1 = __builtin_fma(-e, k0, h0);
-#endif
         const double d = __builtin_fma(-g1, g1, s);
         const double t = __builtin_fma(d, h1, g1);
         const double y = h1 + h1;
@@ -503,7 +460,7 @@ __device__ inline VecT<T> vnormalise_est(VecT<T> a, T t0, T h0, T k0, T s_tol, b
         q.z = __builtin_fma(__builtin_fma(-t, mz, a.z), r, mz);
         // the x of a cylinder normal (a literal +0, known at compile time in a program kernel): 0 r = +0, fma(-t, +0, +0) =
         // +0, fma(+0, r, +0) = +0 for every finite r > 0 — and a lane whose r is anything else fails the test on e below
-        if (ORT_DIET_LATE && __builtin_constant_p(x_zero) && x_zero) q.x = 0.0;
+        if (__builtin_constant_p(x_zero) && x_zero) q.x = 0.0;
         const bool odd = (!x_zero & !(fabs(a.x) > 0x1p-300)) | !(fabs(a.y) > 0x1p-300) | !(fabs(a.z) > 0x1p-300);
         ORT_RARE(1, need & (odd | !(fabs(e) < s_tol)));
         return q;
@@ -541,12 +498,7 @@ using Ray = RayT<double>;
 //                  (a cylinder: the bottle): pos - centre and c = L.L - radius**2 are the system's (axial_start), not the ray's
 //   OPT_ON_AXIS    the surface's centre has cx = cy = +0.0 exactly (host: match_program): pos.x - cx and
 //                  pos.y - cy are pos.x and pos.y, bit for bit (x - (+0) = x for every x, -0 included).
-// ORT_DIET (top of this file): mask of these optimisations compiled in; the build uses all of them.
-constexpr int OPT_UNIT_DIR = (ORT_DIET & 1) ? 1 : 0, OPT_ON_AXIS = (ORT_DIET & 2) ? 2 : 0, OPT_AXIAL_START = (ORT_DIET & 128) ? 4 : 0;
-constexpr bool kDietLate = ORT_DIET_LATE;                      // axial start, the zero of a cylinder normal, wave_any_live, queue loads
-constexpr bool kDietStatusCarriesStep = (ORT_DIET & 4) != 0;   // program kernels: see surface_step NISK
-constexpr bool kDietDiesOnReflect = (ORT_DIET & 8) != 0;       // reflect_refract DIES
-constexpr bool kDietApertureBounds = (ORT_DIET & 16) != 0;     // outside_aperture on precomputed bounds
+constexpr int OPT_UNIT_DIR = 1, OPT_ON_AXIS = 2, OPT_AXIAL_START = 4;
 
 // ----------------------------------------------------------------------------
 // Filtered predicates (FILT = true, the production setting).
@@ -597,28 +549,20 @@ __device__ inline fastd rsq_approx(fastd s) { return fastd(rsq_approx(s.v)); }
 // dword of a double): one v_cndmask.  Pure bit manipulation: the same value as the plain expression, NaNs included.
 __device__ inline double neg_unless(double x, bool keep)
 {
-#if (ORT_DIET_ASM)
     const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
     const int hi = __double2hiint(x);
     int out;
     asm("v_cndmask_b32_e64 %0, -%1, %1, %2" : "=v"(out) : "v"(hi), "s"(m));
     return __hiloint2double(out, __double2loint(x));
-#else
-    return keep ? x : -x;
-#endif
 }
 // flip ? -x : x
 __device__ inline double neg_if(double x, bool flip)
 {
-#if (ORT_DIET_ASM)
     const unsigned long long m = __builtin_amdgcn_ballot_w64(flip);
     const int hi = __double2hiint(x);
     int out;
     asm("v_cndmask_b32_e64 %0, %1, -%1, %2" : "=v"(out) : "v"(hi), "s"(m));
     return __hiloint2double(out, __double2loint(x));
-#else
-    return flip ? -x : x;
-#endif
 }
 __device__ inline float neg_if(float x, bool flip) { return flip ? -x : x; }
 __device__ inline fastd neg_if(fastd x, bool flip) { return fastd(neg_if(x.v, flip)); }
@@ -745,12 +689,8 @@ __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit
         const bool a_ok = UNIT ? true : ((a > T(0x1p-100)) & (a < T(0x1p100)));
         const bool common = (fabs(D) > T(1e-10) * hh) & (fabs(D) < T(0x1p900)) & a_ok & (fabs(c) > T(0x1p-300));
         const bool ok = common & (neg | ((fabs(q) > T(0x1p-300)) & (fabs(q) < T(0x1p300))));
-#if defined(ORT_ABL_FASTDIV)
-        t = ORT_DIV(num, den);
-#else
         if constexpr (std::is_same<T, double>::value) t = div_plain(num, den);
         else t = ORT_DIV(num, den);
-#endif
         hit = (qpos || cneg) && nneg;
         ORT_RARE(2, live & !ok);                     // tangent, degenerate, on the surface, out of range, or NaN
     } else {
@@ -864,20 +804,13 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
         // `sint2 > 1` (:353) holds whatever its rounding and it returns 1: u <= 1 reflects.
         // (diff is NaN there and is not consulted.)  NaN anywhere else -> undecided; c1 >= 1 and
         // k within 1e-6 of zero -> literal path.
-        if constexpr ((ORT_DIET & 32) != 0) {
-            // The same decisions in four compares instead of five.  With c1 < 1 and |k| > 1e-6: k > 0 makes c2,
-            // P, rhs and diff finite numbers; k < 0 makes c2 = sqrt(k) NaN and with it diff.  So "diff is NaN"
-            // IS total reflection there, and the two tests on diff are written so that a NaN takes the
-            // reflecting side: decided unless |diff| <= margin (unordered: decided), reflected unless diff >= 0.
-            const bool decided = (c1 < T(1.0)) & (fabs(k) > T(1e-6)) & !(fabs(diff) <= T(1e-10) * P);
-            reflected = !(diff >= T(0.0));
-            ORT_RARE(3, live & !decided);
-        } else {
-        const bool tir = k < T(-1e-6);
-        const bool decided = (c1 < T(1.0)) & (tir | ((k > T(1e-6)) & (fabs(diff) > T(1e-10) * P)));
-        reflected = tir | (diff < T(0.0));
+        // The same decisions in four compares instead of five.  With c1 < 1 and |k| > 1e-6: k > 0 makes c2,
+        // P, rhs and diff finite numbers; k < 0 makes c2 = sqrt(k) NaN and with it diff.  So "diff is NaN"
+        // IS total reflection there, and the two tests on diff are written so that a NaN takes the
+        // reflecting side: decided unless |diff| <= margin (unordered: decided), reflected unless diff >= 0.
+        const bool decided = (c1 < T(1.0)) & (fabs(k) > T(1e-6)) & !(fabs(diff) <= T(1e-10) * P);
+        reflected = !(diff >= T(0.0));
         ORT_RARE(3, live & !decided);
-        }
     } else {
         reflected = u <= fresnel(c1, n1, n2, eta);       // :275
     }
@@ -900,15 +833,11 @@ __device__ inline bool outside_aperture(T x, T y, T A, T A2, T A2tol, T A2lo, T 
 {
     const T s2 = x * x + y * y;
     if constexpr (FILT) {                               // A2 = A*A, A2tol = 1e-12 A2 (SurfAuxT)
-        if constexpr (kDietApertureBounds) {
-            // the same margin as two bounds formed once per surface: A2lo = A2 - A2tol, A2hi = A2 + A2tol
-            // (SurfAuxT); inside [A2lo, A2hi], or NaN: the reference's square root decides
-            const bool out = s2 > A2hi;
-            ORT_RARE(4, live & !out & !(s2 < A2lo));
-            return out;
-        }
-        ORT_RARE(4, live & !(fabs(s2 - A2) > A2tol));
-        return s2 > A2;
+        // the same margin as two bounds formed once per surface: A2lo = A2 - A2tol, A2hi = A2 + A2tol
+        // (SurfAuxT); inside [A2lo, A2hi], or NaN: the reference's square root decides
+        const bool out = s2 > A2hi;
+        ORT_RARE(4, live & !out & !(s2 < A2lo));
+        return out;
     } else {
         return ORT_SQRT(s2) > A;
     }
@@ -1583,7 +1512,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
                                     int &nis, int &st, int &xp, int &yp, bool &rare)
 {
     constexpr int tag = (NISK >= 0 ? NISK : 0) << 8;
-    constexpr bool DIES = kDietDiesOnReflect && !KEEP && FLAGS >= 0 && (FLAGS & ORT_F_SKIP_ON_REFLECT) != 0;
+    constexpr bool DIES = !KEEP && FLAGS >= 0 && (FLAGS & ORT_F_SKIP_ON_REFLECT) != 0;
     static_assert(PART == 0 || (!EXT && !KEEP && KIND >= 0 && KIND != ORT_SURF_IMAGE && KIND != ORT_SURF_IRIS),
                   "half steps exist for the refracting steps of the surface programs");
     const bool live = st < 0;

@@ -41,7 +41,6 @@
 #include <rccl/rccl.h>       // types and enums only: the library is resolved at run time (ort_allreduce)
 #include "../../include/ort.h"
 #include "ort_device.h"
-#include "ort_pair.h"
 
 using namespace ort;
 
@@ -242,9 +241,6 @@ __global__ __launch_bounds__(256) void fold_kernel(int32_t *image, int32_t *repl
     }
 }
 
-#ifdef ORT_ABL_NOREDO
-namespace ort { __device__ unsigned long long abl_sink; }
-#endif
 // One lockstep pass of a wave over surfaces [k0, k1): every lane steps with its `st`
 // predicate; the loop leaves as soon as no lane of the wave is alive (uniform branch).
 // KEEP: see surface_step — false where only st/xp/yp/nis of an ended ray are read afterwards.
@@ -463,10 +459,10 @@ template <int P> constexpr int draw_index(int K)
 // steps [K, K1) of program P, each entered only while some lane of the wave is alive.  FRESH: no
 // hash is at hand for the next odd draw (the walk starts behind the queue)
 // OPT: what every step may assume (ort_device.h OPT_*); a step's status carries its intersection count
-// (surface_step NISK) when kDietStatusCarriesStep
+// (surface_step NISK)
 // (OPT_COUNT_STEPS: the rays did not start at step 0 with a count of 0 — they are counted per step and lane)
 constexpr int OPT_COUNT_STEPS = 8;
-template <int K, int OPT = 0> constexpr int nisk() { return kDietStatusCarriesStep && !(OPT & OPT_COUNT_STEPS) ? K + 1 : -1; }
+template <int K, int OPT = 0> constexpr int nisk() { return !(OPT & OPT_COUNT_STEPS) ? K + 1 : -1; }
 
 template <bool FILT, class T, bool KEEP, int P, int K, int K1, bool FRESH, int OPT, class Sys, class D>
 __device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t surf, typename ConstPtrs<T>::aux_t aux, RayT<T> &r, D &draws,
@@ -537,12 +533,7 @@ __device__ inline void walk(const Sys &S, const Surf *surf, const SurfAuxT<T> *a
     } else {
         const int nis0 = nis, xp0 = xp, yp0 = yp;
         walk_pass<true, T, EXT, KEEP>(S, surf, aux, k0, k1, r, draws, nis, st, xp, yp, rare);
-#ifdef ORT_ABL_NOREDO
-        if (wave_rare(rare)) { if (rare) atomicAdd(&ort::abl_sink, 1ull); }
-        if (false) {
-#else
         if (wave_rare(rare)) {
-#endif
             RayT<T> r2;
             D d2 = draws;
             int st2, nis2 = nis0, xp2 = xp0, yp2 = yp0;
@@ -822,7 +813,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     constexpr bool axial = MODE == MODE_FUSED && prog_starts_on_axis<PROG>() && FILT && std::is_same<T, double>::value;
     constexpr int OPT = fixed ? ((MODE == MODE_FUSED ? OPT_UNIT_DIR : 0) | OPT_ON_AXIS | (axial ? OPT_AXIAL_START : 0) |
                                  (MODE == MODE_CONTINUE ? OPT_COUNT_STEPS : 0)) : 0;
-    constexpr bool tagged = fixed && kDietStatusCarriesStep && MODE != MODE_CONTINUE;     // st = ORT_ST_* | intersections << 8
+    constexpr bool tagged = fixed && MODE != MODE_CONTINUE;     // st = ORT_ST_* | intersections << 8
     unsigned int lost = 0, isect = 0, binned = 0, help3 = 0, culled = 0;
     auto finish = [&](int st_in, int nis_in, int xp, int yp) {
         const int st = tagged ? status_code(st_in) : st_in;
@@ -830,9 +821,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
         isect += (unsigned)nis;
         if (st == ORT_ST_BINNED) {
             binned++;
-#ifndef ORT_ABL_NOATOMIC
             bin_hit(layer, xp, yp, a.replicas != nullptr);
-#endif
         } else if (st >= ORT_ST_LOST_BOTTLE) {
             lost++;                                                          // optics_system.f90:32,42; main.f90:151
             if (st == ORT_ST_HELP3) help3++;
@@ -865,7 +854,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             DrawsT d;
             QD dw = 0;                                   // the queued image of the draw state
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
-            if (act || kDietLate) {
+            {
                 r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
                 r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
                 dw = qd[slot];
@@ -1014,191 +1003,6 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     if (PRE && threadIdx.x == 4 && blk[4]) atomicAdd(&a.work[ORT_W_CULLED], (unsigned long long)blk[4]);
 }
 
-
-// ---------------------------------------------------------------------------
-// trace_pair_kernel<PROG> (opt-in, kernel variant bit 5; NOT the default: it is slower, ort_pair.h says why): the
-// fused surface programs in fp32 with TWO RAYS PER LANE: a wavefront carries 128 rays, every add / mul / fma of
-// the walk is a packed instruction serving both rays of a lane.  The
-// structure is trace_queue_kernel's — contiguous ray ranges per wave, segment 0 (ring cull), segment 1, wave-private
-// LDS queue, segment 2 on full wavefronts — with batches of 128; per-ray arithmetic, draws and outcomes are those
-// of the one-ray fp32 kernels, bit for bit.
-// ---------------------------------------------------------------------------
-constexpr int kPairQueueCap = 256;  // >= 127 leftover + 128 new survivors
-
-template <int P, int K, int K1, bool FRESH, class Sys>
-__device__ inline void pair_walk(const Sys &S, ConstPtrs<float>::surf_t surf, pk::pray &r, pk::PairDraws &d, pk::pi &st,
-                                 pk::pi &xp, pk::pi &yp)
-{
-    if constexpr (K < K1) {
-        if (pk::any_lane(pk::live_of(st))) {
-            const SurfaceT<float> s = load_surface<float>(surf + K);
-            constexpr bool draws_here = Prog<P>::kind[K] != ORT_SURF_IRIS && Prog<P>::kind[K] != ORT_SURF_IMAGE;
-            constexpr bool axis = OPT_ON_AXIS != 0;
-            if constexpr (draws_here && Prog<P>::ap[K] != 0) {
-                pk::surface_step<Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 1, K + 1, axis>(S, s, r, d, st, xp, yp);
-                if (pk::any_lane(pk::live_of(st)))
-                    pk::surface_step<Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 2, K + 1, axis>(S, s, r, d, st, xp, yp);
-            } else {
-                pk::surface_step<Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 0, K + 1, axis>(S, s, r, d, st, xp, yp);
-            }
-            pair_walk<P, K + 1, K1, FRESH && !draws_here>(S, surf, r, d, st, xp, yp);
-        }
-    }
-}
-
-template <int P, int K, int PART, class Sys>
-__device__ inline void pair_step_part(const Sys &S, ConstPtrs<float>::surf_t surf, pk::pray &r, pk::PairDraws &d, pk::pi &st,
-                                      pk::pi &xp, pk::pi &yp)
-{
-    if (pk::any_lane(pk::live_of(st))) {
-        const SurfaceT<float> s = load_surface<float>(surf + K);
-        pk::surface_step<Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), PART == 2, PART, K + 1, OPT_ON_AXIS != 0>(
-            S, s, r, d, st, xp, yp);
-    }
-}
-
-template <int PROG>
-__global__ __launch_bounds__(kBlock, 4) void trace_pair_kernel(TraceArgs a)
-{
-    static_assert(PROG != PROG_GENERIC && prog_static_draws<PROG>(), "surface programs with compile-time draw indices only");
-    __shared__ float Q[kWavesPerBlock][kQueueFields][kPairQueueCap];
-    __shared__ uint32_t QI[kWavesPerBlock][kPairQueueCap];
-    constexpr bool PRE = prog_culls<PROG>();
-    __shared__ uint32_t CQ[kWavesPerBlock][PRE ? kPairQueueCap : 1];
-    __shared__ unsigned int blk[5];
-    if (threadIdx.x < 5) blk[threadIdx.x] = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float (*q)[kPairQueueCap] = Q[wave];
-    uint32_t *qi = QI[wave], *cq = CQ[wave];
-    constexpr int phase = Prog<PROG>::phase, qstep = queue_step<PROG, MODE_FUSED>();
-    const ConstPtrs<float>::sys_t csys = (ConstPtrs<float>::sys_t)a.sysf;
-    const ConstPtrs<float>::surf_t csurf = (ConstPtrs<float>::surf_t)a.sysf->surfaces[phase - 1];
-    int32_t *layer = hist_layer(a);
-    const uint64_t n = a.n_rays;
-    const bool head = blockIdx.x < a.head_blocks;
-    const uint64_t wid = (uint64_t)(head ? blockIdx.x : blockIdx.x - a.head_blocks) * kWavesPerBlock + wave;
-    const uint64_t chunk = head ? a.head_chunk : a.tail_chunk;
-    const uint64_t end = head ? a.head_rays : n;
-    uint64_t lo = (head ? 0 : a.head_rays) + wid * chunk; if (lo > end) lo = end;
-    uint64_t hi = lo + chunk;  if (hi > end) hi = end;
-
-    unsigned int lost = 0, isect = 0, binned = 0, help3 = 0, culled = 0;
-    auto finish = [&](bool act, int st_in, int xp, int yp) {
-        if (!act) return;
-        const int st = status_code(st_in);
-        isect += (unsigned)status_isect(st_in);
-        if (st == ORT_ST_BINNED) {
-            binned++;
-            bin_hit(layer, xp, yp, a.replicas != nullptr);
-        } else if (st >= ORT_ST_LOST_BOTTLE) {
-            lost++;
-            if (st == ORT_ST_HELP3) help3++;
-        }
-    };
-    uint64_t next = lo;
-    int qcount = 0, qhead = 0, ccount = 0, chead = 0;
-    const uint64_t z0 = zray_of(a.rng_base, a.first_ray);
-    for (;;) {
-        const bool have_new = next < hi;
-        const bool cand_ready = PRE && (ccount >= 128 || (!have_new && ccount > 0));
-        if (qcount >= 128 || (!have_new && !cand_ready && qcount > 0)) {
-            // ---- segment 2 on up to 128 queued rays
-            const int m = qcount < 128 ? qcount : 128;
-            const pk::pb act = {lane < m, lane + 64 < m};
-            const int sa = (qhead + lane) & (kPairQueueCap - 1), sb = (qhead + 64 + lane) & (kPairQueueCap - 1);
-            qhead = (qhead + m) & (kPairQueueCap - 1);
-            qcount -= m;
-            // (idle lanes read no slot: they carry a harmless ray along the axis)
-            float fa0 = 0.f, fa1 = 0.f, fa2 = 0.f, fa3 = 0.f, fa4 = 0.f, fa5 = 1.f, fb0 = 0.f, fb1 = 0.f, fb2 = 0.f, fb3 = 0.f, fb4 = 0.f, fb5 = 1.f;
-            uint32_t ia = 0, ib = 0;
-            if (act.a) { fa0 = q[0][sa]; fa1 = q[1][sa]; fa2 = q[2][sa]; fa3 = q[3][sa]; fa4 = q[4][sa]; fa5 = q[5][sa]; ia = qi[sa]; }
-            if (act.b) { fb0 = q[0][sb]; fb1 = q[1][sb]; fb2 = q[2][sb]; fb3 = q[3][sb]; fb4 = q[4][sb]; fb5 = q[5][sb]; ib = qi[sb]; }
-            pk::pray r = {{pk::pf(fa0, fb0), pk::pf(fa1, fb1), pk::pf(fa2, fb2)}, {pk::pf(fa3, fb3), pk::pf(fa4, fb4), pk::pf(fa5, fb5)}};
-            pk::PairDraws d;
-            d.init_index(z0, ia, ib);
-            pk::pi st = {act.a ? -1 : ORT_ST_NA_REJECT, act.b ? -1 : ORT_ST_NA_REJECT}, xp = {0, 0}, yp = {0, 0};
-            pair_step_part<PROG, qstep - 1, 2>(*csys, csurf, r, d, st, xp, yp);
-            pair_walk<PROG, qstep, Prog<PROG>::n, false>(*csys, csurf, r, d, st, xp, yp);
-            finish(act.a, st.a, xp.a, yp.a);
-            finish(act.b, st.b, xp.b, yp.b);
-            __builtin_amdgcn_wave_barrier();
-        } else if (cand_ready || (!PRE && have_new)) {
-            // ---- segment 1 on up to 128 rays (ring programs: rays that passed segment 0)
-            uint64_t ia, ib;
-            pk::pb act;
-            if constexpr (PRE) {
-                const int m = ccount < 128 ? ccount : 128;
-                act = {lane < m, lane + 64 < m};
-                ia = act.a ? (uint64_t)cq[(chead + lane) & (kPairQueueCap - 1)] : lo;
-                ib = act.b ? (uint64_t)cq[(chead + 64 + lane) & (kPairQueueCap - 1)] : lo;
-                chead = (chead + m) & (kPairQueueCap - 1);
-                ccount -= m;
-            } else {
-                ia = next + (uint64_t)lane; ib = next + 64ull + (uint64_t)lane;
-                act = {ia < hi, ib < hi};
-                next += 128;
-                ia = act.a ? ia : hi - 1; ib = act.b ? ib : hi - 1;
-            }
-            pk::pray r;
-            pk::PairDraws d;
-            d.init_index(z0, (uint32_t)ia, (uint32_t)ib);
-            if constexpr (Prog<PROG>::emitter == ORT_EMIT_RING) pk::emit_ring(*csys, r, d);
-            else pk::emit_point(*csys, r, d);
-            pk::pi st = {act.a ? -1 : ORT_ST_NA_REJECT, act.b ? -1 : ORT_ST_NA_REJECT}, xp = {0, 0}, yp = {0, 0};
-            pair_walk<PROG, 0, qstep - 1, false>(*csys, csurf, r, d, st, xp, yp);
-            pair_step_part<PROG, qstep - 1, 1>(*csys, csurf, r, d, st, xp, yp);
-            const pk::pb survive = {act.a && st.a < 0, act.b && st.b < 0};
-            const unsigned long long ma = __builtin_amdgcn_ballot_w64(survive.a), mb = __builtin_amdgcn_ballot_w64(survive.b);
-            if (survive.a) {
-                const int slot = (qhead + qcount + lane_prefix(ma)) & (kPairQueueCap - 1);
-                q[0][slot] = r.pos.x.v.x; q[1][slot] = r.pos.y.v.x; q[2][slot] = r.pos.z.v.x;
-                q[3][slot] = r.dir.x.v.x; q[4][slot] = r.dir.y.v.x; q[5][slot] = r.dir.z.v.x;
-                qi[slot] = (uint32_t)ia;
-            } else finish(act.a, st.a, xp.a, yp.a);
-            qcount += __popcll(ma);
-            if (survive.b) {
-                const int slot = (qhead + qcount + lane_prefix(mb)) & (kPairQueueCap - 1);
-                q[0][slot] = r.pos.x.v.y; q[1][slot] = r.pos.y.v.y; q[2][slot] = r.pos.z.v.y;
-                q[3][slot] = r.dir.x.v.y; q[4][slot] = r.dir.y.v.y; q[5][slot] = r.dir.z.v.y;
-                qi[slot] = (uint32_t)ib;
-            } else finish(act.b, st.b, xp.b, yp.b);
-            qcount += __popcll(mb);
-            __builtin_amdgcn_wave_barrier();
-        } else if (PRE && have_new) {
-            // ---- segment 0 (ring programs) on 128 fresh ray indices: see trace_queue_kernel
-            if constexpr (PRE) {
-                auto half = [&](uint64_t i) {
-                    const bool act = i < hi;
-                    const uint64_t ic = act ? i : hi - 1;
-                    ProgDraws d;
-                    d.init_index(z0, (uint32_t)ic, 0);
-                    const float u3 = d.template at<float, 2, true>();
-                    const float rr = 0.f + u3 * (csys->ring_lens_r2 - 0.f);
-                    const bool cand = act && !(rr > a.cullf);
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
-                    if (cand) cq[(chead + ccount + lane_prefix(mask)) & (kPairQueueCap - 1)] = (uint32_t)i;
-                    else if (act) { finish(true, ORT_ST_LOST_TELESCOPE | (1 << 8), 0, 0); culled++; }
-                    ccount += __popcll(mask);
-                };
-                half(next + (uint64_t)lane);
-                half(next + 64ull + (uint64_t)lane);
-                next += 128;
-            }
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            break;
-        }
-    }
-    atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect);
-    atomicAdd(&blk[2], binned); atomicAdd(&blk[3], help3);
-    if constexpr (PRE) atomicAdd(&blk[4], culled);
-    __syncthreads();
-    if (threadIdx.x < 4 && blk[threadIdx.x])
-        atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
-    if (PRE && threadIdx.x == 4 && blk[4]) atomicAdd(&a.work[ORT_W_CULLED], (unsigned long long)blk[4]);
-}
 
 // ---------------------------------------------------------------------------
 // In-bottle scattering (src/lens.f90:262-282, :312-333, src/surfaces.f90:13-50,
@@ -1888,17 +1692,6 @@ static void launch_lean(ort_ctx *c, int mode, const TraceArgs &a, int grid)
     int prog = c->prog[a.phase - 1];
     if (mode != MODE_FUSED && a.draw_base != (a.phase == 1 ? 4 : 2)) prog = PROG_GENERIC;
     if (a.strict) prog = PROG_GENERIC;                   // strict libm emitters live in the generic kernels (variant bit 6)
-    if constexpr (std::is_same<T, float>::value) {
-        // variant bit 5: fp32, fused, a surface program with two rays per lane (ort_pair.h) — measured SLOWER than one
-        // ray per lane on gfx950 (0.226 vs 0.217 ms per 1e7 point rays), see ort_pair.h: kept as the A/B that shows it
-        if (mode == MODE_FUSED && prog != PROG_GENERIC && (c->variant & 32) != 0) {
-            switch (prog) {
-#define ORT_PAIR(P) case P: ORT_LAUNCH((trace_pair_kernel<P>)); return;
-                ORT_PROGRAMS(ORT_PAIR)
-#undef ORT_PAIR
-            }
-        }
-    }
 #define ORT_CASE(P)                                                                                        \
     case P:                                                                                                \
         if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, FILT, false, T, P>));           \

@@ -96,36 +96,33 @@ def test_fp32_image_deviation(ctx):
 @pytest.mark.parametrize("name", ["large", "large_iris_before", "small_iris_after", "ellipse",
                                   "small_f60_nobottle", "large_crs"])
 def test_fp32_queued_kernel_equals_fp32_lockstep_kernel(hip_library, name):
-    """fp32 runs on the queued program kernels (variant bit 0, default) exactly as fp64 does; variant bit 5 selects
-    the two-rays-per-lane kernels (csrc/ort_pair.h: packed fp32 arithmetic).  Per-ray arithmetic and draw order
-    are those of the fp32 lockstep kernel in all of them, so images and counters are identical — for every
-    surface program and for a system that takes the generic walk."""
+    """fp32 runs on the queued program kernels (variant bit 0, default) exactly as fp64 does.  Per-ray arithmetic and
+    draw order are those of the fp32 lockstep kernel, so images and counters are identical — for every surface program
+    and for a system that takes the generic walk."""
     from opticalraytrace_amd.capi import Context
     _, osys = make_system(name)
     n = 300_000
     with Context(osys) as c:
         c.set_precision(1)
         out = []
-        for variant in (1, 0, 9, 33, 41):    # queued; lockstep; queued without the ring cull; two rays per lane; ... without the cull
+        for variant in (1, 0, 9):    # queued; lockstep; queued without the ring cull
             c.set_kernel_variant(variant)
             c.reset()
             c.trace(1, 0, n, SEED)
             c.trace(2, 5, n, SEED)
             out.append(c.read())
-        for m in (1, 63, 64, 65, 127, 128, 129, 191, 193, 4097):   # ragged sizes: partial batches of 128, queue flush at the tail
+        for m in (1, 63, 64, 65, 127, 128, 129, 191, 193, 4097):   # ragged sizes: partial batches, queue flush at the tail
             res = []
-            for variant in (1, 0, 33):
+            for variant in (1, 0):
                 c.set_kernel_variant(variant)
                 c.reset(); c.trace(1, 3, m, SEED); c.trace(2, 7, m, SEED)
                 res.append(c.read())
-            for v in (1, 2):
-                assert np.array_equal(res[0][0], res[v][0]) and np.array_equal(res[0][1], res[v][1]), (name, m, v)
+            assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), (name, m)
         c.set_kernel_variant(1)
     (iq, cq), (il, cl) = out[0], out[1]
     assert int(cq[2]) > n and int(cq[3]) > n
     assert np.array_equal(iq, il) and np.array_equal(cq, cl)
-    for k in (2, 3, 4):
-        assert np.array_equal(iq, out[k][0]) and np.array_equal(cq, out[k][1]), (name, k)
+    assert np.array_equal(iq, out[2][0]) and np.array_equal(cq, out[2][1]), name
 
 
 def test_config4_fp32_full_size(ctx):
