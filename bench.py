@@ -618,8 +618,9 @@ def main() -> int:
             "image_l1_vs_exact": int(abs(r.image.astype("int64") - res.image.astype("int64")).sum()),
             "image_l1_vs_exact_frac_of_binned": float(abs(r.image.astype("int64") - res.image.astype("int64")).sum()) / max(binned_total, 1),
             "binned": b32, "binned_exact": binned_total, "intersections": i32, "intersections_exact": isect_total,
-            "note": "ort_set_precision(1), BASELINE configs[4]: the same operations in single precision, literal "
-                    "predicates, uniforms = top 24 bits of the same draws; tests/test_gpu_fp32.py holds the tolerance study",
+            "note": "ort_set_precision(1), BASELINE configs[4]: the path in single precision — hardware rcp / sqrt / rsq, fused "
+                    "multiply-adds, the cheap decision forms without margins or deferrals; uniforms = top 24 bits of the same "
+                    "draws; tests/test_gpu_fp32.py holds the tolerance study",
         }
     if "fast_fp64" in legs:
         el, kms, r, cul = legs["fast_fp64"]

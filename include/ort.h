@@ -293,8 +293,9 @@ int ort_set_timing(ort_ctx *ctx, int enable);
  * many steps without synchronising and read the per-launch times afterwards. */
 int ort_kernel_times(ort_ctx *ctx, float *ms, int capacity, int *count);
 /* Arithmetic of the traced path from now on: 0 (default) = fp64, the reference's arithmetic
- * (all `real` are fp64, src/Makefile:2), bit-exact; 1 = fp32 study path (BASELINE configs[4]):
- * the same operations in single precision, uniforms = top 24 bits of the same draws.  It has
+ * (all `real` are fp64, src/Makefile:2), bit-exact; 1 = fp32 path (BASELINE configs[4]): the same
+ * path in single precision, uniforms = top 24 bits of the same draws, without the exact path's corset
+ * (hardware reciprocal / square root, fused multiply-adds, the cheap decision forms without margins).  It has
  * no reference to be exact against; tests/test_gpu_fp32.py measures its deviation from fp64;
  * 2 = fast fp64 (csrc/ort_fastd.h): fused multiply-adds, Newton-refined reciprocal / rsqrt
  * instead of IEEE divide / sqrt — ~1e-13 relative from the exact path (inside the 1e-10 of the

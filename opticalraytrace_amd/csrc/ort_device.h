@@ -224,20 +224,17 @@ struct ProgDraws {
 //   double  the compiler's correctly rounded IEEE operations (the reference's arithmetic)
 //   fastd   ort_fastd.h (its own operator/ and sqrt)
 //   float   the fp32 path of BASELINE configs[4], which has no reference to be bit-exact against
-//           (the reference is fp64 only, src/Makefile:2): hardware reciprocal + one correction step
-//           and hardware square root, each within ~1 ulp (fp32) — a third of the instructions of
-//           the correctly rounded fp32 expansions, which made the fp32 path slower than fp64
+//           (the reference is fp64 only, src/Makefile:2) and therefore none of the exact path's corset:
+//           hardware reciprocal / square root / reciprocal square root as they come (~1 ulp fp32), fused
+//           multiply-adds wherever a product feeds a sum (mad, dot3, ...: -ffp-contract=off keeps the compiler
+//           from fusing the SHARED templates, so the float forms say it), the filtered decision forms without
+//           their margins or deferrals (kLoose).  tests/test_gpu_fp32.py holds its deviation from fp64.
 __device__ inline double div_t(double a, double b)
 {
     return a / b;
 }
 __device__ inline fastd div_t(fastd a, fastd b) { return a / b; }
-__device__ inline float div_t(float a, float b)
-{
-    const float r = __builtin_amdgcn_rcpf(b);
-    const float q = a * r;
-    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
-}
+__device__ inline float div_t(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }     // v_rcp_f32: 1 ulp
 __device__ inline double sqrt_t(double x)
 {
     return sqrt(x);
@@ -299,6 +296,31 @@ template <class T> __device__ inline VecT<T> vsub(VecT<T> a, VecT<T> b) { return
 template <class T> __device__ inline VecT<T> vadd(VecT<T> a, VecT<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 template <class T> __device__ inline VecT<T> vscale(VecT<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
 template <class T> __device__ inline T vdot(VecT<T> a, VecT<T> b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+// kLoose<T>: an arithmetic without a bit-exact contract (fp32): products are fused into the sums they feed, and a
+// lane inside a filtered predicate's margin is simply decided by the cheap form (no `rare`, no deferral).
+template <class T> constexpr bool kLoose = std::is_same<T, float>::value;
+// a * b + c, (a . b), b + a s, I alpha + N beta: separately rounded in the reference's order for the exact types, fused for fp32
+template <class T> __device__ inline T mad(T a, T b, T c)
+{
+    if constexpr (kLoose<T>) return __builtin_fmaf(a, b, c);
+    else return a * b + c;
+}
+template <class T> __device__ inline T dot3(T ax, T ay, T az, T bx, T by, T bz)
+{
+    if constexpr (kLoose<T>) return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
+    else return (ax * bx) + (ay * by) + (az * bz);
+}
+template <class T> __device__ inline VecT<T> vmad(VecT<T> a, T s, VecT<T> b)      // b + a s
+{
+    if constexpr (kLoose<T>) return {__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y), __builtin_fmaf(a.z, s, b.z)};
+    else return vadd(b, vscale(a, s));
+}
+template <class T> __device__ inline VecT<T> vlin2(VecT<T> a, T s, VecT<T> b, T t)      // a s + b t
+{
+    if constexpr (kLoose<T>) return {__builtin_fmaf(b.x, t, a.x * s), __builtin_fmaf(b.y, t, a.y * s), __builtin_fmaf(b.z, t, a.z * s)};
+    else return vadd(vscale(a, s), vscale(b, t));
+}
+template <> __device__ inline float vdot<float>(VecT<float> a, VecT<float> b) { return dot3(a.x, a.y, a.z, b.x, b.y, b.z); }
 template <class T> __device__ inline VecT<T> vselect(bool c, VecT<T> a, VecT<T> b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 
 // x/t, y/t, z/t — three IEEE-754 divisions by the same denominator — with the
@@ -336,7 +358,11 @@ __device__ inline Vec div3_shared(Vec v, double t, bool &shared)
 
 // the three quotients, self-contained (emitters): lanes where the shared form does not apply
 // divide plainly, behind a wave-uniform branch
-__device__ inline VecT<float> div3(VecT<float> v, float t) { return {div_t(v.x, t), div_t(v.y, t), div_t(v.z, t)}; }
+__device__ inline VecT<float> div3(VecT<float> v, float t)
+{
+    const float r = __builtin_amdgcn_rcpf(t);
+    return {v.x * r, v.y * r, v.z * r};
+}
 __device__ inline VecT<fastd> div3(VecT<fastd> v, fastd t)
 {
     const double r = rcp_nr2(t.v);
@@ -359,6 +385,11 @@ template <class T> __device__ inline VecT<T> vnormalise(VecT<T> a)
 {
     T tmp = ORT_SQRT(a.x * a.x + a.y * a.y + a.z * a.z);
     return div3(a, tmp);
+}
+template <> __device__ inline VecT<float> vnormalise<float>(VecT<float> a)
+{
+    const float y = __builtin_amdgcn_rsqf(dot3(a.x, a.y, a.z, a.x, a.y, a.z));       // v_rsq_f32: multiply by 1/|a|
+    return {a.x * y, a.y * y, a.z * y};
 }
 template <> __device__ inline VecT<fastd> vnormalise<fastd>(VecT<fastd> a)
 {
@@ -538,6 +569,8 @@ __device__ inline double rsq_approx(double s)
     return __builtin_fma(y, e, y);
 }
 __device__ inline fastd rcp_approx(fastd y) { return fastd(rcp_approx(y.v)); }
+__device__ inline float rcp_approx(float y) { return __builtin_amdgcn_rcpf(y); }
+__device__ inline float rsq_approx(float s) { return __builtin_amdgcn_rsqf(s); }
 // a b + c in one rounding, for decision-only arithmetic (the traced state never uses it)
 __device__ inline double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ inline fastd fmad(fastd a, fastd b, fastd c) { return fastd(__builtin_fma(a.v, b.v, c.v)); }
@@ -662,10 +695,11 @@ template <> __device__ inline bool aperture_present<float>(float a)
 template <bool FILT, class T, bool UNIT = false>
 __device__ inline void solve_and_pick(T a, T hb, T c, bool live, T &t, bool &hit, bool &rare)
 {
-    static_assert(!FILT || sizeof(T) == 8, "filtered predicates are derived for fp64 only");
+    // (fp32, kLoose: the filtered FORM — one quotient, the root picked by signs — without its margins: `rare` is never
+    // consulted for that type)
     if constexpr (FILT) {
         const T hh = hb * hb;
-        const T D = hh - a * c;
+        const T D = kLoose<T> ? mad(-a, c, hh) : hh - a * c;
         const bool nneg = !(D < T(0.0));              // :243 — D < 0: no real root (one compare serves `ok` and `hit`)
         const bool neg = !nneg;
         bool unused = false;
@@ -727,9 +761,9 @@ __device__ inline void intersect_quadric(const RayT<T> &r, T cx, T cy, T cz, T r
     T Ly = start ? ax_ly : (axis ? r.pos.y : r.pos.y - cy);
     T Lz = start ? ax_lz : r.pos.z - cz;
     T dx = cylinder ? T(0.0) : r.dir.x;
-    T a = (dx * dx) + (r.dir.y * r.dir.y) + (r.dir.z * r.dir.z);
-    T hb = (dx * Lx) + (r.dir.y * Ly) + (r.dir.z * Lz);
-    T c = start ? ax_c : ((Lx * Lx) + (Ly * Ly) + (Lz * Lz)) - (FILT ? r2 : radius * radius);
+    T a = dot3(dx, r.dir.y, r.dir.z, dx, r.dir.y, r.dir.z);
+    T hb = dot3(dx, r.dir.y, r.dir.z, Lx, Ly, Lz);
+    T c = start ? ax_c : dot3(Lx, Ly, Lz, Lx, Ly, Lz) - (FILT ? r2 : radius * radius);
     solve_and_pick<FILT, T, (OPT & 1) != 0>(a, hb, c, live, t, hit, rare);
 }
 
@@ -781,7 +815,8 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
     const T c1s = vdot(N, I);                            // == vdot(I, N): the products commute
     const T c1 = fabs(c1s);                              // costt (fresnel) and |c1| (refract)
     // refract's radicand, refract's order (:327); eta2 = eta**2 (SurfAuxT)
-    const T k = T(1.0) - (FILT ? eta2 : eta * eta) * (T(1.0) - c1 * c1);
+    const T k = kLoose<T> ? mad(-(FILT ? eta2 : eta * eta), mad(-c1, c1, T(1.0)), T(1.0))
+                          : T(1.0) - (FILT ? eta2 : eta * eta) * (T(1.0) - c1 * c1);
     bool unused = false;
     const T c2 = sqrt_f<FILT, T>(k, false, unused);      // NaN beyond total reflection: unused there
     const T ec1 = eta * c1;
@@ -821,7 +856,7 @@ __device__ inline bool reflect_refract(VecT<T> &I, VecT<T> N, T n1, T n2, T eta,
     const T mm = neg_unless(m, c1s < T(0.));
     const T alpha = DIES ? eta : (reflected ? T(1.) : eta);
     const T beta = DIES ? mm : (reflected ? -(T(2.) * c1s) : mm);
-    const VecT<T> out = vadd(vscale(I, alpha), vscale(N, beta));
+    const VecT<T> out = vlin2(I, alpha, N, beta);
     I = KEEP ? vselect(live, out, I) : out;
     return reflected;
 }
@@ -1444,8 +1479,10 @@ __device__ inline int make_image(const Sys &S, const RayT<T> &r, bool live, int 
     if constexpr (FILT) {
         // x = dir_z / |dir| up to 1e-13; the literal form below rounds it five more times.
         // UNIT (OPT_UNIT_DIR): |dir| = 1 to a few ulps, so dir_z itself is x to 1e-14 (margin 1e-10)
+        // (fp32: the same form in every kernel — without margins and deferrals a decision is only the same everywhere if
+        // its arithmetic is)
         T xa;
-        if constexpr (UNIT) xa = r.dir.z;
+        if constexpr (UNIT && !kLoose<T>) xa = r.dir.z;
         else xa = r.dir.z * rsq_approx(vdot(r.dir, r.dir));
         reject = xa < T(S.na_cos_min);
         // floor(x / binwid) from one multiply.  |q| > 1e3: off the +-200 grid whatever the rounding.
@@ -1559,7 +1596,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
             scatter_walk<T>(s, S.twopi, r, t, live && hit && !rare, draws, nis, walk_end);
             hit = hit && walk_end < 0;
         }
-        const VecT<T> moved = vadd(r.pos, vscale(r.dir, t));
+        const VecT<T> moved = vmad(r.dir, t, r.pos);
         r.pos = KEEP ? vselect(live && hit, moved, r.pos) : moved;
         bool out = false;
         if (has_ap) out = outside_aperture<FILT, T>(moved.x, moved.y, s.aperture, ax.ap2, ax.ap_tol, ax.ap_lo, ax.ap_hi, live && hit, rare);
@@ -1577,7 +1614,7 @@ __device__ inline void surface_step(const Sys &S, const Surf &s, const SurfAuxT<
     } else {
         // plane kinds: d = (z_plane - pos%z) / dir%z ; pos = pos + dir*d
         const T d = ORT_DIV(s.cz - r.pos.z, r.dir.z);
-        const VecT<T> moved = vadd(r.pos, vscale(r.dir, d));
+        const VecT<T> moved = vmad(r.dir, d, r.pos);
         if (kind == ORT_SURF_IMAGE) {
             r.pos = KEEP ? vselect(live, moved, r.pos) : moved;
             const int ist = make_image<FILT, T, (OPT & OPT_UNIT_DIR) != 0>(S, r, live, xp, yp, rare) | tag;
