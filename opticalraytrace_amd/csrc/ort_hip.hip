@@ -533,7 +533,7 @@ __device__ inline void walk(const Sys &S, const Surf *surf, const SurfAuxT<T> *a
     } else {
         const int nis0 = nis, xp0 = xp, yp0 = yp;
         walk_pass<true, T, EXT, KEEP>(S, surf, aux, k0, k1, r, draws, nis, st, xp, yp, rare);
-        if (wave_rare(rare)) {
+        if (!kLoose<T> && wave_rare(rare)) {             // (fp32: the filtered forms stand)
             RayT<T> r2;
             D d2 = draws;
             int st2, nis2 = nis0, xp2 = xp0, yp2 = yp0;
@@ -718,9 +718,9 @@ __device__ inline int lane_prefix(unsigned long long mask)
 template <int MODE, bool FILT, bool ANYSRC, class T, int PROG = PROG_GENERIC, bool SCAT = ANYSRC>
 __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) void trace_queue_kernel(TraceArgs a)
 {
-    static_assert(PROG == PROG_GENERIC || (!ANYSRC && !SCAT && (FILT || std::is_same<T, float>::value)),
-                  "programs exist for the lean kernels only: filtered (fp64, fast fp64) or fp32");
-    static_assert(!FILT || !std::is_same<T, float>::value, "the fp32 path evaluates every predicate literally");
+    static_assert(PROG == PROG_GENERIC || (!ANYSRC && !SCAT && FILT), "programs exist for the lean kernels only (filtered forms)");
+    // fp32 (kLoose): the filtered forms decide every lane — nothing is deferred, `rare` is not looked at
+    constexpr bool DEFER = FILT && !kLoose<T>;
     __shared__ typename SysTypes<T>::Sys S;
     // 26.6 KB per workgroup of a program kernel in fp64 (6 workgroups per CU's 160 KB), 14 KB in fp32
     constexpr bool fixed = PROG != PROG_GENERIC;        // surface program known at compile time
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 walk_fixed<FILT, T, false, PROG, queue_step<PROG, MODE>(), Prog<PROG>::n, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
             } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
             if (act) {
-                if (FILT && rare) defer(sdraws ? (uint64_t)dw : d.ray_of_packed(dw, a.rng_base) - a.first_ray);
+                if (DEFER && rare) defer(sdraws ? (uint64_t)dw : d.ray_of_packed(dw, a.rng_base) - a.first_ray);
                 else finish(st, nis, xp, yp);
             }
             __builtin_amdgcn_wave_barrier();
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 walk_fixed<FILT, T, false, PROG, 0, queue_step<PROG, MODE>() - 1, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
                 step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 1, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
             } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, k0, split, r, d, nis, st, xp, yp, rare);
-            const bool deferred = FILT && rare && act;
+            const bool deferred = DEFER && rare && act;
             const bool survive = act && st < 0 && !deferred;
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(survive);
             if (survive) {
@@ -1879,12 +1879,13 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
             launch_lean<fastd>(c, mode, a, grid);
         }
     } else if (c->precision == 1) {
-        // fp32 path (BASELINE configs[4]): literal predicates; queued program kernels for the default
-        // emitters in clear media, the lockstep kernel for everything else
-        if (mode == MODE_DEBUG) ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, float, true>));
-        else if (queued && !anysrc) launch_lean<float, false>(c, mode, a, grid);
-        else if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, false, float, true>));
-        else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, float, true>));
+        // fp32 path (BASELINE configs[4]): always the filtered forms, never a deferral (ort_device.h kLoose) — in every kernel,
+        // so that they agree bit for bit; queued program kernels for the default emitters in clear media, the lockstep
+        // kernel for everything else
+        if (mode == MODE_DEBUG) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, float, true>));
+        else if (queued && !anysrc) launch_lean<float, true>(c, mode, a, grid);
+        else if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, true, float, true>));
+        else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true, float, true>));
     } else if (mode == MODE_DEBUG) {
         if (filt) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, double, true>));
         else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, double, true>));
