@@ -316,14 +316,21 @@ __device__ inline SurfAuxT<T> load_aux(typename ConstPtrs<T>::aux_t p)
 // branches + the blocks they cut the schedule into) disappears and the steps are laid out
 // back to back: -8 % kernel time.  The host selects a program only when the staged system
 // matches it field for field (match_program); everything else runs the generic walk.
+// A program = a surface LIST (low four bits) + the light source in front of it (bits 4..): 0 the phase's default emitter
+// (ring / point), SRC_* another one.  Every list is instantiated with every source its phase has.
 enum { PROG_GENERIC = 0, PROG_POINT, PROG_RING, PROG_POINT_IRIS_B, PROG_POINT_IRIS_A, PROG_RING_IRIS_B, PROG_RING_IRIS_A,
-       PROG_POINT_BARE, PROG_POINT_ELLIPSE, PROG_CRS, PROG_ISORS, PROG_IMAGE, PROG_POINT_WALKED };
-// every program of the default emitters (ring / point): X(name) — instantiated fused and resident, in every arithmetic
-#define ORT_PROGRAMS(X) X(PROG_POINT) X(PROG_RING) X(PROG_POINT_IRIS_B) X(PROG_POINT_IRIS_A) X(PROG_RING_IRIS_B) X(PROG_RING_IRIS_A) \
-    X(PROG_POINT_BARE) X(PROG_POINT_ELLIPSE)
-// the default surface lists behind the other bulk light sources (runner.py's crs / iSORS / Bessel-image experiments):
-// fused, exact fp64 only; everything else of those sources (iris variants, resident bundles, fp32) runs the generic walk
-#define ORT_SOURCE_PROGRAMS(X) X(PROG_CRS) X(PROG_ISORS) X(PROG_IMAGE)
+       PROG_POINT_BARE, PROG_POINT_ELLIPSE, PROG_LIST_MASK = 15 };
+enum { SRC_CRS = 1 << 4, SRC_ISORS = 2 << 4, SRC_IMAGE = 3 << 4, SRC_HANDED_OVER = 4 << 4 };
+constexpr int PROG_CRS = PROG_RING | SRC_CRS, PROG_ISORS = PROG_RING | SRC_ISORS, PROG_IMAGE = PROG_POINT | SRC_IMAGE,
+              PROG_POINT_WALKED = PROG_POINT | SRC_HANDED_OVER;
+// every list with its phase's default emitter (ring / point): X(name) — instantiated fused and resident, in every arithmetic
+#define ORT_RING_LISTS(X, S) X(PROG_RING | S) X(PROG_RING_IRIS_B | S) X(PROG_RING_IRIS_A | S)
+#define ORT_POINT_LISTS(X, S) X(PROG_POINT | S) X(PROG_POINT_IRIS_B | S) X(PROG_POINT_IRIS_A | S) X(PROG_POINT_BARE | S) X(PROG_POINT_ELLIPSE | S)
+#define ORT_PROGRAMS(X) ORT_POINT_LISTS(X, 0) ORT_RING_LISTS(X, 0)
+// ... and with the other bulk light sources (runner.py's crs / iSORS / Bessel-image experiments, with and without an iris):
+// crs and isors in front of the ring loop's lists, the image source in front of the point loop's; fused, fp64 and fp32
+// (resident bundles and fast fp64 of those sources run the generic walk)
+#define ORT_SOURCE_PROGRAMS(X) ORT_RING_LISTS(X, SRC_CRS) ORT_RING_LISTS(X, SRC_ISORS) ORT_POINT_LISTS(X, SRC_IMAGE)
 
 namespace prog {
 constexpr int CYL = ORT_SURF_CYLINDER, ELL = ORT_SURF_ELLIPSE, PLN = ORT_SURF_PLANE, SPH = ORT_SURF_SPHERE, IRS = ORT_SURF_IRIS, IMG = ORT_SURF_IMAGE;
@@ -395,15 +402,19 @@ template <> struct Prog<PROG_POINT_ELLIPSE> {
     static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 0};
 };
 
-// the default lists behind the crs source (point_on_bottle, src/sourceMod.f90:50-89, src/main.f90:99), the isors source
-// (iSORS, :162-247, main.f90:97) and the image source (emit_image, :303-361, main.f90:133)
-template <> struct Prog<PROG_CRS> : Prog<PROG_RING> { static constexpr int emitter = ORT_EMIT_CRS; };
-template <> struct Prog<PROG_ISORS> : Prog<PROG_RING> { static constexpr int emitter = ORT_EMIT_ISORS; };
-template <> struct Prog<PROG_IMAGE> : Prog<PROG_POINT> { static constexpr int emitter = ORT_EMIT_IMAGE; };
-// the point loop's list behind a scattering bottle (trace_queue_kernel<MODE_CONTINUE>: rays handed over by scatter_front_kernel,
-// each at its own draw; whatever source emitted them)
+// a list behind another light source: the crs source (point_on_bottle, src/sourceMod.f90:50-89, src/main.f90:99), the isors
+// source (iSORS, :162-247, main.f90:97), the image source (emit_image, :303-361, main.f90:133) — or, SRC_HANDED_OVER, behind
+// a scattering bottle (trace_queue_kernel<MODE_CONTINUE>: rays handed over by scatter_front_kernel, each at its own draw;
+// whatever source emitted them)
 constexpr int ORT_EMIT_HANDED_OVER = -2;
-template <> struct Prog<PROG_POINT_WALKED> : Prog<PROG_POINT> { static constexpr int emitter = ORT_EMIT_HANDED_OVER; };
+constexpr int source_emitter(int src)
+{
+    return src == SRC_CRS ? ORT_EMIT_CRS : src == SRC_ISORS ? ORT_EMIT_ISORS : src == SRC_IMAGE ? ORT_EMIT_IMAGE : ORT_EMIT_HANDED_OVER;
+}
+template <int P> struct Prog : Prog<(P & PROG_LIST_MASK)> {
+    static_assert(P > PROG_LIST_MASK, "a list without a Prog<> specialisation");
+    static constexpr int emitter = source_emitter(P & ~PROG_LIST_MASK);
+};
 
 template <int P> constexpr bool prog_is_ring()             // phase-1 list (plano-convex first)
 {
@@ -1884,12 +1895,19 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
         // kernel for everything else
         if (mode == MODE_DEBUG) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, float, true>));
         else if (queued && !anysrc) launch_lean<float, true>(c, mode, a, grid);
+        else if (queued && mode == MODE_FUSED && !scat && c->prog[a.phase - 1] > PROG_LIST_MASK) {
+            switch (c->prog[a.phase - 1]) {                   // the other bulk light sources: their own program kernels
+#define ORT_CASE(P) case P: ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, float, P>)); break;
+                ORT_SOURCE_PROGRAMS(ORT_CASE)
+#undef ORT_CASE
+            }
+        }
         else if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, true, float, true>));
         else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true, float, true>));
     } else if (mode == MODE_DEBUG) {
         if (filt) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, double, true>));
         else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, double, true>));
-    } else if (anysrc && filt && queued && mode == MODE_FUSED && !scat && c->prog[a.phase - 1] >= PROG_CRS && !a.strict) {
+    } else if (anysrc && filt && queued && mode == MODE_FUSED && !scat && c->prog[a.phase - 1] > PROG_LIST_MASK && !a.strict) {
         // the other bulk light sources in front of a default surface list: their own program kernels
         switch (c->prog[a.phase - 1]) {
 #define ORT_CASE(P) case P: ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, double, P>)); break;

@@ -123,10 +123,11 @@ def needs_extended_res(settings) -> bool:
     return settings.light_source == "image" or settings.bottle_file in SCATTER_BOTTLES or settings.bottle_file == "scatterBottle-ellipse.params"
 
 
-def make_system(name: str):
+def make_system(name: str, **over):
+    """The system of CONFIGS[name], `over` = further Settings overrides (e.g. an iris in front of another light source)."""
     from opticalraytrace_amd.params import Settings, resource_dir
     from opticalraytrace_amd.system import OpticalSystem
-    s = Settings(**{**dict(nphotons=100000, make_images=True), **CONFIGS[name]})
+    s = Settings(**{**dict(nphotons=100000, make_images=True), **CONFIGS[name], **over})
     res = res_dir_with_image(resource_dir()) if needs_extended_res(s) else None
     return s, OpticalSystem.from_settings(s, res)
 

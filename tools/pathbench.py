@@ -77,6 +77,9 @@ def main():
     measure("(clock settle, discard)", large, n, 150)
     if args.only == "generic":
         measure("generic walk (no surface program), fp64", large, n, reps)
+        measure("generic walk: crs, iris before the doublet", dict(bottle_file="clearBottle-large.params", light_source="crs", crs_spot_size=0.5e-3,
+                                                                   iris="before", iris_size=0.5), n, reps)
+        measure("generic walk: crs, fp32", dict(bottle_file="clearBottle-large.params", light_source="crs", crs_spot_size=0.5e-3), n, reps, precision=1)
         return 0
     measure("surface programs, fused, fp64 (the bench)", large, n, reps)
     measure("surface programs, fused, fp32", large, n, reps, precision=1)
@@ -89,6 +92,14 @@ def main():
     measure("light source image", dict(bottle_file="clearBottle-large.params", light_source="image",
                                        image_source="synthetic-source.dat"), n, reps)
     measure("light source isors", dict(bottle_file="clearBottle-small.params", light_source="isors", isors_offset=0.5e-3), n, reps)
+    # round 4: every list x every source of its phase has a program, in fp64 and fp32
+    iris = dict(iris="before", iris_size=0.5)
+    measure("crs, iris before the doublet", dict(bottle_file="clearBottle-large.params", light_source="crs", crs_spot_size=0.5e-3, **iris), n, reps)
+    measure("isors, iris before the doublet", dict(bottle_file="clearBottle-small.params", light_source="isors", isors_offset=0.5e-3, **iris), n, reps)
+    measure("image, iris before the doublet", dict(bottle_file="clearBottle-large.params", light_source="image", image_source="synthetic-source.dat", **iris), n, reps)
+    measure("crs, fp32", dict(bottle_file="clearBottle-large.params", light_source="crs", crs_spot_size=0.5e-3), n, reps, precision=1)
+    measure("isors, fp32", dict(bottle_file="clearBottle-small.params", light_source="isors", isors_offset=0.5e-3), n, reps, precision=1)
+    measure("image, fp32", dict(bottle_file="clearBottle-large.params", light_source="image", image_source="synthetic-source.dat"), n, reps, precision=1)
     measure("scattering bottle (contents + wall)", dict(bottle_file="scatterBottle-both.params"), n // 10, reps)
     return 0
 
