@@ -578,6 +578,14 @@ def main() -> int:
             # are counted (lost, one surface solve) without being emitted — DESIGN §3.8; radius^2 / (radius + 10 mm)^2
             "ring_rays_culled_fraction": ring_cull_fraction(system) if 1 in phases else None,
             "algorithmic_flop_per_launch": alg_flop,
+            # COUNTED instead of assumed: 64 x (ADD_F64 + MUL_F64 + 2 FMA_F64) wave-instructions of this very build's PMC
+            # pass (profiles/pmc_per_launch.json; null when the committed counters are another build's) over the same
+            # mean launch duration — what the vector units really delivered, IEEE division / sqrt expansions included
+            "counted_flop_per_launch": prof.get("counted_fp64_flop_per_launch"),
+            "frac_counted": (prof["counted_fp64_flop_per_launch"] * (rays_launch / prof["rays_per_launch_nominal"]) / k_s / 1e12 / FP64_VEC_PEAK_TFLOPS
+                             if prof.get("counted_fp64_flop_per_launch") and prof.get("rays_per_launch_nominal") else None),
+            "non_arithmetic_share_of_valu": prof.get("non_arithmetic_share_of_valu"),   # compares, selects, moves, integer (the draw), conversions
+            "sq_insts_salu_per_launch": prof.get("salu_instructions_per_launch"),
             "note": "algorithmic flop = an assumed 100 per surface solve (SURVEY §8d; + 61 per emitted ring "
                     "ray in the ring loop) / mean launch duration (HIP events on the context's stream)"
                     + ("; ring loop: the rays whose lens-disc draw already puts them outside the first aperture "

@@ -25,7 +25,7 @@ DOMINANT = {"point1e7": "trace_queue_kernel<0, true, false, double, 1, false>",
             "ring1e8": "trace_queue_kernel<0, true, false, double, 2, false>",
             "full1e9": "trace_queue_kernel<0, true, false, double, 1, false>"}
 # the informational legs of a workload: their program kernels (bench.py `fp32` / `fast_fp64`)
-LEGS = {"point1e7": {"fp32": "trace_queue_kernel<0, false, false, float, 1, false>",
+LEGS = {"point1e7": {"fp32": "trace_queue_kernel<0, true, false, float, 1, false>",
                      "fast_fp64": "trace_queue_kernel<0, true, false, ort::fastd, 1, false>"}}
 
 
@@ -89,9 +89,17 @@ def main():
         if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
             entry["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
         for c, key in (("SQ_INSTS_VALU", "valu_instructions_per_launch"), ("SQ_INSTS_SALU", "salu_instructions_per_launch"),
-                       ("SQ_WAVES", "waves_per_launch"), ("TCC_EA0_ATOMIC_sum", "memory_side_atomics_per_launch")):
+                       ("SQ_WAVES", "waves_per_launch"), ("TCC_EA0_ATOMIC_sum", "memory_side_atomics_per_launch"),
+                       ("SQ_INSTS_VALU_FMA_F64", "fma_f64"), ("SQ_INSTS_VALU_MUL_F64", "mul_f64"), ("SQ_INSTS_VALU_ADD_F64", "add_f64"),
+                       ("SQ_INSTS_VALU_TRANS_F64", "trans_f64"), ("SQ_INSTS_VALU_INT32", "int32"), ("SQ_INSTS_VALU_INT64", "int64"),
+                       ("SQ_INSTS_VALU_CVT", "cvt")):
             if g(c) is not None:
                 entry[key] = g(c)
+        if all(k in entry for k in ("fma_f64", "mul_f64", "add_f64")):
+            # COUNTED fp64 flop of one launch: wave-instructions x 64 lanes, an FMA = 2 (the roofline's own convention)
+            entry["counted_fp64_flop_per_launch"] = 64.0 * (entry["add_f64"] + entry["mul_f64"] + 2.0 * entry["fma_f64"])
+            if entry.get("valu_instructions_per_launch"):
+                entry["non_arithmetic_share_of_valu"] = 1.0 - (entry["add_f64"] + entry["mul_f64"] + entry["fma_f64"]) / entry["valu_instructions_per_launch"]
         # intersections per launch of the dominant kernel, from the bench line of the PMC-sized run
         p1 = os.path.join(d, "pmc1.json")
         if os.path.exists(p1):
