@@ -582,8 +582,8 @@ def main() -> int:
             # pass (profiles/pmc_per_launch.json; null when the committed counters are another build's) over the same
             # mean launch duration — what the vector units really delivered, IEEE division / sqrt expansions included
             "counted_flop_per_launch": prof.get("counted_fp64_flop_per_launch"),
-            "frac_counted": (prof["counted_fp64_flop_per_launch"] * (rays_launch / prof["rays_per_launch_nominal"]) / k_s / 1e12 / FP64_VEC_PEAK_TFLOPS
-                             if prof.get("counted_fp64_flop_per_launch") and prof.get("rays_per_launch_nominal") else None),
+            "frac_counted": (prof["counted_fp64_flop_per_launch"] * (rays_launch / prof["rays_per_launch_nominal"] if prof.get("rays_per_launch_nominal") else 1.0)
+                             / k_s / 1e12 / FP64_VEC_PEAK_TFLOPS if prof.get("counted_fp64_flop_per_launch") else None),
             "non_arithmetic_share_of_valu": prof.get("non_arithmetic_share_of_valu"),   # compares, selects, moves, integer (the draw), conversions
             "sq_insts_salu_per_launch": prof.get("salu_instructions_per_launch"),
             "note": "algorithmic flop = an assumed 100 per surface solve (SURVEY §8d; + 61 per emitted ring "
