@@ -309,8 +309,13 @@ int ort_set_precision(ort_ctx *ctx, int precision);
  * whose third draw already puts them outside the first aperture are counted without being emitted
  * (queued surface-program kernels); bit 4 set = scattering bottles run the monolithic kernel (the random walk
  * compiled into the surface walk), clear (default) = the scattering pipeline (walk stages on full wavefronts in
- * front of the lean walk); bit 5: unused (round 3's two-rays-per-lane fp32 kernel, measured slower and removed:
- * HISTORY.md).  All combinations of bits 0-4 produce bit-identical rays, images and counters.
+ * front of the lean walk).  All combinations of bits 0-4 produce bit-identical rays, images and counters.
+ * Bit 5 set = 53-BIT DRAWS (stream ORT-RNG-v2w, csrc/ort_device.h): every uniform is (h >> 11) * 2^-53 of its own hash,
+ * as the reference's ran2() fills a real(8) (src/random_mod.f90:39-46), where the default stream ORT-RNG-v2 hands out
+ * 32-bit draws, two per hash.  A different stream, therefore different rays (same statistics: tests/test_gpu_wide_draws.py
+ * against the unmodified program); traced by the lockstep kernel (the surface programs and the scattering pipeline are
+ * built on v2's pairs; ~1.5 x the time).  Every entry that draws honours it (ort_trace, ort_emit, ort_trace_resident,
+ * ort_trace_rays with u == NULL, ort_trace_paths); the checker's keyed mode has the same switch.
  * Bit 6 set = STRICT LIBM EMITTERS (exact fp64 only): the light sources evaluate sin / cos through glibc 2.35's own
  * algorithms (csrc/ort_libm.h), entry by entry as the reference's compiled code calls them, so an emitted ray — and with it
  * every ray state, image and counter — equals the CPU checker's bit for bit; the surface-program kernels

@@ -78,6 +78,24 @@ template <class T> __device__ inline T unit_from(uint32_t w)
 }
 __device__ inline uint32_t draw_word(uint64_t h, bool odd) { return odd ? (uint32_t)h : (uint32_t)(h >> 32); }
 
+// ORT-RNG-v2w, the 53-bit stream (kernel variant bit 5; ran2() fills a real(8), src/random_mod.f90:39-46, and the
+// runtime's random_number gives it 53 random bits): ONE hash per draw, all of a double's mantissa from it,
+//   h = mix64(base + GOLDEN * (c + 1)),   u = (h >> 11) * 2^-53          (fp32 path: the top 24 bits of h)
+// — every value k * 2^-53 of [0, 1) can occur, where v2's 32-bit draws stop at multiples of 2^-32.  The two halves
+// of h >> 11 convert exactly and their sum is exact.  Offered by the kernels that count draws per lane (the
+// lockstep kernel and the parity entry); the surface programs and the scattering pipeline are built on v2's pairs.
+__host__ __device__ inline uint64_t wide_hash(uint64_t base, uint64_t c) { return mix64(base + kGolden * (c + 1ull)); }
+__host__ __device__ inline double unit53(uint64_t h)
+{
+    const uint64_t x = h >> 11;
+    return (double)(uint32_t)(x >> 32) * 0x1p-21 + (double)(uint32_t)x * 0x1p-53;
+}
+template <class T> __device__ inline T wide_unit_from(uint64_t h)
+{
+    if constexpr (sizeof(T) == 8) return T(unit53(h));
+    else return (float)(uint32_t)(h >> 40) * 0x1.0p-24f;
+}
+
 // the i1 ballot builtin: an s_and of the compare mask with exec.  (HIP's __ballot(int) first
 // materialises the predicate as 0/1 in a VGPR and compares it again: two VALU instructions.)
 __device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
@@ -98,19 +116,21 @@ struct Draws {
     int64_t stride;
     int len;
     int k;                 // draws consumed so far
+    bool wide;             // keyed: ORT-RNG-v2w (wave-uniform)
 
-    __device__ inline void init_keyed(uint64_t b, uint64_t ray, int first_draw)
+    __device__ inline void init_keyed(uint64_t b, uint64_t ray, int first_draw, bool w = false)
     {
-        table = nullptr; stride = 0; len = 0; k = first_draw; base = b;
+        table = nullptr; stride = 0; len = 0; k = first_draw; base = b; wide = w;
         c = (ray << 24) + (uint64_t)first_draw;
     }
     __device__ inline void init_table(const double *t, int64_t s, int l, int first_draw)
     {
-        table = t; stride = s; len = l; k = first_draw; c = 0; base = 0;
+        table = t; stride = s; len = l; k = first_draw; c = 0; base = 0; wide = false;
     }
     __device__ inline double peek() const
     {
         if (table) return k < len ? table[(int64_t)k * stride] : 0.5;
+        if (wide) return unit53(wide_hash(base, c));
         return bits_to_unit(draw_word(mix64(base + kGolden * ((c >> 1) + 1ull)), (c & 1ull) != 0));
     }
     __device__ inline void advance(bool cnd)
@@ -131,7 +151,18 @@ struct Draws {
 
 // keyed-only variant of the bulk kernels that walk a list they do not know at compile time
 // (generic walk, lockstep kernel): the linear counter per lane, one hash per draw
-struct KeyedDraws {
+// DYN: the stream is chosen at run time (set_wide: v2, or the 53-bit v2w of kernel variant bit 5) — the lockstep kernel and
+// emit_kernel; DYN = false (the queued kernels, the scattering pipeline) knows v2 alone and pays nothing for the choice.
+template <bool DYN> struct WideChoice {
+    bool wide_ = false;
+    __device__ inline bool wide() const { return wide_; }
+    __device__ inline void set_wide(bool w) { wide_ = w; }
+};
+template <> struct WideChoice<false> {
+    __device__ inline constexpr bool wide() const { return false; }
+    __device__ inline void set_wide(bool) {}
+};
+template <bool DYN> struct KeyedDrawsT : WideChoice<DYN> {
     uint64_t c;            // (ray << 24) + k
     uint64_t base;
     __device__ inline void init_keyed(uint64_t b, uint64_t ray, int first_draw)
@@ -143,11 +174,15 @@ struct KeyedDraws {
     {
         return draw_word(mix64(base + kGolden * ((c >> 1) + 1ull)), (c & 1ull) != 0);
     }
-    __device__ inline double peek() const { return bits_to_unit(word()); }
+    __device__ inline double peek() const { return peek_as<double>(); }
     __device__ inline void advance(bool cnd) { c += cnd ? 1ull : 0ull; }
-    __device__ inline void take(bool cnd, const KeyedDraws &o) { c = cnd ? o.c : c; }
+    __device__ inline void take(bool cnd, const KeyedDrawsT &o) { c = cnd ? o.c : c; }
     __device__ inline double next() { const double u = peek(); c += 1ull; return u; }
-    template <class T> __device__ inline T peek_as() const { return unit_from<T>(word()); }
+    template <class T> __device__ inline T peek_as() const
+    {
+        if (DYN && this->wide()) return wide_unit_from<T>(wide_hash(base, c));
+        return unit_from<T>(word());
+    }
     template <class T> __device__ inline T next_as()
     {
         const T u = peek_as<T>();
@@ -159,7 +194,7 @@ struct KeyedDraws {
     // Box-Muller loops of the crs and isors sources, which start at draw 2 / 0 and consume pairs — one hash serves both
     template <class T> __device__ inline void next_pair_as(bool cnd, T &u1, T &u2)
     {
-        if (!wave_any((c & 1ull) != 0)) {
+        if (!(DYN && this->wide()) && !wave_any((c & 1ull) != 0)) {
             const uint64_t h = mix64(base + kGolden * ((c >> 1) + 1ull));
             u1 = unit_from<T>((uint32_t)(h >> 32));
             u2 = unit_from<T>((uint32_t)h);
@@ -175,6 +210,7 @@ struct KeyedDraws {
     __device__ inline void unpack(uint64_t w, uint64_t b) { c = w; base = b; }
     __device__ inline uint64_t ray_of_packed(uint64_t w, uint64_t) const { return w >> 24; }
 };
+using KeyedDraws = KeyedDrawsT<false>;
 
 // Draw source of the surface-program kernels: every live lane of a wave is at the same draw
 // index K, a compile-time constant of the program step, so nothing is counted per lane: the

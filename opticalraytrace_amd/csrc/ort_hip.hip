@@ -91,6 +91,7 @@ struct TraceArgs {
     double cull;
     float cullf;
     int strict;                  // kernel variant bit 6: the emitters call glibc's own sin / cos / sincos (ort_device.h: sincos_em)
+    int wide;                    // kernel variant bit 5: 53-bit draws (ORT-RNG-v2w, ort_device.h); lockstep kernel only
     uint64_t defer_base;         // queued kernel: list entry of ray i of this launch = defer_base + i (the entries of all
                                  // launches of a group are relative to the group's first ray, see close_group)
     int listed;                  // trace_kernel: iterate redo_list instead of [0, n_rays)
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
         if (MODE == MODE_DEBUG) {
             Draws d;
             if (a.u) d.init_table(a.u + ic, (int64_t)n, a.nu, a.draw_base);
-            else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
+            else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base, a.wide != 0);
             if (!have_in) {
                 const Draws d_none = d;
                 const int est = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf, a.strict != 0);
@@ -644,17 +645,18 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             }
             kdraws = d.k;
         } else {
-            KeyedDraws d;
+            KeyedDrawsT<true> d;
             d.init_keyed(a.rng_base, a.first_ray + ic, have_in ? a.draw_base : 0);
+            d.set_wide(a.wide != 0);
             if (!have_in) {
                 const int est = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf, a.strict != 0);
                 st = est < 0 ? st : est;
             }
             const RayT<T> r0 = r;
-            const KeyedDraws d0 = d;
+            const KeyedDrawsT<true> d0 = d;
             const int st0 = st;
             walk<FILT, T, ANYSRC, false>(S, surf, AUX, 0, ns, r, d, nis, st, xp, yp,
-                                         [&](RayT<T> &rr, KeyedDraws &dd, int &ss) { rr = r0; dd = d0; ss = st0; });
+                                         [&](RayT<T> &rr, KeyedDrawsT<true> &dd, int &ss) { rr = r0; dd = d0; ss = st0; });
         }
         if (!act) continue;
         if (MODE == MODE_DEBUG) {
@@ -1368,14 +1370,15 @@ __global__ __launch_bounds__(64 * kScatWaves) void scatter_front_kernel(TraceArg
 
 __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int phase,
                                                       uint64_t first_ray, uint64_t n, uint64_t rng_base,
-                                                      double *pos_dir, const long long *img_cdf, int strict)
+                                                      double *pos_dir, const long long *img_cdf, int strict, int wide)
 {
     __shared__ ort_system S;
     stage_system(S, sys);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        KeyedDraws d;
+        KeyedDrawsT<true> d;
         d.init_keyed(rng_base, first_ray + i, 0);
+        d.set_wide(wide != 0);
         Ray r;
         emit<double, true>(S, phase, r, d, first_ray + i, img_cdf, strict != 0);
         pos_dir[0 * n + i] = (double)r.pos.x; pos_dir[1 * n + i] = (double)r.pos.y; pos_dir[2 * n + i] = (double)r.pos.z;
@@ -2018,12 +2021,13 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     a0.in_stride = a0.n_rays;
     const bool culling = (c->variant & 8) == 0;                 // bit 3: A/B knob, ring rays are all emitted
     a0.strict = ((c->variant & 64) != 0 && c->precision == 0) ? 1 : 0;
+    a0.wide = (c->variant & 32) ? 1 : 0;
     a0.cull = culling ? c->ring_cull : HUGE_VAL;
     a0.cullf = culling ? c->ring_cullf : HUGE_VALF;
     if (a0.first_ray > ORT_MAX_RAY_INDEX || a0.n_rays > ORT_MAX_RAY_INDEX - a0.first_ray)
         return fail(ORT_E_INVALID, "ray indices reach beyond 2^40 (ORT_MAX_RAY_INDEX): the keyed draw counter holds 40 bits of ray index");
     if (a0.n_rays == 0) return ORT_OK;
-    const bool queued = (c->variant & 1) && mode != MODE_DEBUG;
+    const bool queued = (c->variant & 1) && mode != MODE_DEBUG && !a0.wide;     // 53-bit draws: the lockstep kernel
     const bool filt = (c->variant & 2) == 0 && c->precision != 1;      // fp32: literal predicates, nothing is deferred
     const bool anysrc_emitter = c->emitter[a0.phase - 1] != (a0.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT);
     const bool anysrc = anysrc_emitter || c->scatter[a0.phase - 1];
@@ -2166,7 +2170,8 @@ int ort_emit(ort_ctx *c, int phase, uint64_t first_ray, uint64_t n_rays, uint64_
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2][0], c->stream));
     hipLaunchKernelGGL(emit_kernel, dim3(grid_for(n_rays)), dim3(kBlock), 0, c->stream,
                        &c->d_sys->sys, phase, first_ray, n_rays, stream_base(seed, phase), d_pos_dir,
-                       (const long long *)c->d_img_cdf, ((c->variant & 64) != 0 && c->precision == 0) ? 1 : 0);
+                       (const long long *)c->d_img_cdf, ((c->variant & 64) != 0 && c->precision == 0) ? 1 : 0,
+                       (c->variant & 32) ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (c->timing) { HIP_TRY(hipEventRecord(c->ev[2][1], c->stream)); c->ev_valid[2] = true; }
     return ORT_OK;

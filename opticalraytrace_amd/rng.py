@@ -5,7 +5,10 @@
     h    = mix64(base + GOLDEN * ((c >> 1) + 1))         (mix64 = SplitMix64 finaliser)
     u    = (k even ? h >> 32 : h & 0xffffffff) * 2^-32   (one hash serves two consecutive draws)
 
-Same definition as csrc/ort_device.h (device) — restated, not shared.
+ORT-RNG-v2w (kernel variant bit 5, `wide=True`): one hash per draw and 53 bits of it,
+    h = mix64(base + GOLDEN * (c + 1)),  u = (h >> 11) * 2^-53
+
+Same definitions as csrc/ort_device.h (device) — restated, not shared.
 """
 import numpy as np
 
@@ -23,12 +26,14 @@ def mix64(z):
     return z
 
 
-def uniforms(seed: int, phase: int, ray: int, draws) -> np.ndarray:
+def uniforms(seed: int, phase: int, ray: int, draws, wide: bool = False) -> np.ndarray:
     """u for draw indices `draws` (array) of key (seed, phase, ray)."""
     k = np.asarray(draws, dtype=np.uint64)
     with np.errstate(over="ignore"):
         base = mix64(np.uint64(seed & 0xFFFFFFFFFFFFFFFF) ^ (GOLDEN * np.uint64(phase)))
         c = (np.uint64(ray) << np.uint64(24)) + k
+        if wide:
+            return (mix64(base + GOLDEN * (c + np.uint64(1))) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
         h = mix64(base + GOLDEN * ((c >> np.uint64(1)) + np.uint64(1)))
     w = np.where((c & np.uint64(1)) != 0, h & np.uint64(0xFFFFFFFF), h >> np.uint64(32))
     return w.astype(np.float64) * 2.0 ** -32

@@ -122,6 +122,8 @@ class Oracle:
         L.orc_cauchy.argtypes = L.orc_dispersion.argtypes = [C.c_double] * 4
         L.orc_uniform.restype = C.c_double
         L.orc_uniform.argtypes = [C.c_uint64, C.c_int32, C.c_uint64, C.c_int32]
+        L.orc_set_wide_draws.restype = None
+        L.orc_set_wide_draws.argtypes = [C.c_int32]
         L.orc_trace_rays.restype = C.c_int
         L.orc_trace_rays.argtypes = [C.POINTER(OrcSystem), C.c_int, C.c_int64, _DP, C.c_int, _DP,
                                      C.c_int, C.c_uint64, C.c_uint64, _DP, _DP, _IP, _IP, _IP, _IP]
@@ -143,6 +145,10 @@ class Oracle:
 
     def uniform(self, seed, phase, ray, draw) -> float:
         return self.lib.orc_uniform(seed, phase, ray, draw)
+
+    def set_wide_draws(self, on: bool) -> None:
+        """Keyed draws: ORT-RNG-v2w (53 bits, one hash per draw) instead of v2.  Process-wide: switch it back."""
+        self.lib.orc_set_wide_draws(1 if on else 0)
 
     def trace_rays(self, phase, n, pos_dir_in=None, u=None, draw_base=0, seed=0, first_ray=0):
         if pos_dir_in is not None:

@@ -29,10 +29,16 @@ static inline uint64_t mix64(uint64_t z)
     return z;
 }
 
+/* ORT-RNG-v2w (the product's kernel variant bit 5): one hash per draw, u = (h >> 11) * 2^-53 — 53 random bits as the
+ * runtime's random_number gives ran2's real(8) (src/random_mod.f90:44).  Process-wide switch of the keyed mode. */
+static int g_wide_draws = 0;
+void orc_set_wide_draws(int32_t on) { g_wide_draws = on != 0; }
+
 double orc_uniform(uint64_t seed, int32_t phase, uint64_t ray, int32_t draw)
 {
     uint64_t base = mix64(seed ^ (GOLDEN * (uint64_t)phase));
     uint64_t c = (ray << 24) + (uint64_t)draw;
+    if (g_wide_draws) return (double)(mix64(base + GOLDEN * (c + 1ull)) >> 11) * 0x1.0p-53;
     uint64_t h = mix64(base + GOLDEN * ((c >> 1) + 1ull));
     uint32_t w = (c & 1ull) ? (uint32_t)h : (uint32_t)(h >> 32);
     return (double)w * 0x1.0p-32;

@@ -83,6 +83,9 @@ double orc_sellmeier(double wave, double b1, double b2, double b3, double c1, do
 double orc_cauchy(double wave, double a, double b, double c);
 double orc_dispersion(double wave, double a, double b, double c);
 double orc_uniform(uint64_t seed, int32_t phase, uint64_t ray, int32_t draw);
+/* keyed draws from now on: 0 (default) ORT-RNG-v2 (32-bit draws, two per hash), 1 ORT-RNG-v2w (53-bit draws,
+ * one per hash) — the streams of the product's kernel variant bit 5 */
+void orc_set_wide_draws(int32_t on);
 
 /* init_emit_image, src/sourceMod.f90:363-408, serial semantics (nphotonsLocal = nphotons):
  * img is the 512x512 float64 file content as read (first index fastest); rounding draw k of

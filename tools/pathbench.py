@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 SEED = 123456789
 
 
-def measure(name, settings_kw, n, reps, resident=False, precision=0):
+def measure(name, settings_kw, n, reps, resident=False, precision=0, variant=1):
     import torch
     from opticalraytrace_amd import capi
     from opticalraytrace_amd.params import Settings, resource_dir
@@ -30,6 +30,7 @@ def measure(name, settings_kw, n, reps, resident=False, precision=0):
     with capi.Context(osys, device=0) as c:
         c.set_timing(True)
         c.set_precision(precision)
+        c.set_kernel_variant(variant)
         bundle = torch.empty((6, n), dtype=torch.float64, device="cuda:0") if resident else None
         for phase in (1, 2):
             ms, ems = [], []
@@ -101,6 +102,10 @@ def main():
     measure("isors, fp32", dict(bottle_file="clearBottle-small.params", light_source="isors", isors_offset=0.5e-3), n, reps, precision=1)
     measure("image, fp32", dict(bottle_file="clearBottle-large.params", light_source="image", image_source="synthetic-source.dat"), n, reps, precision=1)
     measure("scattering bottle (contents + wall)", dict(bottle_file="scatterBottle-both.params"), n // 10, reps)
+    # the variants that leave the programs: strict libm emitters (generic queued walk), 53-bit draws (lockstep kernel)
+    measure("strict libm emitters (variant 1|64)", large, n, reps, variant=1 | 64)
+    measure("53-bit draws (variant 1|32)", large, n, reps, variant=1 | 32)
+    measure("53-bit draws, fp32", large, n, reps, precision=1, variant=1 | 32)
     return 0
 
 
