@@ -86,10 +86,10 @@ struct TraceArgs {
     uint32_t *redo_list;
     unsigned int *redo_ctl;
     // ring programs (trace_queue_kernel, segment 0): a ring ray whose lens-disc sample rr (its third draw x
-    // ring_lens_r2) exceeds `cull` misses the plano-convex aperture for certain and is counted without
-    // being emitted; +inf: nothing is culled (host: ring_cull_threshold)
-    double cull;
-    float cullf;
+    // ring_lens_r2) exceeds the host's threshold (ring_cull_threshold) misses the plano-convex aperture for certain and is
+    // counted without being emitted.  rr does not decrease with the draw's 32-bit word, so the test is taken on the word:
+    // the ray dies iff word > cull_word (fp32 arithmetic: cull_wordf; host: cull_word_of); 0xffffffff: nothing is culled
+    uint32_t cull_word, cull_wordf;
     int strict;                  // kernel variant bit 6: the emitters call glibc's own sin / cos / sincos (ort_device.h: sincos_em)
     int wide;                    // kernel variant bit 5: 53-bit draws (ORT-RNG-v2w, ort_device.h); lockstep kernel only
     uint64_t defer_base;         // queued kernel: list entry of ray i of this launch = defer_base + i (the entries of all
@@ -850,6 +850,10 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     int qcount = 0, qhead = 0;
     int ccount = 0, chead = 0;
     const uint64_t z0 = zray_of(a.rng_base, a.first_ray);      // ProgDraws::init_index (a launch holds < 2^32 rays)
+    // segment 0: zray of ray next + lane = znext (wave-uniform) + zlane
+    uint64_t znext = z0 + (kGolden << 23) * next;
+    const uint64_t zlane = (kGolden << 23) * (uint64_t)lane;
+    unsigned int culled_wave = 0;     // rays segment 0 culled (wave-uniform): each is lost after one intersection
     for (;;) {
         const bool have_new = next < hi;
         const bool cand_ready = PRE && (ccount >= 64 || (!have_new && ccount > 0));
@@ -984,29 +988,33 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             // three draws are: the ray ends there after ONE surface solve.  69 % of the ring rays; they
             // are counted (lost, one intersection) and never emitted.  Results are unchanged
             // (tests: with culling == without it, bit for bit, on every system of the parity suite).
-            const uint64_t i = next + (uint64_t)lane;
-            const bool act = i < hi;
-            next += 64;
-            const uint64_t ic = act ? i : hi - 1;
+            // The pass is ~30 vector instructions for 64 rays: the ray's hash input is a wave-uniform 64-bit sum (scalar
+            // unit) plus a per-lane constant; the test rr > cull, rr = 0 + u3 (ring_lens_r2 - 0) as emit_ring forms it, is
+            // monotone in the draw's 32-bit word and is taken on the word (cull_word: the largest word that survives, found
+            // by the host with the kernel's own arithmetic); the culled rays are counted per wave, not per lane.
             if constexpr (PRE) {
-                ProgDraws d;
-                d.init_index(z0, (uint32_t)ic, 0);
-                const T u3 = d.template at<T, 2, true>();
-                const T rr = T(0.) + u3 * (T(csys->ring_lens_r2) - T(0.));       // as emit_ring forms it
+                const uint32_t left = (uint32_t)(hi - next);                  // >= 1, and a launch holds < 2^32 rays
+                const bool act = (uint32_t)lane < left;
+                const uint64_t h = mix64((znext + zlane) + kGolden * 2ull);   // pair 1 of ray next + lane: its draws 2 and 3
+                const uint32_t w = (uint32_t)(h >> 32);                       // draw 2, the third (ProgDraws::at<T, 2>)
                 bool dies;
-                if constexpr (std::is_same<T, float>::value) dies = rr > a.cullf;
-                else dies = rr > T(a.cull);
+                if constexpr (std::is_same<T, float>::value) dies = w > a.cull_wordf;
+                else dies = w > a.cull_word;
                 const bool cand = act && !dies;
                 const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
-                if (cand) cq[(chead + ccount + lane_prefix(mask)) & (kQueueCap - 1)] = (uint32_t)i;
-                else if (act) { finish(ORT_ST_LOST_TELESCOPE | (tagged ? 1 << 8 : 0), 1, 0, 0); culled++; }
-                ccount += __popcll(mask);
+                if (cand) cq[(chead + ccount + lane_prefix(mask)) & (kQueueCap - 1)] = (uint32_t)next + (uint32_t)lane;
+                const int passed = __popcll(mask);
+                culled_wave += (unsigned)((left < 64u ? (int)left : 64) - passed);
+                ccount += passed;
+                znext += (kGolden << 23) * 64ull;
             }
+            next += 64;
             __builtin_amdgcn_wave_barrier();
         } else {
             break;
         }
     }
+    if (PRE && lane == 0) { lost += culled_wave; isect += culled_wave; culled = culled_wave; }   // src/optics_system.f90:42 (lost), one intersection each
     atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect);
     atomicAdd(&blk[2], binned); atomicAdd(&blk[3], help3);
     if constexpr (PRE) atomicAdd(&blk[4], culled);
@@ -1532,8 +1540,9 @@ struct ort_ctx {
     uint64_t cont_cap;
     unsigned long long *d_scat_ctl;      // kScatCtlWords: the pipeline's work heads and slot counter (TraceArgs.scat_ctl)
     int n_cus;                   // compute units of the device (one workgroup of scatter_front_kernel each)
-    double ring_cull;            // TraceArgs.cull of the staged system (ring_cull_threshold), +inf: no culling
+    double ring_cull;            // squared-radius threshold of the staged system (ring_cull_threshold), +inf: no culling
     float ring_cullf;
+    uint32_t ring_cull_word, ring_cull_wordf;      // TraceArgs.cull_word / cull_wordf (cull_word_of)
     hipEvent_t ev[3][2];
     hipEvent_t ring[kTimingRing][2];   // fused-trace launches, most recent kTimingRing
     unsigned long long ring_count;
@@ -1559,7 +1568,7 @@ static bool matches(const ort_system *sys)
     return true;
 }
 
-// TraceArgs.cull for the ring programs' segment 0: radius^2 (1 + margin) of the plano-convex aperture if
+// Threshold on rr for the ring programs' segment 0: radius^2 (1 + margin) of the plano-convex aperture if
 // the geometry the argument needs holds for this system, else +inf.  With the aim point T on the plane
 // z = zt (ring_lens_z), the start point P (|P.xy| <= sqrt(r2), P.z in [zmin, zmax] on the bottle) and
 // the flat face at zp, the ray crosses the face at P + (T - P) s, s = (zp - P.z) / (zt - P.z):
@@ -1567,6 +1576,31 @@ static bool matches(const ort_system *sys)
 // (so |s - 1| <= 1e-9), the start points inside the aperture (|P.xy| < radius), a real bottle point
 // under every start point.  The crossing point's squared radius then differs from rr by less than
 // 3e-9 rr + rounding (1e-14 in fp64, 1e-5 in fp32, which also moves zp by an ulp): margins 1e-6 / 1e-3.
+// The largest 32-bit draw word w whose ray is NOT culled: rr(w) > cull is false.  rr(w) is formed with the operations of
+// emit_ring and of the kernel's arithmetic (fp64 — also the fast fp64, whose product + 0 is the same value —: u = w 2^-32;
+// fp32: u = (w >> 8) 2^-24), compiled here with the same -ffp-contract=off; it does not decrease with w, so a bisection
+// finds the border.  0xffffffff when no word is culled.
+template <class T> static uint32_t cull_word_of(T r2, T cull)
+{
+    auto dies = [&](uint32_t w) {
+        volatile T u;
+        if (sizeof(T) == 8) u = (T)((double)w * 0x1p-32);
+        else u = (T)((float)(w >> 8) * 0x1.0p-24f);
+        volatile T span = r2 - T(0.);
+        volatile T prod = u * span;
+        volatile T rr = T(0.) + prod;
+        return rr > cull;
+    };
+    if (!dies(0xffffffffu)) return 0xffffffffu;
+    if (dies(0u)) return 0xffffffffu;              // (cannot happen: rr(0) = 0 and cull > 0) nothing is culled
+    uint32_t lo = 0u, hi = 0xffffffffu;            // lo survives, hi dies
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (dies(mid)) hi = mid; else lo = mid;
+    }
+    return lo;
+}
+
 static void ring_cull_threshold(const ort_system *sys, bool is_ring_program, double *cull, float *cullf)
 {
     *cull = HUGE_VAL; *cullf = HUGE_VALF;
@@ -1632,6 +1666,8 @@ static void note_system(ort_ctx *c, const ort_system *sys)
 #undef ORT_MATCH
     if (getenv("ORT_NO_PROGRAMS")) c->prog[0] = c->prog[1] = PROG_GENERIC;      // development knob (A/B)
     ring_cull_threshold(sys, c->prog[0] != PROG_GENERIC && sys->emitter[0] == ORT_EMIT_RING, &c->ring_cull, &c->ring_cullf);
+    c->ring_cull_word = cull_word_of<double>(sys->ring_lens_r2, c->ring_cull);
+    c->ring_cull_wordf = cull_word_of<float>((float)sys->ring_lens_r2, c->ring_cullf);
 }
 
 // system + derived per-surface constants -> the next device slot, asynchronously (the staging copy is the
@@ -2022,8 +2058,8 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     const bool culling = (c->variant & 8) == 0;                 // bit 3: A/B knob, ring rays are all emitted
     a0.strict = ((c->variant & 64) != 0 && c->precision == 0) ? 1 : 0;
     a0.wide = (c->variant & 32) ? 1 : 0;
-    a0.cull = culling ? c->ring_cull : HUGE_VAL;
-    a0.cullf = culling ? c->ring_cullf : HUGE_VALF;
+    a0.cull_word = culling ? c->ring_cull_word : 0xffffffffu;
+    a0.cull_wordf = culling ? c->ring_cull_wordf : 0xffffffffu;
     if (a0.first_ray > ORT_MAX_RAY_INDEX || a0.n_rays > ORT_MAX_RAY_INDEX - a0.first_ray)
         return fail(ORT_E_INVALID, "ray indices reach beyond 2^40 (ORT_MAX_RAY_INDEX): the keyed draw counter holds 40 bits of ray index");
     if (a0.n_rays == 0) return ORT_OK;
