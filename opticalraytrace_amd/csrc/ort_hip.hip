@@ -51,7 +51,10 @@ constexpr int kBlock = 256;
 #define ORT_MIN_WAVES 1
 #endif
 constexpr int kTimingRing = 64;         // launches kept by ort_kernel_times
-constexpr int kReplicas = 8;            // image replicas, one per XCD (a power of two: xcc_id masks with it)
+#ifndef ORT_REPLICAS
+#define ORT_REPLICAS 8
+#endif
+constexpr int kReplicas = ORT_REPLICAS;  // image replicas (a power of two >= 8: replica_id masks with it)
 // A replica stores one layer in 2^18 slots; bin i lives in slot (i * kSlotMul) mod 2^18 (a bijection:
 // the multiplier is odd), so neighbouring bins — the focal blob — land in unrelated 64-byte lines.
 constexpr int kSlotBits = 18;
@@ -123,6 +126,11 @@ struct TraceArgs {
     uint64_t scat_share;
     uint32_t scat_grab;
     const long long *img_cdf;    // image-source table or null
+    // fp32 queued kernels: hits are LOGGED, not binned (see bin_log_kernel).  A wave writes the bins of its hits to the
+    // bottom of its own region of the log — entries [lo, lo + hits) of its ray range [lo, hi): a ray ends at most once —
+    // and leaves (lo << 32 | hits) in the directory, one word per wave of the grid
+    uint32_t *hit_log;
+    unsigned long long *hit_dir;
     double *path;                // [n][ORT_MAX_PATH][3] or null (tracker)
     int32_t *npath;
 };
@@ -207,17 +215,24 @@ __device__ inline void stage_aux(SurfAuxT<T> *aux, const Surf *surf, int ns)
 // bins are scattered over 2^18 slots by a multiplicative hash: every hot bin gets a line of its own
 // and the load spreads over all channels, whatever the placement.  fold_kernel undoes the hash.
 // Integer adds commute: the image is bit-identical either way.
-__device__ inline int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & (kReplicas - 1); }   // hwreg(HW_REG_XCC_ID, 0, 4)
+__device__ inline int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7; }   // hwreg(HW_REG_XCC_ID, 0, 4)
+__device__ inline int replica_id() { return (xcc_id() | ((int)blockIdx.x << 3)) & (kReplicas - 1); }
 
 __device__ inline void bin_hit(int32_t *layer, int xp, int yp, bool replicated)
 {
     const uint32_t bin = (uint32_t)((xp + 200) + ORT_IMAGE_N * (yp + 200));         // imageMod.f90:55-56
+#ifdef ORT_DEV_NO_BIN                                                                // A/B build: what the image atomics cost
+    if (xp != 0x7fffffff) return;
+#endif
+#ifdef ORT_DEV_WG_ATOMICS
+    if (replicated) { __hip_atomic_fetch_add(&layer[(bin * kSlotMul) & (kSlots - 1)], 1, __ATOMIC_RELAXED, ORT_DEV_WG_ATOMICS); return; }
+#endif
     atomicAdd(&layer[replicated ? (bin * kSlotMul) & (kSlots - 1) : bin], 1);
 }
 
 __device__ inline int32_t *hist_layer(const TraceArgs &a)
 {
-    if (a.replicas) return a.replicas + (size_t)xcc_id() * kReplicaInts + (size_t)(a.phase - 1) * kSlots;
+    if (a.replicas) return a.replicas + (size_t)replica_id() * kReplicaInts + (size_t)(a.phase - 1) * kSlots;
     return a.image + (size_t)(a.phase - 1) * ORT_IMAGE_N * ORT_IMAGE_N;
 }
 
@@ -239,6 +254,71 @@ __global__ __launch_bounds__(256) void fold_kernel(int32_t *image, int32_t *repl
             if (v) { s += v; *p = 0; }
         }
         if (s) img[bin] += s;
+    }
+}
+
+// The image atomics are performed at the memory side — one DRAM read-modify-write per hit, whatever the scope of the
+// atomic, the number of replicas or their layout beyond "one hot bin per line" (profiles/r04/atomics_ab.log) — at ~21
+// per ns for the whole device.  The fp64 kernels produce 14 hits per ns and do not notice; the fp32 point program would
+// produce 32 and was BOUND by them (0.202 ms per 1e7 rays against 0.132 with the atomic compiled out).  So the fp32
+// queued kernels write the bin of every hit to a log with plain coalesced stores (4 B per hit), and this kernel bins
+// the log of a launch in LDS: workgroup (u, t) takes the waves [u wpu, (u + 1) wpu) of the traced grid and tile t of
+// the layer (the bins with bin % kBinTiles == t: 126 KB of LDS counters), reads the directory slice once, then every wave of it streams
+// one traced wave's entries at a time; the tile's counts are then ADDED — plain loads and stores, no atomic — to slab u
+// of the layer, which this workgroup alone touches during the launch (launches are ordered by the stream).
+// fold_slabs_kernel sums the kBinUnits slabs into the image when it is next needed (flush_replicas).
+// Integer adds commute: the image equals the one the atomics would have produced, bit for bit.
+constexpr int kBinUnits = 51, kBinTiles = 5, kBinTile = (ORT_IMAGE_N * ORT_IMAGE_N + kBinTiles - 1) / kBinTiles, kBinDirMax = 2048;
+constexpr int kBinThreads = 1024;
+__global__ __launch_bounds__(kBinThreads) void bin_log_kernel(const uint32_t *log, const unsigned long long *dir, uint32_t nwaves,
+                                                               uint32_t wpu, int32_t *slabs)
+{
+    __shared__ int32_t H[kBinTile];
+    __shared__ unsigned long long D[kBinDirMax];
+    const uint32_t w0 = blockIdx.x * wpu, w1 = w0 + wpu < nwaves ? w0 + wpu : nwaves;
+    const uint32_t nd = w1 > w0 ? w1 - w0 : 0u;
+    for (uint32_t j = threadIdx.x; j < (uint32_t)kBinTile; j += kBinThreads) H[j] = 0;
+    for (uint32_t j = threadIdx.x; j < nd; j += kBinThreads) D[j] = dir[w0 + j];
+    __syncthreads();
+    // tile t = the bins with bin % kBinTiles == t: the focal blob spreads evenly over the tiles' workgroups
+    const uint32_t tile = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    auto count = [&](uint32_t b) { if (b % (uint32_t)kBinTiles == tile) atomicAdd(&H[b / (uint32_t)kBinTiles], 1); };
+    for (uint32_t r = wave; r < nd; r += kBinThreads / 64) {
+        const uint32_t base = (uint32_t)(D[r] >> 32), cnt = (uint32_t)D[r];
+        // four entries per lane and load (a wave's region starts at a multiple of 64 entries; the log is padded)
+        for (uint32_t j = lane * 4u; j < cnt; j += 256u) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(log + base + j);
+            count(v.x);
+            if (j + 1u < cnt) count(v.y);
+            if (j + 2u < cnt) count(v.z);
+            if (j + 3u < cnt) count(v.w);
+        }
+    }
+    __syncthreads();
+    const uint32_t nb = ORT_IMAGE_N * ORT_IMAGE_N;
+    int32_t *slab = slabs + (size_t)blockIdx.x * nb;
+    for (uint32_t j = threadIdx.x; j < (uint32_t)kBinTile; j += kBinThreads) {
+        const int v = H[j];
+        const uint32_t bin = j * (uint32_t)kBinTiles + tile;
+        if (v != 0 && bin < nb) slab[bin] += v;
+    }
+}
+
+// image[layer] += sum of the layer's slabs; the slabs are left zero
+__global__ __launch_bounds__(256) void fold_slabs_kernel(int32_t *image, int32_t *slabs, int phase)
+{
+    const uint32_t nb = ORT_IMAGE_N * ORT_IMAGE_N;
+    int32_t *img = image + (size_t)(phase - 1) * nb;
+    int32_t *sl = slabs + (size_t)(phase - 1) * kBinUnits * nb;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nb; j += gridDim.x * blockDim.x) {
+        int s = 0;
+        for (int u = 0; u < kBinUnits; ++u) {
+            int32_t *p = sl + (size_t)u * nb + j;
+            const int v = *p;
+            if (v) { s += v; *p = 0; }
+        }
+        if (s) img[j] += s;
     }
 }
 
@@ -827,14 +907,18 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     constexpr int OPT = fixed ? ((MODE == MODE_FUSED ? OPT_UNIT_DIR : 0) | OPT_ON_AXIS | (axial ? OPT_AXIAL_START : 0) |
                                  (MODE == MODE_CONTINUE ? OPT_COUNT_STEPS : 0)) : 0;
     constexpr bool tagged = fixed && MODE != MODE_CONTINUE;     // st = ORT_ST_* | intersections << 8
+    // fp32: the hits go to the launch's log instead of the image (bin_log_kernel: the memory-side atomics bound this kernel)
+    constexpr bool LOG = kLoose<T> && MODE != MODE_CONTINUE;
+    const bool logging = LOG && a.hit_log != nullptr;           // the host's choice per launch (launch_trace)
     unsigned int lost = 0, isect = 0, binned = 0, help3 = 0, culled = 0;
+    unsigned int hits = 0;            // LOG: entries this wave has written (wave-uniform)
     auto finish = [&](int st_in, int nis_in, int xp, int yp) {
         const int st = tagged ? status_code(st_in) : st_in;
         const int nis = tagged ? status_isect(st_in) : nis_in;
         isect += (unsigned)nis;
         if (st == ORT_ST_BINNED) {
             binned++;
-            bin_hit(layer, xp, yp, a.replicas != nullptr);
+            if (!logging) bin_hit(layer, xp, yp, a.replicas != nullptr);
         } else if (st >= ORT_ST_LOST_BOTTLE) {
             lost++;                                                          // optics_system.f90:32,42; main.f90:151
             if (st == ORT_ST_HELP3) help3++;
@@ -844,6 +928,13 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     // predicate) leaves this kernel without any side effect: its index goes to the re-run list
     // and trace_kernel<literal> traces it from the start afterwards.  ~4e-6 of the rays.
     auto defer = [&](uint64_t i) { a.redo_list[atomicAdd(&a.redo_ctl[0], 1u)] = (uint32_t)(a.defer_base + i); };
+    // LOG: called by the whole wave (uniform control flow) with `hit` = this lane's ray ended binned in this pass
+    auto log_hits = [&](bool hit, int st_in, int xp, int yp) {
+        hit = hit && (tagged ? status_code(st_in) : st_in) == ORT_ST_BINNED;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (hit) a.hit_log[lo + hits + (unsigned)lane_prefix(m)] = (uint32_t)((xp + 200) + ORT_IMAGE_N * (yp + 200));   // imageMod.f90:55-56
+        hits += (unsigned)__popcll(m);
+    };
 
     uint64_t next = lo;
     int img_hint = -1;           // image source: the cell of the previous batch's first ray (emit_image)
@@ -889,6 +980,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
                 if (DEFER && rare) defer(sdraws ? (uint64_t)dw : d.ray_of_packed(dw, a.rng_base) - a.first_ray);
                 else finish(st, nis, xp, yp);
             }
+            if constexpr (LOG) { if (logging) log_hits(act, st, xp, yp); }      // (fp32 defers nothing)
             __builtin_amdgcn_wave_barrier();
         } else if (cand_ready || (!PRE && have_new)) {
             // ---- segment 1 on 64 fresh rays (ring programs: on up to 64 rays that passed segment 0)
@@ -976,6 +1068,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             } else if (act) {
                 finish(st, nis, xp, yp);
             }
+            if constexpr (LOG) { if (logging) log_hits(act && !survive, st, xp, yp); }
             qcount += __popcll(mask);
             __builtin_amdgcn_wave_barrier();
         } else if (PRE && have_new) {
@@ -1014,6 +1107,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             break;
         }
     }
+    if (logging && lane == 0) a.hit_dir[(size_t)blockIdx.x * kWavesPerBlock + wave] = ((unsigned long long)lo << 32) | hits;
     if (PRE && lane == 0) { lost += culled_wave; isect += culled_wave; culled = culled_wave; }   // src/optics_system.f90:42 (lost), one intersection each
     atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect);
     atomicAdd(&blk[2], binned); atomicAdd(&blk[3], help3);
@@ -1515,6 +1609,12 @@ struct ort_ctx {
     int32_t *d_image, *own_image;
     int32_t *d_replicas;         // kReplicas x 2 layers x kSlots: hits not yet folded into the image
     bool fold_pending[2];        // per layer: the replicas hold hits (fold_kernel runs when the image is needed)
+    // fp32 queued launches (bin_log_kernel): the hit log of one launch, its directory, the slabs [2][kBinUnits][bins]
+    uint32_t *d_hit_log;
+    unsigned long long *d_hit_dir;
+    uint64_t hit_log_cap, hit_dir_cap;
+    int32_t *d_slabs;
+    bool slab_pending[2];
     hipEvent_t launch_ev[2];     // start / stop events the next kernel launch carries itself (null: none)
     // deferral group: consecutive fused launches of one phase / seed / system whose deferred rays share
     // the re-run list; the literal re-run is launched when the group closes (close_group)
@@ -1731,6 +1831,12 @@ static int flush_replicas(ort_ctx *c)
         HIP_TRY(hipGetLastError());
         c->fold_pending[p] = false;
     }
+    for (int p = 0; p < 2; ++p) {
+        if (!c->slab_pending[p]) continue;
+        hipLaunchKernelGGL(fold_slabs_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_slabs, p + 1);
+        HIP_TRY(hipGetLastError());
+        c->slab_pending[p] = false;
+    }
     return ORT_OK;
 }
 
@@ -1864,6 +1970,7 @@ int ort_destroy(ort_ctx *c)
     (void)hipFree(c->d_redo_list); (void)hipFree(c->d_redo_ctl); (void)hipFree(c->d_work);
     (void)hipFree(c->d_cont_pos_dir); (void)hipFree(c->d_cont_draw); (void)hipFree(c->d_cont_nis); (void)hipFree(c->d_cont_t);
     (void)hipFree(c->d_scat_ctl);
+    (void)hipFree(c->d_hit_log); (void)hipFree(c->d_hit_dir); (void)hipFree(c->d_slabs);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ORT_OK;
@@ -2031,6 +2138,40 @@ static uint32_t scatter_grab(uint64_t n, unsigned groups)
     if (forced > 0) g = (uint64_t)forced;
     return (uint32_t)(64 * g);
 }
+// fp32 queued launches: the hit log of one launch (4 B per ray of the launch), the directory (one word per traced wave),
+// and — once — the slabs the binning kernel accumulates into (2 layers x kBinUnits x 643 KB = 82 MB of the 288 GB)
+static int reserve_hit_log(ort_ctx *c, uint64_t rays, uint64_t nwaves)
+{
+    if (rays > c->hit_log_cap || nwaves > c->hit_dir_cap || !c->d_slabs) {
+        { const int rc = close_group(c); if (rc) return rc; }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (rays > c->hit_log_cap) {
+        (void)hipFree(c->d_hit_log); c->d_hit_log = nullptr; c->hit_log_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_hit_log, (rays + 4) * sizeof(uint32_t)));   // (+4: bin_log_kernel reads four entries at a time)
+        c->hit_log_cap = rays;
+    }
+    if (nwaves > c->hit_dir_cap) {
+        (void)hipFree(c->d_hit_dir); c->d_hit_dir = nullptr; c->hit_dir_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_hit_dir, nwaves * sizeof(unsigned long long)));
+        c->hit_dir_cap = nwaves;
+    }
+    if (!c->d_slabs) {
+        const size_t bytes = (size_t)2 * kBinUnits * ORT_IMAGE_N * ORT_IMAGE_N * sizeof(int32_t);
+        HIP_TRY(hipMalloc(&c->d_slabs, bytes));
+        HIP_TRY(hipMemsetAsync(c->d_slabs, 0, bytes, c->stream));
+    }
+    return ORT_OK;
+}
+
+// does this launch go to an fp32 instantiation of trace_queue_kernel (launch_one's own decision)?
+static bool fp32_queued_launch(const ort_ctx *c, int mode, int phase, bool queued, bool anysrc)
+{
+    if (c->precision != 1 || !queued || mode == MODE_DEBUG) return false;
+    if (!anysrc) return true;
+    return mode == MODE_FUSED && !c->scatter[phase - 1] && c->prog[phase - 1] > PROG_LIST_MASK;
+}
+
 static int reserve_handover(ort_ctx *c, uint64_t n_rays)
 {
     // every ray of a launch can be handed over, and every wavefront leaves up to one chunk of slots partly used
@@ -2078,7 +2219,13 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     // scattering media, exact fp64, the default kernel variant: the three-stage pipeline (scatter_front_kernel)
     const bool pipeline = mode == MODE_FUSED && deferring && c->precision == 0 && c->scatter[a0.phase - 1] &&
                           c->scat_k0[a0.phase - 1] > 0 && (c->variant & 16) == 0;
-    const uint64_t step = pipeline ? scatter_chunk() : (deferring ? kChunkRays : total);
+    // (a queued launch indexes its rays with 32 bits)
+    const uint64_t step = pipeline ? scatter_chunk() : (queued ? kChunkRays : total);
+    // fp32 hit log: worth its second kernel (~10 us + the launch gap) where a large share of the rays is binned — the point loop
+    // (42 % of its rays: -17 % per step); the ring loop bins 1 % of its rays and keeps the atomics.  ORT_HIT_LOG = 1 never,
+    // 2 the point loop (default), 3 both loops (development knob; the image is the same bit for bit)
+    static const int hit_log_mode = env_int("ORT_HIT_LOG", 2);
+    const bool logging = fp32_queued_launch(c, mode, a0.phase, queued, anysrc) && hit_log_mode >= (a0.phase == 2 ? 2 : 3);
     if (pipeline) {
         const int rc = reserve_handover(c, total);
         if (rc) return rc;
@@ -2097,7 +2244,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     // hands the pair to the launch itself (hipExtLaunchKernel: start / stop of that dispatch, no
     // packet of its own); every separate event record is a packet the command processor handles
     // between two kernels (~2 us each at 1e7 rays per launch).
-    const bool one_launch = total <= step && !pipeline;        // the pipeline is two kernels per launch
+    const bool one_launch = total <= step && !pipeline && !logging;    // the pipeline and the fp32 hit log are two kernels per launch
     const bool ext_timed = c->timing && evk == 0 && one_launch;
     if (c->timing && evk > 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
     if (c->timing && evk == 0 && !ext_timed) HIP_TRY(hipEventRecord(c->ring[slot][0], c->stream));
@@ -2143,6 +2290,19 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
             else
                 hipLaunchKernelGGL((trace_queue_kernel<MODE_CONTINUE, true, false, double, PROG_GENERIC, false>), dim3(grid), dim3(kBlock), 0,
                                    c->stream, a);
+        } else if (logging) {
+            const uint64_t nwaves = (uint64_t)grid * kWavesPerBlock;
+            { const int rc = reserve_hit_log(c, a.n_rays, nwaves); if (rc) return rc; }
+            a.hit_log = c->d_hit_log; a.hit_dir = c->d_hit_dir;
+            launch_one(c, mode, a, grid, queued, filt, anysrc);
+            HIP_TRY(hipGetLastError());
+            const uint32_t units = nwaves < (uint64_t)kBinUnits ? (uint32_t)nwaves : (uint32_t)kBinUnits;
+            const uint32_t wpu = (uint32_t)((nwaves + units - 1) / units);
+            if (wpu > (uint32_t)kBinDirMax) return fail(ORT_E_INVALID, "fp32 hit log: the launch has more waves than the binning kernel's directory slice holds");
+            hipLaunchKernelGGL(bin_log_kernel, dim3(units, kBinTiles), dim3(kBinThreads), 0, c->stream, (const uint32_t *)c->d_hit_log,
+                               (const unsigned long long *)c->d_hit_dir, (uint32_t)nwaves, wpu,
+                               c->d_slabs + (size_t)(a.phase - 1) * kBinUnits * ORT_IMAGE_N * ORT_IMAGE_N);
+            c->slab_pending[a.phase - 1] = true;
         } else
         launch_one(c, mode, a, grid, queued, filt, anysrc);
         c->launch_ev[0] = c->launch_ev[1] = nullptr;
