@@ -126,11 +126,14 @@ struct TraceArgs {
     uint64_t scat_share;
     uint32_t scat_grab;
     const long long *img_cdf;    // image-source table or null
-    // fp32 queued kernels: hits are LOGGED, not binned (see bin_log_kernel).  A wave writes the bins of its hits to the
-    // bottom of its own region of the log — entries [lo, lo + hits) of its ray range [lo, hi): a ray ends at most once —
-    // and leaves (lo << 32 | hits) in the directory, one word per wave of the grid
-    uint32_t *hit_log;
-    unsigned long long *hit_dir;
+    // fp32 queued kernels: hits are LOGGED, not binned (see bin_log_kernel).  The log has kBinTiles parts of hit_stride
+    // 16-bit entries, part t for the bins with bin % kBinTiles == t (entry = bin / kBinTiles).  A wave writes its hits to
+    // the bottom of its own region of each part — entries [lo, lo + hits_t) of its ray range [lo, hi): a ray ends at
+    // most once — and leaves hits_0 .. hits_4 and lo in its eight words of the directory
+    uint16_t *hit_log;
+    uint64_t hit_stride;
+    uint32_t hit_base;           // this launch's first entry in every part (the log holds several launches: bin_pending)
+    uint32_t *hit_dir;           // this launch's first directory entry
     double *path;                // [n][ORT_MAX_PATH][3] or null (tracker)
     int32_t *npath;
 };
@@ -261,47 +264,94 @@ __global__ __launch_bounds__(256) void fold_kernel(int32_t *image, int32_t *repl
 // atomic, the number of replicas or their layout beyond "one hot bin per line" (profiles/r04/atomics_ab.log) — at ~21
 // per ns for the whole device.  The fp64 kernels produce 14 hits per ns and do not notice; the fp32 point program would
 // produce 32 and was BOUND by them (0.202 ms per 1e7 rays against 0.132 with the atomic compiled out).  So the fp32
-// queued kernels write the bin of every hit to a log with plain coalesced stores (4 B per hit), and this kernel bins
-// the log of a launch in LDS: workgroup (u, t) takes the waves [u wpu, (u + 1) wpu) of the traced grid and tile t of
-// the layer (the bins with bin % kBinTiles == t: 126 KB of LDS counters), reads the directory slice once, then every wave of it streams
-// one traced wave's entries at a time; the tile's counts are then ADDED — plain loads and stores, no atomic — to slab u
+// queued kernels write every hit to a log with plain coalesced stores (2 B per hit, sorted into kBinTiles parts by
+// bin % kBinTiles), and this kernel bins the log of a launch in LDS: workgroup (u, t) takes the waves [u wpu, (u + 1) wpu)
+// of the traced grid and part t (126 KB of LDS counters for its 32 161 bins — the focal blob spreads evenly over the
+// parts), reads the directory slice once, then every wave of it streams the traced waves' entries; the counts are
+// then ADDED — plain loads and stores, no atomic — to slab u
 // of the layer, which this workgroup alone touches during the launch (launches are ordered by the stream).
 // fold_slabs_kernel sums the kBinUnits slabs into the image when it is next needed (flush_replicas).
 // Integer adds commute: the image equals the one the atomics would have produced, bit for bit.
 constexpr int kBinUnits = 51, kBinTiles = 5, kBinTile = (ORT_IMAGE_N * ORT_IMAGE_N + kBinTiles - 1) / kBinTiles, kBinDirMax = 2048;
-constexpr int kBinThreads = 1024;
-__global__ __launch_bounds__(kBinThreads) void bin_log_kernel(const uint32_t *log, const unsigned long long *dir, uint32_t nwaves,
+constexpr int kBinThreads = 1024, kBinDirWords = 8;
+static_assert(kBinTile <= 65536, "a log entry (bin / kBinTiles) must fit 16 bits");
+__global__ __launch_bounds__(kBinThreads) void bin_log_kernel(const uint16_t *log, uint64_t stride, const uint32_t *dir, uint32_t nwaves,
                                                                uint32_t wpu, int32_t *slabs)
 {
     __shared__ int32_t H[kBinTile];
     __shared__ unsigned long long D[kBinDirMax];
+    const uint32_t tile = blockIdx.y;
     const uint32_t w0 = blockIdx.x * wpu, w1 = w0 + wpu < nwaves ? w0 + wpu : nwaves;
     const uint32_t nd = w1 > w0 ? w1 - w0 : 0u;
     for (uint32_t j = threadIdx.x; j < (uint32_t)kBinTile; j += kBinThreads) H[j] = 0;
-    for (uint32_t j = threadIdx.x; j < nd; j += kBinThreads) D[j] = dir[w0 + j];
+    for (uint32_t j = threadIdx.x; j < nd; j += kBinThreads) {
+        const uint32_t *e = dir + (size_t)(w0 + j) * kBinDirWords;
+        D[j] = ((unsigned long long)e[kBinTiles] << 32) | e[tile];            // first entry of the wave's region << 32 | hits of this tile
+    }
     __syncthreads();
-    // tile t = the bins with bin % kBinTiles == t: the focal blob spreads evenly over the tiles' workgroups
-    const uint32_t tile = blockIdx.y;
+    const uint16_t *part = log + (size_t)tile * stride;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    auto count = [&](uint32_t b) { if (b % (uint32_t)kBinTiles == tile) atomicAdd(&H[b / (uint32_t)kBinTiles], 1); };
-    for (uint32_t r = wave; r < nd; r += kBinThreads / 64) {
-        const uint32_t base = (uint32_t)(D[r] >> 32), cnt = (uint32_t)D[r];
-        // four entries per lane and load (a wave's region starts at a multiple of 64 entries; the log is padded)
-        for (uint32_t j = lane * 4u; j < cnt; j += 256u) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(log + base + j);
-            count(v.x);
-            if (j + 1u < cnt) count(v.y);
-            if (j + 2u < cnt) count(v.z);
-            if (j + 3u < cnt) count(v.w);
+    // A wave streams TWELVE traced waves' regions at a time, eight entries per lane and load (a region starts at a multiple
+    // of 64 entries; the parts are padded): the loads of a step are in flight together — the kernel is a chain of memory
+    // round trips (directory, entries, slab), not of work
+    constexpr uint32_t W = kBinThreads / 64, G = 12;
+    for (uint32_t r = wave; r < nd; r += W * G) {
+        uint32_t base[G], cnt[G], most = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t rg = r + g * W;
+            const unsigned long long e = rg < nd ? D[rg] : 0ull;
+            base[g] = (uint32_t)(e >> 32); cnt[g] = (uint32_t)e;
+            most = cnt[g] > most ? cnt[g] : most;
+        }
+        for (uint32_t j = lane * 8u; j < most; j += 512u) {
+            uint4 v[G];
+#pragma unroll
+            for (uint32_t g = 0; g < G; ++g)
+                v[g] = j < cnt[g] ? *reinterpret_cast<const uint4 *>(part + base[g] + j) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (uint32_t g = 0; g < G; ++g) {
+                const uint32_t w4[4] = {v[g].x, v[g].y, v[g].z, v[g].w};
+#pragma unroll
+                for (uint32_t k = 0; k < 8; ++k)
+#ifdef ORT_DEV_BIN_NOATOM
+                    if (j + k < cnt[g] && ((w4[k >> 1] >> (16u * (k & 1u))) & 0xffffu) == 0xfffeu) atomicAdd(&H[0], 1);
+#else
+                    if (j + k < cnt[g]) atomicAdd(&H[(w4[k >> 1] >> (16u * (k & 1u))) & 0xffffu], 1);
+#endif
+            }
         }
     }
     __syncthreads();
     const uint32_t nb = ORT_IMAGE_N * ORT_IMAGE_N;
     int32_t *slab = slabs + (size_t)blockIdx.x * nb;
-    for (uint32_t j = threadIdx.x; j < (uint32_t)kBinTile; j += kBinThreads) {
-        const int v = H[j];
-        const uint32_t bin = j * (uint32_t)kBinTiles + tile;
-        if (v != 0 && bin < nb) slab[bin] += v;
+    // slab += H: the loads of a thread's bins first, all in flight together, then the stores (a load-add-store loop
+    // waits for one memory round trip per bin)
+    constexpr int PER = (kBinTile + kBinThreads - 1) / kBinThreads;
+    int add[PER], have[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t j = threadIdx.x + (uint32_t)k * kBinThreads;
+        add[k] = j < (uint32_t)kBinTile ? H[j] : 0;
+        have[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t bin = (threadIdx.x + (uint32_t)k * kBinThreads) * (uint32_t)kBinTiles + tile;
+#ifdef ORT_DEV_BIN_NOFLUSH
+        if (add[k] == 0x7fffffff && bin < nb) have[k] = __builtin_nontemporal_load(slab + bin);
+#else
+        if (add[k] != 0 && bin < nb) have[k] = __builtin_nontemporal_load(slab + bin);
+#endif
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t bin = (threadIdx.x + (uint32_t)k * kBinThreads) * (uint32_t)kBinTiles + tile;
+#ifdef ORT_DEV_BIN_NOFLUSH
+        if (add[k] == 0x7fffffff && bin < nb) slab[bin] = have[k] + add[k];
+#else
+        if (add[k] != 0 && bin < nb) slab[bin] = have[k] + add[k];
+#endif
     }
 }
 
@@ -911,7 +961,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     constexpr bool LOG = kLoose<T> && MODE != MODE_CONTINUE;
     const bool logging = LOG && a.hit_log != nullptr;           // the host's choice per launch (launch_trace)
     unsigned int lost = 0, isect = 0, binned = 0, help3 = 0, culled = 0;
-    unsigned int hits = 0;            // LOG: entries this wave has written (wave-uniform)
+    unsigned int hits[kBinTiles] = {0, 0, 0, 0, 0};            // LOG: entries this wave has written to each part (wave-uniform)
     auto finish = [&](int st_in, int nis_in, int xp, int yp) {
         const int st = tagged ? status_code(st_in) : st_in;
         const int nis = tagged ? status_isect(st_in) : nis_in;
@@ -931,9 +981,15 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     // LOG: called by the whole wave (uniform control flow) with `hit` = this lane's ray ended binned in this pass
     auto log_hits = [&](bool hit, int st_in, int xp, int yp) {
         hit = hit && (tagged ? status_code(st_in) : st_in) == ORT_ST_BINNED;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-        if (hit) a.hit_log[lo + hits + (unsigned)lane_prefix(m)] = (uint32_t)((xp + 200) + ORT_IMAGE_N * (yp + 200));   // imageMod.f90:55-56
-        hits += (unsigned)__popcll(m);
+        const uint32_t bin = (uint32_t)((xp + 200) + ORT_IMAGE_N * (yp + 200));   // imageMod.f90:55-56
+        const uint32_t part = bin % (uint32_t)kBinTiles, idx = bin / (uint32_t)kBinTiles;
+#pragma unroll
+        for (int t = 0; t < kBinTiles; ++t) {
+            const bool mine = hit && part == (uint32_t)t;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+            if (mine) a.hit_log[(size_t)t * a.hit_stride + a.hit_base + lo + hits[t] + (unsigned)lane_prefix(m)] = (uint16_t)idx;
+            hits[t] += (unsigned)__popcll(m);
+        }
     };
 
     uint64_t next = lo;
@@ -1107,7 +1163,12 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             break;
         }
     }
-    if (logging && lane == 0) a.hit_dir[(size_t)blockIdx.x * kWavesPerBlock + wave] = ((unsigned long long)lo << 32) | hits;
+    if (logging && lane == 0) {
+        uint32_t *e = a.hit_dir + ((size_t)blockIdx.x * kWavesPerBlock + wave) * kBinDirWords;
+#pragma unroll
+        for (int t = 0; t < kBinTiles; ++t) e[t] = hits[t];
+        e[kBinTiles] = a.hit_base + (uint32_t)lo;
+    }
     if (PRE && lane == 0) { lost += culled_wave; isect += culled_wave; culled = culled_wave; }   // src/optics_system.f90:42 (lost), one intersection each
     atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect);
     atomicAdd(&blk[2], binned); atomicAdd(&blk[3], help3);
@@ -1610,9 +1671,11 @@ struct ort_ctx {
     int32_t *d_replicas;         // kReplicas x 2 layers x kSlots: hits not yet folded into the image
     bool fold_pending[2];        // per layer: the replicas hold hits (fold_kernel runs when the image is needed)
     // fp32 queued launches (bin_log_kernel): the hit log of one launch, its directory, the slabs [2][kBinUnits][bins]
-    uint32_t *d_hit_log;
-    unsigned long long *d_hit_dir;
+    uint16_t *d_hit_log;         // kBinTiles parts of hit_log_cap entries
+    uint32_t *d_hit_dir;         // kBinDirWords words per traced wave
     uint64_t hit_log_cap, hit_dir_cap;
+    uint64_t hit_used, hit_waves;            // entries per part / directory entries the launches since the last binning hold
+    int hit_phase;                           // their layer (1 or 2), 0: the log is empty
     int32_t *d_slabs;
     bool slab_pending[2];
     hipEvent_t launch_ev[2];     // start / stop events the next kernel launch carries itself (null: none)
@@ -1822,6 +1885,7 @@ static int close_group(ort_ctx *c)
     return ORT_OK;
 }
 
+static int bin_pending(ort_ctx *c);
 static int flush_replicas(ort_ctx *c)
 {
     { const int rc = close_group(c); if (rc) return rc; }
@@ -1831,6 +1895,7 @@ static int flush_replicas(ort_ctx *c)
         HIP_TRY(hipGetLastError());
         c->fold_pending[p] = false;
     }
+    { const int rc = bin_pending(c); if (rc) return rc; }
     for (int p = 0; p < 2; ++p) {
         if (!c->slab_pending[p]) continue;
         hipLaunchKernelGGL(fold_slabs_kernel, dim3(256), dim3(256), 0, c->stream, c->d_image, c->d_slabs, p + 1);
@@ -2138,28 +2203,53 @@ static uint32_t scatter_grab(uint64_t n, unsigned groups)
     if (forced > 0) g = (uint64_t)forced;
     return (uint32_t)(64 * g);
 }
-// fp32 queued launches: the hit log of one launch (4 B per ray of the launch), the directory (one word per traced wave),
-// and — once — the slabs the binning kernel accumulates into (2 layers x kBinUnits x 643 KB = 82 MB of the 288 GB)
-static int reserve_hit_log(ort_ctx *c, uint64_t rays, uint64_t nwaves)
+// fp32 queued launches.  The hit log holds the launches since the last binning (kHitLogEntries 16-bit entries per part:
+// 0.67 GB of the 288 GB; a launch larger than that gets a log of its own size), the directory eight words per traced
+// wave, the slabs (2 layers x kBinUnits x 643 KB = 66 MB) what bin_log_kernel has accumulated since the last fold.
+// Binning is LAZY like the fold: bin_log_kernel costs ~20 us whatever the log holds (a chain of memory round trips, and
+// one scattered store per non-empty bin and unit), so the launches of a run append to the log and one kernel bins them
+// when the log or the directory is full, when the other layer's launch comes, or when the image is needed
+// (flush_replicas).  Tracing and binning are ordered by the stream.
+constexpr uint64_t kHitLogEntries = 1ull << 26;
+constexpr uint64_t kHitDirEntries = (uint64_t)kBinUnits * kBinDirMax;
+static int bin_pending(ort_ctx *c)
 {
-    if (rays > c->hit_log_cap || nwaves > c->hit_dir_cap || !c->d_slabs) {
-        { const int rc = close_group(c); if (rc) return rc; }
-        HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->hit_phase) return ORT_OK;
+    const uint64_t nwaves = c->hit_waves;
+    const uint32_t units = nwaves < (uint64_t)kBinUnits ? (uint32_t)nwaves : (uint32_t)kBinUnits;
+    const uint32_t wpu = (uint32_t)((nwaves + units - 1) / units);           // <= kBinDirMax: launch_trace bins before it could not be
+    hipLaunchKernelGGL(bin_log_kernel, dim3(units, kBinTiles), dim3(kBinThreads), 0, c->stream, (const uint16_t *)c->d_hit_log,
+                       (uint64_t)c->hit_log_cap, (const uint32_t *)c->d_hit_dir, (uint32_t)nwaves, wpu,
+                       c->d_slabs + (size_t)(c->hit_phase - 1) * kBinUnits * ORT_IMAGE_N * ORT_IMAGE_N);
+    HIP_TRY(hipGetLastError());
+    c->slab_pending[c->hit_phase - 1] = true;
+    c->hit_used = 0; c->hit_waves = 0; c->hit_phase = 0;
+    return ORT_OK;
+}
+
+// room for a launch of `rays` rays on `nwaves` waves of layer `phase` behind what the log holds (bins it first if not)
+static int reserve_hit_log(ort_ctx *c, int phase, uint64_t rays, uint64_t nwaves)
+{
+    if (nwaves > kHitDirEntries) return fail(ORT_E_INVALID, "fp32 hit log: the launch has more waves than the binning kernel's directory holds");
+    if (c->hit_phase && (c->hit_phase != phase || c->hit_used + rays + 8 > c->hit_log_cap || c->hit_waves + nwaves > kHitDirEntries)) {
+        const int rc = bin_pending(c);
+        if (rc) return rc;
     }
-    if (rays > c->hit_log_cap) {
-        (void)hipFree(c->d_hit_log); c->d_hit_log = nullptr; c->hit_log_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_hit_log, (rays + 4) * sizeof(uint32_t)));   // (+4: bin_log_kernel reads four entries at a time)
-        c->hit_log_cap = rays;
-    }
-    if (nwaves > c->hit_dir_cap) {
-        (void)hipFree(c->d_hit_dir); c->d_hit_dir = nullptr; c->hit_dir_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_hit_dir, nwaves * sizeof(unsigned long long)));
-        c->hit_dir_cap = nwaves;
-    }
-    if (!c->d_slabs) {
-        const size_t bytes = (size_t)2 * kBinUnits * ORT_IMAGE_N * ORT_IMAGE_N * sizeof(int32_t);
-        HIP_TRY(hipMalloc(&c->d_slabs, bytes));
-        HIP_TRY(hipMemsetAsync(c->d_slabs, 0, bytes, c->stream));
+    if (rays + 8 > c->hit_log_cap || !c->d_hit_dir || !c->d_slabs) {
+        HIP_TRY(hipStreamSynchronize(c->stream));            // (the log is empty here; a kernel may still be reading the old buffers)
+        if (rays + 8 > c->hit_log_cap) {
+            (void)hipFree(c->d_hit_log); c->d_hit_log = nullptr; c->hit_log_cap = 0;
+            const uint64_t want = rays + 8 > kHitLogEntries ? rays + 8 : kHitLogEntries;
+            const uint64_t cap = (want + 63) & ~63ull;          // (+8: bin_log_kernel reads eight entries at a time)
+            HIP_TRY(hipMalloc(&c->d_hit_log, (size_t)kBinTiles * cap * sizeof(uint16_t)));
+            c->hit_log_cap = cap;
+        }
+        if (!c->d_hit_dir) HIP_TRY(hipMalloc(&c->d_hit_dir, kHitDirEntries * kBinDirWords * sizeof(uint32_t)));
+        if (!c->d_slabs) {
+            const size_t bytes = (size_t)2 * kBinUnits * ORT_IMAGE_N * ORT_IMAGE_N * sizeof(int32_t);
+            HIP_TRY(hipMalloc(&c->d_slabs, bytes));
+            HIP_TRY(hipMemsetAsync(c->d_slabs, 0, bytes, c->stream));
+        }
     }
     return ORT_OK;
 }
@@ -2244,7 +2334,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     // hands the pair to the launch itself (hipExtLaunchKernel: start / stop of that dispatch, no
     // packet of its own); every separate event record is a packet the command processor handles
     // between two kernels (~2 us each at 1e7 rays per launch).
-    const bool one_launch = total <= step && !pipeline && !logging;    // the pipeline and the fp32 hit log are two kernels per launch
+    const bool one_launch = total <= step && !pipeline;        // the pipeline is two kernels per launch
     const bool ext_timed = c->timing && evk == 0 && one_launch;
     if (c->timing && evk > 0) HIP_TRY(hipEventRecord(c->ev[evk][0], c->stream));
     if (c->timing && evk == 0 && !ext_timed) HIP_TRY(hipEventRecord(c->ring[slot][0], c->stream));
@@ -2292,17 +2382,14 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
                                    c->stream, a);
         } else if (logging) {
             const uint64_t nwaves = (uint64_t)grid * kWavesPerBlock;
-            { const int rc = reserve_hit_log(c, a.n_rays, nwaves); if (rc) return rc; }
-            a.hit_log = c->d_hit_log; a.hit_dir = c->d_hit_dir;
+            { const int rc = reserve_hit_log(c, a.phase, a.n_rays, nwaves); if (rc) return rc; }
+            a.hit_log = c->d_hit_log; a.hit_stride = c->hit_log_cap;
+            a.hit_base = (uint32_t)c->hit_used;                              // a multiple of 64: the waves' regions stay aligned
+            a.hit_dir = c->d_hit_dir + c->hit_waves * kBinDirWords;
             launch_one(c, mode, a, grid, queued, filt, anysrc);
-            HIP_TRY(hipGetLastError());
-            const uint32_t units = nwaves < (uint64_t)kBinUnits ? (uint32_t)nwaves : (uint32_t)kBinUnits;
-            const uint32_t wpu = (uint32_t)((nwaves + units - 1) / units);
-            if (wpu > (uint32_t)kBinDirMax) return fail(ORT_E_INVALID, "fp32 hit log: the launch has more waves than the binning kernel's directory slice holds");
-            hipLaunchKernelGGL(bin_log_kernel, dim3(units, kBinTiles), dim3(kBinThreads), 0, c->stream, (const uint32_t *)c->d_hit_log,
-                               (const unsigned long long *)c->d_hit_dir, (uint32_t)nwaves, wpu,
-                               c->d_slabs + (size_t)(a.phase - 1) * kBinUnits * ORT_IMAGE_N * ORT_IMAGE_N);
-            c->slab_pending[a.phase - 1] = true;
+            c->hit_used = (c->hit_used + a.n_rays + 63) & ~63ull;
+            c->hit_waves += nwaves;
+            c->hit_phase = a.phase;
         } else
         launch_one(c, mode, a, grid, queued, filt, anysrc);
         c->launch_ev[0] = c->launch_ev[1] = nullptr;

@@ -163,3 +163,40 @@ def test_config4_fp32_full_size(ctx):
     assert abs(int(c32[3]) / n - 6.315) < 0.002 and abs(int(c32[2]) / n - 1.553) < 0.002
     assert int(i32.max()) < 2 ** 31 - 1
     _record(res, "fp32_config4_1e9.json")
+
+
+_HIT_LOG_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from conftest import make_system
+from opticalraytrace_amd.capi import Context
+_, osys = make_system(sys.argv[3])
+n = int(sys.argv[4])
+with Context(osys) as c:
+    c.set_precision(1)
+    c.trace(1, 0, n, 123456789); c.trace(2, 11, n, 123456789)
+    img, cnt = c.read()
+    c.trace(2, 11 + n, 1000, 123456789)          # and a small launch on top of the folded image
+    img2, cnt2 = c.read()
+np.savez(sys.argv[2], img=img, cnt=cnt, img2=img2, cnt2=cnt2)
+"""
+
+
+@pytest.mark.parametrize("name,n", [("large", (1 << 25) + 4321), ("large_crs", 400_000), ("large_image", 50_000)])
+def test_fp32_hit_log_modes_give_the_same_image(hip_library, tmp_path, name, n):
+    """The fp32 queued kernels either bin their hits with atomics or log them for bin_log_kernel (ORT_HIT_LOG: 1 never,
+    2 the point loop — the default —, 3 both loops; read once per process): integer adds commute, so the three images and
+    counter sets are identical — across a launch boundary (2^25 rays), for a source program and for the image source."""
+    import subprocess
+    import sys
+    got = []
+    for mode in ("1", "2", "3"):
+        out = str(tmp_path / f"m{mode}.npz")
+        env = {**os.environ, "ORT_HIT_LOG": mode}
+        r = subprocess.run([sys.executable, "-c", _HIT_LOG_CHILD, ROOT, out, name, str(n)], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(np.load(out))
+    for g in got[1:]:
+        for k in ("img", "cnt", "img2", "cnt2"):
+            assert np.array_equal(g[k], got[0][k]), (name, k)
+    assert int(got[0]["img"].sum()) == int(got[0]["cnt"][4]) + int(got[0]["cnt"][5])
