@@ -1593,14 +1593,13 @@ int env_int(const char *name, int dflt)
 // per launch (profiles/r02/range_plan_sweep.log): 1280 / 86 % / 6; 1024 or 1536 long workgroups
 // +2 %, 2560 / 92 % / 4 +3 %, equal ranges +5 %; at 2^25 rays per launch the choice is within
 // 0.5 %.  Small launches keep equal ranges.  Scheduling only: results do not depend on it.
-// The fp32 kernels (52 VGPRs, 14 KB of LDS per workgroup) fit 8 workgroups per CU: their long ranges go to 2048
-// (tools/headsweep.sh, profiles/r04/headsweep.log: 0.2094 -> 0.2023 ms per 1e7 point rays; the fp64 plan is confirmed).
-constexpr int kHeadBlocks = 1280, kHeadBlocksF32 = 2048, kHeadPercent = 86, kTailBatches = 6;
-int plan_ranges(TraceArgs &a, bool f32)
+// (The fp32 kernels fit 8 workgroups per CU; more long workgroups gained 3 % while the point program was bound by its image
+// atomics and lose 12 % in the ring loop now that it is not — profiles/r04/headsweep.log, hb.log: one plan for all.)
+constexpr int kHeadBlocks = 1280, kHeadPercent = 86, kTailBatches = 6;
+int plan_ranges(TraceArgs &a)
 {
-    static const int head_env = env_int("ORT_HEAD_BLOCKS", 0), head_pct = env_int("ORT_HEAD_PERCENT", kHeadPercent),
+    static const int head_blocks = env_int("ORT_HEAD_BLOCKS", kHeadBlocks), head_pct = env_int("ORT_HEAD_PERCENT", kHeadPercent),
                      tail_batches = env_int("ORT_TAIL_BATCHES", kTailBatches);
-    const int head_blocks = head_env > 0 ? head_env : (f32 ? kHeadBlocksF32 : kHeadBlocks);
     const uint64_t n = a.n_rays, per_block = 64ull * kWavesPerBlock;
     if (n < (uint64_t)head_blocks * per_block * 4 || head_pct >= 100) {       // equal ranges
         int grid = grid_for(n);
@@ -2344,7 +2343,7 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
         a.first_ray = a0.first_ray + off;
         if (a.pos_dir_in) a.pos_dir_in += off;              // same component stride (in_stride)
         // queued: every wave walks 64-aligned contiguous ranges (plan_ranges); lockstep: grid-stride
-        const int grid = queued ? plan_ranges(a, c->precision == 1) : grid_for(a.n_rays);
+        const int grid = queued ? plan_ranges(a) : grid_for(a.n_rays);
         if (deferring && mode == MODE_FUSED) {
             // fused launches share the re-run list of their group; the literal re-run comes when the
             // group closes (close_group)
