@@ -510,7 +510,7 @@ def main() -> int:
                                                                        "mul_f64", "add_f64", "trans_f64") if k in p} or None}
 
     def fp_roofline(kms, r, culled, peak, bound, kernels):
-        """per CALL here: the fp32 path is not cut into launches of 2^25 rays (nothing is deferred)"""
+        """(every queued call is cut into launches of at most 2^25 rays, whatever the arithmetic)"""
         ks = (sum(kms) / len(kms)) * 1e-3 / kernels
         i, _ = isect_binned(r)
         per_call = 1.0 / args.steps / world / len(phases)
@@ -622,13 +622,16 @@ def main() -> int:
         i32, b32 = isect_binned(r)
         out["fp32"] = {
             "value": i32 / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3, "dtype": "f32",
-            "roofline": {**fp_roofline(kms, r, cul, FP32_VEC_PEAK_TFLOPS, "valu_fp32", 1), **leg_counters("fp32")},
+            "roofline": {**fp_roofline(kms, r, cul, FP32_VEC_PEAK_TFLOPS, "valu_fp32", kernels_per_call), **leg_counters("fp32")},
             "image_l1_vs_exact": int(abs(r.image.astype("int64") - res.image.astype("int64")).sum()),
             "image_l1_vs_exact_frac_of_binned": float(abs(r.image.astype("int64") - res.image.astype("int64")).sum()) / max(binned_total, 1),
             "binned": b32, "binned_exact": binned_total, "intersections": i32, "intersections_exact": isect_total,
             "note": "ort_set_precision(1), BASELINE configs[4]: the path in single precision — hardware rcp / sqrt / rsq, fused "
                     "multiply-adds, the cheap decision forms without margins or deferrals; uniforms = top 24 bits of the same "
-                    "draws; tests/test_gpu_fp32.py holds the tolerance study",
+                    "draws; tests/test_gpu_fp32.py holds the tolerance study.  The point loop's hits are logged by the trace kernel "
+                    "and binned in LDS by bin_log_kernel once per several launches and at the flush inside the timed region "
+                    "(the memory-side image atomics bound the fp32 program: profiles/r04/atomics_ab.log); roofline.kernel_ms is "
+                    "the trace kernel, ms_per_step holds everything",
         }
     if "fast_fp64" in legs:
         el, kms, r, cul = legs["fast_fp64"]
