@@ -180,8 +180,16 @@ template <bool DYN> struct KeyedDrawsT : WideChoice<DYN> {
     __device__ inline double next() { const double u = peek(); c += 1ull; return u; }
     template <class T> __device__ inline T peek_as() const
     {
-        if (DYN && this->wide()) return wide_unit_from<T>(wide_hash(base, c));
-        return unit_from<T>(word());
+        if constexpr (DYN) {
+            // ONE hash and one conversion for both streams (the choice is wave-uniform, but a compiler that turns it into
+            // selects would otherwise hash twice per draw): x = the draw as a 53-bit integer — v2w: h >> 11; v2: its 32-bit
+            // word << 21, and w 2^21 2^-53 = w 2^-32 exactly as bits_to_unit forms it
+            const bool wd = this->wide();
+            const uint64_t h = mix64(base + kGolden * ((wd ? c : c >> 1) + 1ull));
+            const uint64_t x = wd ? h >> 11 : (uint64_t)draw_word(h, (c & 1ull) != 0) << 21;
+            if constexpr (sizeof(T) == 8) return T((double)(uint32_t)(x >> 32) * 0x1p-21 + (double)(uint32_t)x * 0x1p-53);
+            else return (float)(uint32_t)(x >> 29) * 0x1.0p-24f;         // the top 24 bits of either
+        } else return unit_from<T>(word());
     }
     template <class T> __device__ inline T next_as()
     {
