@@ -33,7 +33,7 @@ extern "C" {
 #define ORT_IMAGE_BINS (2 * 401 * 401)
 #define ORT_NUM_COUNTERS 8
 #define ORT_MAX_RAYS_PER_LAUNCH (1u << 25)  /* ort_trace / ort_trace_resident cut a call into kernel launches of at
-                                               most this many rays (fp64 paths; bounds the re-run list) */
+                                               most this many rays (bounds the re-run list and the 32-bit ray keys) */
 #define ORT_MAX_RAY_INDEX (1ull << 40)      /* global ray indices are below this (the keyed draw counter is
                                                (ray << 24) + draw); a call reaching beyond it is ORT_E_INVALID */
 
@@ -314,7 +314,7 @@ int ort_set_precision(ort_ctx *ctx, int precision);
  * as the reference's ran2() fills a real(8) (src/random_mod.f90:39-46), where the default stream ORT-RNG-v2 hands out
  * 32-bit draws, two per hash.  A different stream, therefore different rays (same statistics: tests/test_gpu_wide_draws.py
  * against the unmodified program); traced by the lockstep kernel (the surface programs and the scattering pipeline are
- * built on v2's pairs; ~1.5 x the time).  Every entry that draws honours it (ort_trace, ort_emit, ort_trace_resident,
+ * built on v2's pairs; ~2.5 x the time).  Every entry that draws honours it (ort_trace, ort_emit, ort_trace_resident,
  * ort_trace_rays with u == NULL, ort_trace_paths); the checker's keyed mode has the same switch.
  * Bit 6 set = STRICT LIBM EMITTERS (exact fp64 only): the light sources evaluate sin / cos through glibc 2.35's own
  * algorithms (csrc/ort_libm.h), entry by entry as the reference's compiled code calls them, so an emitted ray — and with it
