@@ -901,6 +901,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     int phase = a.phase, ns, split;
     if constexpr (fixed) {
         phase = Prog<PROG>::phase; ns = Prog<PROG>::n; split = queue_step<PROG, MODE>();   // host: match_program
+        static_assert(queue_step<PROG, MODE>() < Prog<PROG>::n, "segment 1 of a program must end in front of its image plane (the fp32 hit log relies on it)");
     } else {
         ns = S.n_surfaces[phase - 1];
         split = S.split[phase - 1];
@@ -1124,7 +1125,8 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
             } else if (act) {
                 finish(st, nis, xp, yp);
             }
-            if constexpr (LOG) { if (logging) log_hits(act && !survive, st, xp, yp); }
+            // (a surface program's segment 1 ends in front of its image plane: no ray is binned here)
+            if constexpr (LOG && !fixed) { if (logging) log_hits(act && !survive, st, xp, yp); }
             qcount += __popcll(mask);
             __builtin_amdgcn_wave_barrier();
         } else if (PRE && have_new) {
