@@ -51,10 +51,7 @@ constexpr int kBlock = 256;
 #define ORT_MIN_WAVES 1
 #endif
 constexpr int kTimingRing = 64;         // launches kept by ort_kernel_times
-#ifndef ORT_REPLICAS
-#define ORT_REPLICAS 8
-#endif
-constexpr int kReplicas = ORT_REPLICAS;  // image replicas (a power of two >= 8: replica_id masks with it)
+constexpr int kReplicas = 8;            // image replicas, one per XCD
 // A replica stores one layer in 2^18 slots; bin i lives in slot (i * kSlotMul) mod 2^18 (a bijection:
 // the multiplier is odd), so neighbouring bins — the focal blob — land in unrelated 64-byte lines.
 constexpr int kSlotBits = 18;
@@ -219,7 +216,6 @@ __device__ inline void stage_aux(SurfAuxT<T> *aux, const Surf *surf, int ns)
 // and the load spreads over all channels, whatever the placement.  fold_kernel undoes the hash.
 // Integer adds commute: the image is bit-identical either way.
 __device__ inline int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7; }   // hwreg(HW_REG_XCC_ID, 0, 4)
-__device__ inline int replica_id() { return (xcc_id() | ((int)blockIdx.x << 3)) & (kReplicas - 1); }
 
 __device__ inline void bin_hit(int32_t *layer, int xp, int yp, bool replicated)
 {
@@ -227,15 +223,12 @@ __device__ inline void bin_hit(int32_t *layer, int xp, int yp, bool replicated)
 #ifdef ORT_DEV_NO_BIN                                                                // A/B build: what the image atomics cost
     if (xp != 0x7fffffff) return;
 #endif
-#ifdef ORT_DEV_WG_ATOMICS
-    if (replicated) { __hip_atomic_fetch_add(&layer[(bin * kSlotMul) & (kSlots - 1)], 1, __ATOMIC_RELAXED, ORT_DEV_WG_ATOMICS); return; }
-#endif
     atomicAdd(&layer[replicated ? (bin * kSlotMul) & (kSlots - 1) : bin], 1);
 }
 
 __device__ inline int32_t *hist_layer(const TraceArgs &a)
 {
-    if (a.replicas) return a.replicas + (size_t)replica_id() * kReplicaInts + (size_t)(a.phase - 1) * kSlots;
+    if (a.replicas) return a.replicas + (size_t)xcc_id() * kReplicaInts + (size_t)(a.phase - 1) * kSlots;
     return a.image + (size_t)(a.phase - 1) * ORT_IMAGE_N * ORT_IMAGE_N;
 }
 
@@ -314,11 +307,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_log_kernel(const uint16_t *lo
                 const uint32_t w4[4] = {v[g].x, v[g].y, v[g].z, v[g].w};
 #pragma unroll
                 for (uint32_t k = 0; k < 8; ++k)
-#ifdef ORT_DEV_BIN_NOATOM
-                    if (j + k < cnt[g] && ((w4[k >> 1] >> (16u * (k & 1u))) & 0xffffu) == 0xfffeu) atomicAdd(&H[0], 1);
-#else
                     if (j + k < cnt[g]) atomicAdd(&H[(w4[k >> 1] >> (16u * (k & 1u))) & 0xffffu], 1);
-#endif
             }
         }
     }
@@ -338,20 +327,12 @@ __global__ __launch_bounds__(kBinThreads) void bin_log_kernel(const uint16_t *lo
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const uint32_t bin = (threadIdx.x + (uint32_t)k * kBinThreads) * (uint32_t)kBinTiles + tile;
-#ifdef ORT_DEV_BIN_NOFLUSH
-        if (add[k] == 0x7fffffff && bin < nb) have[k] = __builtin_nontemporal_load(slab + bin);
-#else
         if (add[k] != 0 && bin < nb) have[k] = __builtin_nontemporal_load(slab + bin);
-#endif
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const uint32_t bin = (threadIdx.x + (uint32_t)k * kBinThreads) * (uint32_t)kBinTiles + tile;
-#ifdef ORT_DEV_BIN_NOFLUSH
-        if (add[k] == 0x7fffffff && bin < nb) slab[bin] = have[k] + add[k];
-#else
         if (add[k] != 0 && bin < nb) slab[bin] = have[k] + add[k];
-#endif
     }
 }
 
