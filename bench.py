@@ -510,7 +510,7 @@ def main() -> int:
                                                                        "mul_f64", "add_f64", "trans_f64") if k in p} or None}
 
     def fp_roofline(kms, r, culled, peak, bound, kernels):
-        """(every queued call is cut into launches of at most 2^25 rays, whatever the arithmetic)"""
+        """(every queued call is cut into launches of at most 2^27 rays, whatever the arithmetic)"""
         ks = (sum(kms) / len(kms)) * 1e-3 / kernels
         i, _ = isect_binned(r)
         per_call = 1.0 / args.steps / world / len(phases)
@@ -566,11 +566,11 @@ def main() -> int:
             "achieved_executed": exec_tf, "frac_executed": exec_tf / FP64_VEC_PEAK_TFLOPS,
             "executed_flop_per_launch": exec_flop,
             "traffic": traffic,                                   # HBM bytes per launch, rocprofv3 PMC (or null)
-            "kernel": "trace_queue_kernel<MODE_FUSED, filtered, surface program> (one launch per <= 2^25 rays, timed by the "
+            "kernel": "trace_queue_kernel<MODE_FUSED, filtered, surface program> (one launch per <= 2^27 rays, timed by the "
                       "event pair the launch itself carries; the literal re-run of deferred rays — normally none — runs "
                       "once per group of launches, fold_kernel once per run when the image is read)",
             "kernel_ms": k_s * 1e3,                               # mean duration of ONE kernel launch
-            "kernel_launches_per_step": launches_per_step,        # phases x launches of <= 2^25 rays per ort_trace call
+            "kernel_launches_per_step": launches_per_step,        # phases x launches of <= 2^27 rays per ort_trace call
             "rays_per_kernel_launch": rays_launch,
             "flop_per_intersection": FLOP_PER_INTERSECTION,
             "flop_per_ring_emission": FLOP_PER_RING_EMISSION,

@@ -32,8 +32,9 @@ extern "C" {
 #define ORT_IMAGE_N 401
 #define ORT_IMAGE_BINS (2 * 401 * 401)
 #define ORT_NUM_COUNTERS 8
-#define ORT_MAX_RAYS_PER_LAUNCH (1u << 25)  /* ort_trace / ort_trace_resident cut a call into kernel launches of at
-                                               most this many rays (bounds the re-run list and the 32-bit ray keys) */
+#define ORT_MAX_RAYS_PER_LAUNCH (1u << 27)  /* ort_trace / ort_trace_resident cut a call into kernel launches of at
+                                               most this many rays (bounds the re-run list, the fp32 hit log and the
+                                               32-bit ray keys; every launch costs ~25 us of ramp and drain) */
 #define ORT_MAX_RAY_INDEX (1ull << 40)      /* global ray indices are below this (the keyed draw counter is
                                                (ray << 24) + draw); a call reaching beyond it is ORT_E_INVALID */
 

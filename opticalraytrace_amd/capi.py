@@ -20,7 +20,7 @@ IMAGE_N = 401
 IMAGE_BINS = 2 * IMAGE_N * IMAGE_N
 NUM_COUNTERS = 8
 MAX_PATH = 6                 # ORT_MAX_PATH
-MAX_RAYS_PER_LAUNCH = 1 << 25    # ORT_MAX_RAYS_PER_LAUNCH
+MAX_RAYS_PER_LAUNCH = 1 << 27    # ORT_MAX_RAYS_PER_LAUNCH
 
 ST_BINNED, ST_NA_REJECT, ST_OFF_GRID, ST_LOST_BOTTLE, ST_LOST_TELESCOPE, ST_HELP3, ST_NO_INTERSECTION = range(7)
 (C_LOST_RING, C_LOST_POINT, C_ISECT_RING, C_ISECT_POINT,

@@ -61,7 +61,7 @@ static_assert(((kSlotMul * kSlotMulInv) & (kSlots - 1)) == 1u, "kSlotMulInv must
 static_assert(ORT_IMAGE_N * ORT_IMAGE_N <= (int)kSlots, "a layer must fit the slot table");
 constexpr size_t kReplicaInts = 2 * (size_t)kSlots;   // both layers of one replica
 constexpr int kMaxBlocks = 256 * 12;    // grid cap of the lockstep kernels and of small queued launches (equal ranges)
-constexpr uint64_t kChunkRays = ORT_MAX_RAYS_PER_LAUNCH;   // rays per launch of the queued kernel (bounds the re-run list: 4 B per ray)
+constexpr uint64_t kChunkRaysMax = ORT_MAX_RAYS_PER_LAUNCH;   // rays per launch of the queued kernel (bounds the re-run list: 4 B per ray); see chunk_rays()
 constexpr int kRedoBlocks = 128;        // grid of the literal re-run kernel (it normally finds an empty list and returns)
 
 enum { MODE_FUSED = 0, MODE_RESIDENT = 1, MODE_DEBUG = 2, MODE_CONTINUE = 3 };
@@ -1566,6 +1566,19 @@ int env_int(const char *name, int dflt)
     return (e && atoi(e) > 0) ? atoi(e) : dflt;
 }
 
+// Rays per launch of the queued kernels: ORT_MAX_RAYS_PER_LAUNCH = 2^27 — every launch pays ~25 us of ramp and drain, and
+// launches of 2^25 rays cost the ring loop 8 % and the 1e9-ray layers 4 % against these (profiles/r04: ring1e8 1.90e11 ->
+// 2.07e11).  ORT_CHUNK_LOG2 (development knob, read once) makes them smaller: the tests cut small traces into several launches.
+uint64_t chunk_rays()
+{
+    static const uint64_t chunk = [] {
+        const int lg = env_int("ORT_CHUNK_LOG2", 27);
+        const uint64_t c = 1ull << (lg < 6 ? 6 : (lg > 27 ? 27 : lg));
+        return c < kChunkRaysMax ? c : kChunkRaysMax;
+    }();
+    return chunk;
+}
+
 // Ray ranges of a queued launch of n rays.  A launch of equal ranges ends with a partly filled last
 // round of workgroups: the chip runs at 2 waves per SIMD instead of 5-6 for the last ~10 % of the
 // time (measured: two launches overlapped on two streams took 10 % less than back to back).  So the
@@ -2135,13 +2148,13 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
 }
 
 // The re-run list holds one entry per ray of a deferral group.  A group must be able to take every
-// ray of a launch (launches cover at most kChunkRays); beyond that the list is sized for several
+// ray of a launch (launches cover at most chunk_rays()); beyond that the list is sized for several
 // launches, so that a run of back-to-back launches closes a group — one literal re-run launch —
 // only now and then: 8 launches of the largest size seen, at most 2^27 entries (512 MB of the 288 GB).
 constexpr uint64_t kListMax = 1ull << 27;
 static int reserve_list(ort_ctx *c, uint64_t n_rays)
 {
-    const uint64_t chunk = n_rays < kChunkRays ? n_rays : kChunkRays;
+    const uint64_t chunk = n_rays < chunk_rays() ? n_rays : chunk_rays();
     uint64_t want = 8 * chunk < kListMax ? 8 * chunk : kListMax;
     if (want < chunk) want = chunk;
     if (want > c->redo_cap) {
@@ -2156,11 +2169,12 @@ static int reserve_list(ort_ctx *c, uint64_t n_rays)
 }
 
 // Scratch of the scattering pipeline: one hand-over entry (68 bytes) per ray of a launch; launches of that path
-// cover at most 2^25 rays (ORT_MAX_RAYS_PER_LAUNCH; 2.3 GB of the 288 GB, allocated only as far as a trace needs it).
+// cover at most 2^27 rays (9 GB of the 288 GB, allocated only as far as a trace needs it).
 // Every launch ends with the longest random walks of its rays — one scattering event per pass of a wave, ~45 events
-// for the longest of 4e6 rays, ~0.2 ms that nothing else fills: 4e7 rays cost 0.140 / 0.133 / 0.125 ms per 1e6 rays in
-// launches of 2^24 / 2^25 / 2^26 (gpurun_out r4 sweep; round 3's figure was taken at 2^24).
-constexpr int kScatterChunkLog2 = 25;
+// for the longest of 4e6 rays: ~0.3 ms per launch that nothing else fills (time = 0.3 ms x launches + 0.116 ms per 1e6 rays,
+// profiles/r04/scatbench.log: 4e7 rays cost 0.138 / 0.131 / 0.125 ms per 1e6 rays in launches of 2^24 / 2^25 / 2^26).
+// So the launches are as large as the scratch may be: a 1e9-ray layer takes 8 of them, not 30.
+constexpr int kScatterChunkLog2 = 27;
 static uint64_t scatter_chunk()
 {
     static const uint64_t chunk = 1ull << env_int("ORT_SCAT_CHUNK_LOG2", kScatterChunkLog2);     // development knob
@@ -2186,13 +2200,13 @@ static uint32_t scatter_grab(uint64_t n, unsigned groups)
     return (uint32_t)(64 * g);
 }
 // fp32 queued launches.  The hit log holds the launches since the last binning (kHitLogEntries 16-bit entries per part:
-// 0.67 GB of the 288 GB; a launch larger than that gets a log of its own size), the directory eight words per traced
+// 1.34 GB of the 288 GB), the directory eight words per traced
 // wave, the slabs (2 layers x kBinUnits x 643 KB = 66 MB) what bin_log_kernel has accumulated since the last fold.
 // Binning is LAZY like the fold: bin_log_kernel costs ~20 us whatever the log holds (a chain of memory round trips, and
 // one scattered store per non-empty bin and unit), so the launches of a run append to the log and one kernel bins them
 // when the log or the directory is full, when the other layer's launch comes, or when the image is needed
 // (flush_replicas).  Tracing and binning are ordered by the stream.
-constexpr uint64_t kHitLogEntries = 1ull << 26;
+constexpr uint64_t kHitLogEntries = kChunkRaysMax + 64;      // one launch of the largest size, or many smaller ones
 constexpr uint64_t kHitDirEntries = (uint64_t)kBinUnits * kBinDirMax;
 static int bin_pending(ort_ctx *c)
 {
@@ -2285,19 +2299,19 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     const bool anysrc = anysrc_emitter || c->scatter[a0.phase - 1];
     // The queued filtered kernel defers the rays that sit on a decision boundary to a list, which
     // the literal lockstep kernel traces right after it.  Every ray of a launch could be on it
-    // (an axial beam meets every flat face at costt == 1), so a launch covers at most kChunkRays.
+    // (an axial beam meets every flat face at costt == 1), so a launch covers at most chunk_rays().
     const bool deferring = queued && filt;
     const uint64_t total = a0.n_rays;
     // scattering media, exact fp64, the default kernel variant: the three-stage pipeline (scatter_front_kernel)
     const bool pipeline = mode == MODE_FUSED && deferring && c->precision == 0 && c->scatter[a0.phase - 1] &&
                           c->scat_k0[a0.phase - 1] > 0 && (c->variant & 16) == 0;
-    // (a queued launch indexes its rays with 32 bits)
-    const uint64_t step = pipeline ? scatter_chunk() : (queued ? kChunkRays : total);
     // fp32 hit log: worth its second kernel (~10 us + the launch gap) where a large share of the rays is binned — the point loop
-    // (42 % of its rays: -17 % per step); the ring loop bins 1 % of its rays and keeps the atomics.  ORT_HIT_LOG = 1 never,
+    // (42 % of its rays: -28 % per step); the ring loop bins 1 % of its rays and keeps the atomics.  ORT_HIT_LOG = 1 never,
     // 2 the point loop (default), 3 both loops (development knob; the image is the same bit for bit)
     static const int hit_log_mode = env_int("ORT_HIT_LOG", 2);
     const bool logging = fp32_queued_launch(c, mode, a0.phase, queued, anysrc) && hit_log_mode >= (a0.phase == 2 ? 2 : 3);
+    // (a queued launch indexes its rays with 32 bits; a logging launch fits the hit log: kHitLogEntries)
+    const uint64_t step = pipeline ? scatter_chunk() : (queued ? chunk_rays() : total);
     if (pipeline) {
         const int rc = reserve_handover(c, total);
         if (rc) return rc;

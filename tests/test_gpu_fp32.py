@@ -186,7 +186,8 @@ np.savez(sys.argv[2], img=img, cnt=cnt, img2=img2, cnt2=cnt2)
 def test_fp32_hit_log_modes_give_the_same_image(hip_library, tmp_path, name, n):
     """The fp32 queued kernels either bin their hits with atomics or log them for bin_log_kernel (ORT_HIT_LOG: 1 never,
     2 the point loop — the default —, 3 both loops; read once per process): integer adds commute, so the three images and
-    counter sets are identical — across a launch boundary (2^25 rays), for a source program and for the image source."""
+    counter sets are identical — for 3.4e7 rays, for a source program and for the image source (launch boundaries:
+    tests/test_gpu_parity.py::test_a_trace_cut_into_several_launches)."""
     import subprocess
     import sys
     got = []

@@ -6,7 +6,7 @@ Reference loops: src/main.f90:90-109 (ring), :127-162 (point), src/imageMod.f90:
 The oracle (oracle/ort_oracle.c, OpenMP over the host cores) needs ~0.3 s for configs[1], a few
 seconds for configs[2] and about a minute for the 2 x 1e9 rays of the configs[3] shape on the GPU
 box.  What this covers that the <= 3e5-ray tests cannot: the deferral list under load, launches cut
-at 2^25 rays inside one call, 32-bit in-launch ray keys behind ray offsets of 7.5e8, segment 0 of
+at 2^27 rays inside one call, 32-bit in-launch ray keys behind ray offsets of 7.5e8, segment 0 of
 the ring programs (the cull) over 1e9 rays, bins counted 1e5 times.
 
 Budget.  The two sides emit a ray through different sin / cos (device kernels vs glibc, <= 2 ulp);
@@ -68,8 +68,8 @@ def test_config1_point_1e7(sides, record_property):
 
 
 def test_config2_ring_1e8(sides, record_property):
-    """configs[2]: ring source, 1e8 rays, one ort_trace call = three launches (2^25 rays each at
-    most) sharing one deferral group; segment 0 culls 69 % of the rays."""
+    """configs[2]: ring source, 1e8 rays, one ort_trace call = one launch (2^27 rays at most);
+    segment 0 culls 69 % of the rays."""
     ctx, got, want = sides
     rep, img, cnt = _check(ctx, got, want, 1, [(0, 100_000_000)], record_property)
     assert int(cnt[4]) == int(img[0].sum()) > 10_000
