@@ -70,6 +70,34 @@ def main():
                 notes.append(f"production image vs oracle: L1 {l1}, counter delta {dc}")
             worst = max(worst, l1)
             binned = int(imgs[1][1][4]) + int(imgs[1][1][5])
+            # round 4: the fp32 queued kernels (segment 0 on the draw's word, the hit log) == the fp32 lockstep kernel;
+            # strict libm emitters on the 53-bit stream == the oracle on it, without any budget
+            ctx.set_precision(1)
+            f32 = []
+            for variant in (0, 1):
+                ctx.set_kernel_variant(variant)
+                ctx.reset()
+                ctx.trace(1, 0, 2 * n, SEED)
+                ctx.trace(2, 0, 2 * n, SEED)
+                f32.append(ctx.read())
+            if not (np.array_equal(f32[0][0], f32[1][0]) and np.array_equal(f32[0][1], f32[1][1])):
+                notes.append("fp32 queued image != fp32 lockstep image")
+            ctx.set_precision(0)
+            ctx.set_kernel_variant(1 | 32 | 64)
+            ctx.reset()
+            ctx.trace(1, 0, n, SEED)
+            ctx.trace(2, 0, n, SEED)
+            wimg, wcnt = ctx.read()
+            ctx.set_kernel_variant(1)
+            orc.set_wide_draws(True)
+            try:
+                want_img[:] = 0; want_cnt[:] = 0
+                orc.trace(1, 0, n, SEED, want_img, want_cnt)
+                orc.trace(2, 0, n, SEED, want_img, want_cnt)
+            finally:
+                orc.set_wide_draws(False)
+            if not (np.array_equal(wimg, want_img) and np.array_equal(wcnt, want_cnt)):
+                notes.append("strict emitters on the 53-bit stream != oracle")
         bad += bool(notes)
         print(f"seed {seed:4d} iris {settings.iris:6s} bottle {int(settings.use_bottle)} binned {binned:7d} "
               f"{'OK' if not notes else 'MISMATCH: ' + '; '.join(notes)}", flush=True)
