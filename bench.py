@@ -583,7 +583,7 @@ def main() -> int:
             # mean launch duration — what the vector units really delivered, IEEE division / sqrt expansions included
             "counted_flop_per_launch": prof.get("counted_fp64_flop_per_launch"),
             "frac_counted": (prof["counted_fp64_flop_per_launch"] * (rays_launch / prof["rays_per_launch_nominal"] if prof.get("rays_per_launch_nominal") else 1.0)
-                             / k_s / 1e12 / FP64_VEC_PEAK_TFLOPS if prof.get("counted_fp64_flop_per_launch") else None),
+                             / k_s / 1e12 / FP64_VEC_PEAK_TFLOPS if prof.get("counted_fp64_flop_per_launch") and len(phases) == 1 else None),   # (two loops: kernel_ms is the mean over both kernels, the counters are the point kernel's)
             "non_arithmetic_share_of_valu": prof.get("non_arithmetic_share_of_valu"),   # compares, selects, moves, integer (the draw), conversions
             "sq_insts_salu_per_launch": prof.get("salu_instructions_per_launch"),
             "note": "algorithmic flop = an assumed 100 per surface solve (SURVEY §8d; + 61 per emitted ring "

@@ -110,7 +110,7 @@ def main():
                 per_step = c2["intersections_per_step"]
                 if w == "full1e9":       # two phases per step: the point layer holds 6.31 of the 7.87 intersections per ray pair
                     per_step *= 6.3136 / (6.3136 + 1.5524)
-                launches = max(1, -(-c2["rays_per_gpu_per_launch"] // (1 << 25)))     # ort_trace cuts at 2^25 rays
+                launches = max(1, -(-c2["rays_per_gpu_per_launch"] // (1 << 27)))     # ort_trace cuts at 2^27 rays
                 entry["intersections_per_launch"] = per_step / launches
         stamped["workloads"][w] = entry
         print(w, json.dumps(entry, indent=1))
