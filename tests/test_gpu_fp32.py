@@ -172,32 +172,36 @@ from conftest import make_system
 from opticalraytrace_amd.capi import Context
 _, osys = make_system(sys.argv[3])
 n = int(sys.argv[4])
+out = {}
 with Context(osys) as c:
-    c.set_precision(1)
-    c.trace(1, 0, n, 123456789); c.trace(2, 11, n, 123456789)
-    img, cnt = c.read()
-    c.trace(2, 11 + n, 1000, 123456789)          # and a small launch on top of the folded image
-    img2, cnt2 = c.read()
-np.savez(sys.argv[2], img=img, cnt=cnt, img2=img2, cnt2=cnt2)
+    for prec in (1, 0, 2):
+        c.set_precision(prec)
+        c.reset()
+        c.trace(1, 0, n, 123456789); c.trace(2, 11, n, 123456789)
+        out[f"img{prec}"], out[f"cnt{prec}"] = c.read()
+        c.trace(2, 11 + n, 1000, 123456789)          # and a small launch on top of the folded image
+        out[f"img{prec}b"], out[f"cnt{prec}b"] = c.read()
+np.savez(sys.argv[2], **out)
 """
 
 
-@pytest.mark.parametrize("name,n", [("large", (1 << 25) + 4321), ("large_crs", 400_000), ("large_image", 50_000)])
-def test_fp32_hit_log_modes_give_the_same_image(hip_library, tmp_path, name, n):
-    """The fp32 queued kernels either bin their hits with atomics or log them for bin_log_kernel (ORT_HIT_LOG: 1 never,
-    2 the point loop — the default —, 3 both loops; read once per process): integer adds commute, so the three images and
-    counter sets are identical — for 3.4e7 rays, for a source program and for the image source (launch boundaries:
+@pytest.mark.parametrize("name,n", [("large", (1 << 25) + 4321), ("large_crs", 400_000), ("large_image", 50_000), ("small_scatter_bc", 200_000)])
+def test_hit_log_and_atomics_give_the_same_image(hip_library, tmp_path, name, n):
+    """The fp32 queued kernels either bin the point loop's hits with atomics or log them for bin_log_kernel (ORT_HIT_LOG:
+    1 never, 2 — the default — log; read once per process): integer adds commute, so the images and counter sets are
+    identical — for 3.4e7 rays, for a source program, for the image source, and for a scattering bottle (lockstep kernel
+    in fp32); the fp64 arithmetics, which keep the atomics, ride along unchanged (launch boundaries:
     tests/test_gpu_parity.py::test_a_trace_cut_into_several_launches)."""
     import subprocess
     import sys
     got = []
-    for mode in ("1", "2", "3"):
+    for mode in ("1", "2"):
         out = str(tmp_path / f"m{mode}.npz")
         env = {**os.environ, "ORT_HIT_LOG": mode}
         r = subprocess.run([sys.executable, "-c", _HIT_LOG_CHILD, ROOT, out, name, str(n)], env=env, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         got.append(np.load(out))
-    for g in got[1:]:
-        for k in ("img", "cnt", "img2", "cnt2"):
-            assert np.array_equal(g[k], got[0][k]), (name, k)
-    assert int(got[0]["img"].sum()) == int(got[0]["cnt"][4]) + int(got[0]["cnt"][5])
+    for k in got[0].files:
+        assert np.array_equal(got[1][k], got[0][k]), (name, k)
+    for prec in (0, 1, 2):
+        assert int(got[0][f"img{prec}"].sum()) == int(got[0][f"cnt{prec}"][4]) + int(got[0][f"cnt{prec}"][5])
