@@ -205,3 +205,26 @@ def test_hit_log_and_atomics_give_the_same_image(hip_library, tmp_path, name, n)
         assert np.array_equal(got[1][k], got[0][k]), (name, k)
     for prec in (0, 1, 2):
         assert int(got[0][f"img{prec}"].sum()) == int(got[0][f"cnt{prec}"][4]) + int(got[0][f"cnt{prec}"][5])
+
+
+def test_fp32_resident_bundle_queued_equals_lockstep(hip_library):
+    """A bundle resident in HBM traced in fp32: the queued program kernel (hits through the log) against the lockstep
+    kernel (atomics) — the same bundle, the same float arithmetic, identical images and counters."""
+    import torch
+    from opticalraytrace_amd.capi import Context
+    _, osys = make_system("large")
+    n = 250_003
+    with Context(osys) as c:
+        bundle = torch.empty((6, n), dtype=torch.float64, device="cuda:0")
+        c.set_precision(1)
+        out = []
+        for variant in (1, 0):
+            c.set_kernel_variant(variant)
+            c.reset()
+            for phase, base in ((1, 4), (2, 2)):
+                c.emit(phase, 0, n, SEED, bundle.data_ptr())
+                c.trace_resident(phase, 0, n, SEED, base, bundle.data_ptr())
+            out.append(c.read())
+        c.set_kernel_variant(1)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert int(out[0][1][5]) > 50_000
