@@ -63,6 +63,10 @@ extern "C" {
 #define ORT_EMIT_IMAGE 4     /* emit_image/emit src/sourceMod.f90:303-361 (phase 2: image source; needs ort_set_image_source) */
 #define ORT_EMIT_ISORS 5     /* iSORS(ring=.true.) src/sourceMod.f90:162-247 (phase 1: isors source; its phase 2 is
                                 `point` started at bottle%centre%z, src/main.f90:140: point_offset below) */
+#define ORT_EMIT_ISORS_NORING 6 /* iSORS(ring=.false.) + bottle_backward_sub, src/sourceMod.f90:162-247, src/lens.f90:352-423: through
+                                the bottle from outside to the plane z = bottle%centre%z.  No call site of the reference reaches
+                                it (src/main.f90:141 is commented out); generic kernels only.  Needs the point loop's list to
+                                start with the bottle (surfaces[1][0], [1][1]: its glass and contents) */
 #define ORT_IMAGE_SOURCE_CELLS (512 * 512)
 
 /* surface flags */

@@ -26,7 +26,7 @@ ST_BINNED, ST_NA_REJECT, ST_OFF_GRID, ST_LOST_BOTTLE, ST_LOST_TELESCOPE, ST_HELP
 (C_LOST_RING, C_LOST_POINT, C_ISECT_RING, C_ISECT_POINT,
  C_BINNED_RING, C_BINNED_POINT, C_HELP3_RING, C_HELP3_POINT) = range(8)
 
-EMIT_RING, EMIT_POINT, EMIT_SPOT, EMIT_CRS, EMIT_IMAGE, EMIT_ISORS = range(6)
+EMIT_RING, EMIT_POINT, EMIT_SPOT, EMIT_CRS, EMIT_IMAGE, EMIT_ISORS, EMIT_ISORS_NORING = range(7)
 
 _ERRORS = {-1: "ORT_E_INVALID", -2: "ORT_E_NODEVICE", -3: "ORT_E_HIP", -4: "ORT_E_NOMEM", -5: "ORT_E_NOCOMM"}
 
@@ -99,6 +99,10 @@ def pack_system(osys: OpticalSystem) -> OrtSystem:
     src = osys.settings.light_source
     cs.emitter[0] = {"crs": EMIT_CRS, "isors": EMIT_ISORS}.get(src, EMIT_RING)
     cs.emitter[1] = {"spot": EMIT_SPOT, "image": EMIT_IMAGE}.get(src, EMIT_POINT)
+    # an emitter no settings file selects (EMIT_ISORS_NORING: the reference's call of it is commented out, src/main.f90:141)
+    for p, e in enumerate(getattr(osys, "emitter_override", None) or (None, None)):
+        if e is not None:
+            cs.emitter[p] = int(e)
     l2p = osys.L2[1]                          # main.f90:133: emit_image(imgin, pos, dir, L2) after the 843 nm rebuild
     cs.img_lens_r2 = l2p.radius * l2p.radius
     cs.img_lens_z = l2p.fb

@@ -1336,9 +1336,17 @@ __device__ inline void rang(D &draws, T sigma, T &gx, T &gy)
 // with no further draw.  Literal arithmetic throughout (intersect_cone = src/surfaces.f90:179-224) — except FILT (the
 // isors program): the cone's normal, the Fresnel step at it, the bottle quadratic and the aim at the lens in their
 // filtered forms (the same bits, or `rare`); the cone's own quadratic has a < 0 and stays literal.
-template <class T, bool FILT = false, class Sys, class D>
+// RING = false: iSORS(ring = .false.), which no call site of the reference reaches (src/main.f90:141 is commented out):
+// instead of stopping at the bottle's inner wall the beam goes THROUGH the bottle from outside — bottle_backward_sub,
+// src/lens.f90:352-423: outer wall (the full semi-axes: ring_bottle_ra / _rb), Fresnel step air -> glass, inner wall
+// (isors_rad1 / _rad2), Fresnel step glass -> contents, each step only if the one before it happened (a miss or a
+// reflection returns early; the caller does not look at the flag) — is carried to the plane z = bottle%centre%z and aimed
+// at the lens disc of radius L1%radius + 10 mm (ring_lens_r2).  Literal arithmetic; the glass and the contents are those of
+// the point loop's bottle (surfaces[1][0]: the inner wall's n1 = contents, n2 = glass; host: check_system).
+template <class T, bool FILT = false, bool RING = true, class Sys, class D>
 __device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws, bool &rare, bool strict = false)
 {
+    static_assert(RING || !FILT, "iSORS(ring = .false.) has no filtered form");
     T gx, gy;
     rang<T>(draws, T(S.isors_sigma), gx, gy);
     const T height = T(S.isors_height), k = T(S.isors_k);
@@ -1366,6 +1374,40 @@ __device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws, bool &rare
         const T tt = ORT_DIV(T(S.isors_base_pos), d2.z);
         VecT<T> p2 = vadd(hitp, vscale(d2, tt));
         p2.z = T(S.isors_z);
+        if constexpr (!RING) {
+            const bool ell = __builtin_amdgcn_readfirstlane(S.ring_ellipse) != 0;
+            const T cy = T(S.isors_cy), cz = T(S.isors_cz);
+            const T nb = T(S.surfaces[1][0].n2), nc = T(S.surfaces[1][0].n1);
+            auto wall = [&](const RayT<T> &pr, T ra, T rb, T &tw, bool &hit) {
+                if (ell) intersect_ellipse<false, T>(pr, cy, cz, ra, rb, T(0.), T(0.), true, tw, hit, unused);
+                else intersect_quadric<false, T>(pr, T(0.), cy, cz, ra, T(0.), true, true, tw, hit, unused);
+            };
+            T t1, t2;
+            bool hit1, hit2;
+            wall(RayT<T>{p2, d2}, T(S.ring_bottle_ra), T(S.ring_bottle_rb), t1, hit1);          // lens.f90:362-369
+            const bool at1 = cone && hit1;
+            const VecT<T> q1 = vselect(at1, vadd(p2, vscale(d2, t1)), p2);
+            const VecT<T> N1 = vnormalise(VecT<T>{T(0.), q1.y - cy, q1.z - cz});                  // orig - centre, orig%x = centre%x
+            const T ua = draws.template peek_as<T>();
+            draws.advance(at1);
+            VecT<T> d3 = d2;
+            const bool refl1 = reflect_refract<false, true, T>(d3, N1, T(1.), nb, ORT_DIV(T(1.), nb), T(0.), ua, true, unused);
+            d3 = vselect(at1, d3, d2);
+            const bool in1 = at1 && !refl1;                                                       // :378-381
+            wall(RayT<T>{q1, d3}, T(S.isors_rad1), T(S.isors_rad2), t2, hit2);                     // :384-391
+            const bool at2 = in1 && hit2;
+            const VecT<T> q2 = vselect(at2, vadd(q1, vscale(d3, t2)), q1);
+            const VecT<T> N2 = vnormalise(VecT<T>{T(0.), q2.y - cy, q2.z - cz});
+            const T ub = draws.template peek_as<T>();
+            draws.advance(at2);
+            VecT<T> d4 = d3;
+            (void)reflect_refract<false, true, T>(d4, N2, nb, nc, ORT_DIV(nb, nc), T(0.), ub, true, unused);
+            d4 = vselect(at2, d4, d3);
+            const T tz = ORT_DIV(cz - q2.z, d4.z);                                                // sourceMod.f90: to the plane z = centre%z
+            const VecT<T> q3 = vadd(q2, vscale(d4, tz));
+            pos = vselect(cone, q3, pos);
+            dir = vselect(cone, d4, dir);
+        } else {
         // bottle inner wall: circular (rad1 = rad2) or elliptical cylinder about x
         const RayT<T> probe = {p2, d2};
         T tb;
@@ -1380,8 +1422,10 @@ __device__ inline bool emit_isors(const Sys &S, RayT<T> &r, D &draws, bool &rare
         const VecT<T> p3 = vadd(p2, vscale(d2, tb));
         pos = vselect(cone, vselect(hitb, p3, p2), pos);    // at the abort the ray sits beside the bottle
         dir = vselect(cone, d2, dir);
+        }
     }
-    T rr = T(0.) + draws.template peek_as<T>() * (T(S.isors_lens_r2) - T(0.));      // ranu(0., L1%radius**2)
+    const T aim_r2 = RING ? T(S.isors_lens_r2) : T(S.ring_lens_r2);                 // L1%radius**2 / (L1%radius + 10e-3)**2
+    T rr = T(0.) + draws.template peek_as<T>() * (aim_r2 - T(0.));                   // ranu(0., ...)
     draws.advance(ok);
     T theta = draws.template peek_as<T>() * S.twopi;
     draws.advance(ok);
@@ -1497,6 +1541,7 @@ __device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64
     else if (e == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray, strict);
     else if (e == ORT_EMIT_CRS) emit_crs<T>(S, r, draws, unused, strict);
     else if (e == ORT_EMIT_ISORS) return emit_isors<T>(S, r, draws, unused, strict) ? -1 : ORT_ST_NO_INTERSECTION;
+    else if (e == ORT_EMIT_ISORS_NORING) return emit_isors<T, false, false>(S, r, draws, unused, strict) ? -1 : ORT_ST_NO_INTERSECTION;
     else return emit_image<T>(S, cdf, r, draws, ray, nullptr, strict) ? -1 : ORT_ST_LOST_TELESCOPE;
     return -1;
 }

@@ -1641,7 +1641,13 @@ int check_system(const ort_system *sys)
                 return fail(ORT_E_INVALID, "the image plane must be the last surface, and only the last");
         }
         if (sys->split[p] < 0 || sys->split[p] > n) return fail(ORT_E_INVALID, "split out of range");
-        if (sys->emitter[p] < ORT_EMIT_RING || sys->emitter[p] > ORT_EMIT_ISORS) return fail(ORT_E_INVALID, "bad emitter");
+        if (sys->emitter[p] < ORT_EMIT_RING || sys->emitter[p] > ORT_EMIT_ISORS_NORING) return fail(ORT_E_INVALID, "bad emitter");
+        if (sys->emitter[p] == ORT_EMIT_ISORS_NORING) {      // it reads the bottle's glass and contents from the point loop's list
+            const ort_surface &in = sys->surfaces[1][0], &out = sys->surfaces[1][1];
+            const bool wall = (in.kind == ORT_SURF_CYLINDER || in.kind == ORT_SURF_ELLIPSE) && in.kind == out.kind;
+            if (sys->n_surfaces[1] < 2 || !wall || !(in.flags & ORT_F_BOTTLE) || !(out.flags & ORT_F_BOTTLE) || in.n2 != out.n1)
+                return fail(ORT_E_INVALID, "ORT_EMIT_ISORS_NORING needs the point loop's list to start with the bottle's two walls");
+        }
     }
     return ORT_OK;
 }
