@@ -54,3 +54,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(d, f)).read()
                 assert "oracle" not in src, (d, f)
+
+
+def test_emitter_and_surface_codes_match_the_header():
+    """capi.py restates the ORT_EMIT_* / ORT_SURF_* / flag codes of include/ort.h: they must be the header's."""
+    text = open(os.path.join(ROOT, "include", "ort.h")).read()
+    defs = {k: int(v.rstrip("u"), 0) for k, v in re.findall(r"#define\s+(ORT_[A-Z_0-9]+)\s+(\d+u?)\b", text)}
+    for name in ("RING", "POINT", "SPOT", "CRS", "IMAGE", "ISORS", "ISORS_NORING"):
+        assert defs["ORT_EMIT_" + name] == getattr(capi, "EMIT_" + name), name
+    assert defs["ORT_EMIT_ISORS_NORING"] == 6
