@@ -44,6 +44,12 @@ def main(argv=None) -> int:
     ap.add_argument("--data", default=None, help="output root (default ../data, or data/ next to an explicit --res)")
     ap.add_argument("--device", type=int, default=None, help="HIP device (default LOCAL_RANK or 0)")
     ap.add_argument("--quiet", action="store_true")
+    # beyond the reference's program (which has none of these: fp64, its runtime's draws, its libm):
+    ap.add_argument("--fp32", action="store_true", help="trace in single precision (BASELINE configs[4]; ~2 x the rate, images within shot noise)")
+    ap.add_argument("--strict-libm", action="store_true",
+                    help="the light sources call glibc's own sin / cos: emitted rays equal the compiled reference's bit for bit (~1.5 x the time)")
+    ap.add_argument("--wide-draws", action="store_true",
+                    help="53-bit uniforms, as random_number fills ran2's real(8) (src/random_mod.f90:39-46), instead of 32-bit ones (~2.5 x the time)")
     args = ap.parse_args(argv)
 
     path, res_dir = _locate(args.settings, args.res)
@@ -89,6 +95,10 @@ def main(argv=None) -> int:
         else:
             tracer = RayTracer(system, device=device, rank=rank, world=world, process_group=group)
         try:
+            if args.fp32:
+                tracer.ctx.set_precision(1)
+            if args.strict_libm or args.wide_draws:
+                tracer.ctx.set_kernel_variant(1 | (64 if args.strict_libm else 0) | (32 if args.wide_draws else 0))
             res = tracer.run()
             folder = os.path.join(data_dir, settings.data_folder)
             if rank == 0:

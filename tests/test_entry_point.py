@@ -97,6 +97,26 @@ def test_entry_point_writes_what_run_settings_writes(tmp_path, hip_library):
 
 
 @pytest.mark.gpu
+def test_entry_point_options_beyond_the_reference(tmp_path, hip_library):
+    """--fp32, --strict-libm, --wide-draws: the arithmetic / libm / draw-stream choices of the library at the process
+    boundary.  Same files, transmissions within a tenth of a percent of the default run's (other rays, same statistics)."""
+    _tree(tmp_path, bottle_file="clearBottle-small.params")
+    base = None
+    for k, flags in enumerate(([], ["--fp32"], ["--strict-libm"], ["--wide-draws"], ["--strict-libm", "--wide-draws"])):
+        p = _run(str(tmp_path), "res/test_0.params", "--data", f"d{k}", *flags)
+        assert p.returncode == 0, (flags, p.stderr[-1500:])
+        t = [float(w.rstrip("%")) for w in p.stdout.split() if w.endswith("%")]
+        assert len(t) == 2
+        base = base or t
+        assert abs(t[0] - base[0]) < 0.1 and abs(t[1] - base[1]) < 0.5, (flags, t, base)
+        assert len([f for f in os.listdir(tmp_path / f"d{k}" / "images") if "image" in f]) == 3
+    # strict libm changes no outcome on this fixture (identical transmissions); the 53-bit stream traces other rays
+    a = np.fromfile(tmp_path / "d0" / "images" / sorted(os.listdir(tmp_path / "d0" / "images"))[0])
+    b = np.fromfile(tmp_path / "d3" / "images" / sorted(os.listdir(tmp_path / "d3" / "images"))[0])
+    assert not np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_entry_point_with_the_tracker_on(tmp_path, hip_library):
     """use_tracker (src/main.f90:72-74, :121-124, :183): the two path dumps are written, the images are not, the stats
     record is — by the torch-free process and by run_settings alike, byte for byte."""
