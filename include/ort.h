@@ -163,7 +163,7 @@ typedef struct ort_ctx ort_ctx;
 /* Library / device probing. */
 int ort_abi_version(void);
 /* Hash (first 16 hex digits of SHA-256) of the kernel sources the library was built from
- * (csrc/Makefile: ort_hip.hip, ort_device.h, ort_fastd.h, ort_pair.h, include/ort.h in that order), so a host
+ * (csrc/Makefile SOURCES: every ort_*.hip unit, then the headers, include/ort.h among them), so a host
  * — and the tests — can tell a stale binary from the sources next to it. */
 const char *ort_build_id(void);
 const char *ort_last_error(void);
@@ -269,6 +269,11 @@ int ort_allreduce(ort_ctx **ctxs, int n);
 /* The number of ranks of the communicator the last ort_allreduce of this process used, as RCCL reports it
  * (ncclCommCount); 0 before the first one.  A multi-GPU run states it next to its figures (bench.py `ranks_seen`). */
 int ort_allreduce_ranks(int *n_ranks);
+/* Give back the RCCL communicators ort_allreduce keeps for this process (they are created by its first call and re-used
+ * while the device list stays the same; a call that fails drops them by itself, so the next one starts afresh).  For a host
+ * that is done reducing before it is done with the devices — the counterpart of leaving the OpenMP parallel region
+ * (src/main.f90:163).  Safe to call at any time, also before the first ort_allreduce. */
+int ort_comm_destroy(void);
 int ort_device_image(ort_ctx *ctx, void **d_image);
 int ort_device_counters(ort_ctx *ctx, void **d_counters);
 int ort_synchronize(ort_ctx *ctx);
@@ -293,6 +298,9 @@ int ort_reserve(ort_ctx *ctx, uint64_t n_rays);
  * trace, 1 resident trace, 2 emit. */
 int ort_last_kernel_ms(ort_ctx *ctx, int kind, float *ms);
 int ort_set_timing(ort_ctx *ctx, int enable);
+/* Which kernel instantiation the context's last trace launch ran — e.g. "trace_queue_kernel<MODE_FUSED, double, PROG_POINT,
+ * strict=1, wide=0>" — so that a measurement, or a test, can say what it measured (no counterpart in the reference). */
+int ort_last_kernel_name(ort_ctx *ctx, char *buf, int capacity);
 /* Durations (ms) of the most recent fused-trace launches (ort_trace), oldest first, at most 64:
  * every launch records its own event pair on the context's stream, so a host loop can issue
  * many steps without synchronising and read the per-launch times afterwards. */
@@ -318,15 +326,18 @@ int ort_set_precision(ort_ctx *ctx, int precision);
  * Bit 5 set = 53-BIT DRAWS (stream ORT-RNG-v2w, csrc/ort_device.h): every uniform is (h >> 11) * 2^-53 of its own hash,
  * as the reference's ran2() fills a real(8) (src/random_mod.f90:39-46), where the default stream ORT-RNG-v2 hands out
  * 32-bit draws, two per hash.  A different stream, therefore different rays (same statistics: tests/test_gpu_wide_draws.py
- * against the unmodified program); traced by the lockstep kernel (the surface programs and the scattering pipeline are
- * built on v2's pairs; ~2.5 x the time).  Every entry that draws honours it (ort_trace, ort_emit, ort_trace_resident,
- * ort_trace_rays with u == NULL, ort_trace_paths); the checker's keyed mode has the same switch.
- * Bit 6 set = STRICT LIBM EMITTERS (exact fp64 only): the light sources evaluate sin / cos through glibc 2.35's own
- * algorithms (csrc/ort_libm.h), entry by entry as the reference's compiled code calls them, so an emitted ray — and with it
- * every ray state, image and counter — equals the CPU checker's bit for bit; the surface-program kernels
- * stand aside for the generic walk (~1.4 x the time).  Clear (default): the emitters' own sin / cos (within an ulp of
- * glibc's: emitted rays agree to 1e-12, discrete outcomes are identical).  The scattering walk, rang's log and everything
- * behind the emitters are glibc-exact / IEEE-exact in either setting.  Default 1. */
+ * against the unmodified program).  In exact fp64 the production kernels have instantiations on this stream (the surface
+ * programs, the generic filtered walk in clear media, the scattering pipeline: one hash per draw instead of one per two);
+ * fp32 / fast fp64 and the A/B variants of bits 1 and 4 trace it with the lockstep kernel.  Every entry that draws honours
+ * it (ort_trace, ort_emit, ort_trace_resident, ort_trace_rays with u == NULL, ort_trace_paths); the checker's keyed mode has
+ * the same switch.
+ * Bit 6 set = STRICT LIBM EMITTERS (exact fp64 only; ORT_E_INVALID with another precision): the light sources evaluate
+ * sin / cos through glibc 2.35's own algorithms (csrc/ort_libm.h), entry by entry as the reference's compiled code calls
+ * them, so an emitted ray — and with it every ray state, image and counter — equals the CPU checker's bit for bit; the
+ * surface programs have their own instantiations with these emitters (csrc/ort_k_strict.hip).  Clear (default): the
+ * emitters' own sin / cos (within an ulp of glibc's: emitted rays agree to 1e-12, discrete outcomes are identical).  The
+ * scattering walk, rang's log and everything behind the emitters are glibc-exact / IEEE-exact in either setting.
+ * Default 1. */
 int ort_set_kernel_variant(ort_ctx *ctx, int variant);
 
 #ifdef __cplusplus

@@ -142,7 +142,12 @@ def library_path() -> str:
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libort_hip.so")
 
 
-KERNEL_SOURCES = ("ort_hip.hip", "ort_device.h", "ort_fastd.h", "ort_libm.h", "ort_libm_tables.h", os.path.join("..", "..", "include", "ort.h"))
+# csrc/Makefile SOURCES, in its order: the translation units, then the headers
+KERNEL_UNITS = ("ort_hip", "ort_k_prog64", "ort_k_strict", "ort_k_wide", "ort_k_prog32", "ort_k_fast", "ort_k_generic", "ort_k_scatter",
+                "ort_k_batch")
+KERNEL_SOURCES = tuple(u + ".hip" for u in KERNEL_UNITS) + (
+    "ort_device.h", "ort_fastd.h", "ort_libm.h", "ort_libm_tables.h", os.path.join("..", "..", "include", "ort.h"),
+    "ort_trace.h", "ort_scatter.h", "ort_launch.h", "ort_k_program.h")
 
 
 def source_build_id() -> str:
@@ -192,6 +197,8 @@ def load_library(path: Optional[str] = None, no_torch: Optional[bool] = None) ->
         "ort_build_id": (C.c_char_p, []),
         "ort_allreduce": (C.c_int, [C.POINTER(vp), i32]),
         "ort_allreduce_ranks": (C.c_int, [C.POINTER(C.c_int)]),
+        "ort_comm_destroy": (C.c_int, []),
+        "ort_last_kernel_name": (C.c_int, [vp, C.c_char_p, i32]),
         "ort_last_error": (C.c_char_p, []),
         "ort_device_count": (C.c_int, [C.POINTER(C.c_int)]),
         "ort_create": (C.c_int, [C.POINTER(OrtSystem), i32, vp, C.POINTER(vp)]),
@@ -238,7 +245,7 @@ def torch_safe() -> bool:
     return not _LOADED_WITHOUT_TORCH
 
 
-EXPORTED_SYMBOLS = ["ort_abi_version", "ort_build_id", "ort_allreduce", "ort_allreduce_ranks", "ort_last_error", "ort_device_count", "ort_create",
+EXPORTED_SYMBOLS = ["ort_abi_version", "ort_build_id", "ort_allreduce", "ort_allreduce_ranks", "ort_comm_destroy", "ort_last_kernel_name", "ort_last_error", "ort_device_count", "ort_create",
                     "ort_destroy", "ort_set_system", "ort_set_image_source", "ort_reset", "ort_flush", "ort_trace", "ort_emit",
                     "ort_trace_resident", "ort_trace_rays", "ort_trace_paths", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
@@ -378,6 +385,14 @@ class Context:
         _check(self.lib, self.lib.ort_kernel_times(self._h, buf, capacity, C.byref(n)), "ort_kernel_times")
         return [buf[i] for i in range(n.value)]
 
+    def last_kernel_name(self) -> str:
+        """The kernel instantiation the last trace launch of this context ran, as the source spells it (e.g.
+        `(trace_queue_kernel<MODE_FUSED, true, false, T, P, false, RNG>)` is reported with its arguments filled in by the
+        launcher that chose it): tests and bench.py state which kernel a figure belongs to."""
+        buf = C.create_string_buffer(256)
+        _check(self.lib, self.lib.ort_last_kernel_name(self._h, buf, 256), "ort_last_kernel_name")
+        return buf.value.decode()
+
     def set_precision(self, precision: int) -> None:
         """0 = fp64 (reference arithmetic, default), 1 = fp32 study path."""
         _check(self.lib, self.lib.ort_set_precision(self._h, precision), "ort_set_precision")
@@ -427,6 +442,12 @@ def allreduce(contexts) -> None:
     lib = load_library()
     arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
     _check(lib, lib.ort_allreduce(arr, len(contexts)), "ort_allreduce")
+
+
+def comm_destroy() -> None:
+    """ort_comm_destroy: give back the RCCL communicators ort_allreduce keeps for this process."""
+    lib = load_library()
+    _check(lib, lib.ort_comm_destroy(), "ort_comm_destroy")
 
 
 def allreduce_ranks() -> int:

@@ -151,18 +151,23 @@ struct Draws {
 
 // keyed-only variant of the bulk kernels that walk a list they do not know at compile time
 // (generic walk, lockstep kernel): the linear counter per lane, one hash per draw
-// DYN: the stream is chosen at run time (set_wide: v2, or the 53-bit v2w of kernel variant bit 5) — the lockstep kernel and
-// emit_kernel; DYN = false (the queued kernels, the scattering pipeline) knows v2 alone and pays nothing for the choice.
-template <bool DYN> struct WideChoice {
+// WM: 0 = the stream is v2 (the queued kernels and the scattering pipeline by default: nothing is paid for a choice);
+// 1 = chosen at run time (set_wide: v2, or the 53-bit v2w of kernel variant bit 5) — the lockstep kernel and emit_kernel;
+// 2 = v2w, known at compile time (the WIDE instantiations of the queued kernels and of the scattering pipeline)
+template <int WM> struct WideChoice {
     bool wide_ = false;
     __device__ inline bool wide() const { return wide_; }
     __device__ inline void set_wide(bool w) { wide_ = w; }
 };
-template <> struct WideChoice<false> {
+template <> struct WideChoice<0> {
     __device__ inline constexpr bool wide() const { return false; }
     __device__ inline void set_wide(bool) {}
 };
-template <bool DYN> struct KeyedDrawsT : WideChoice<DYN> {
+template <> struct WideChoice<2> {
+    __device__ inline constexpr bool wide() const { return true; }
+    __device__ inline void set_wide(bool) {}
+};
+template <int WM> struct KeyedDrawsT : WideChoice<WM> {
     uint64_t c;            // (ray << 24) + k
     uint64_t base;
     __device__ inline void init_keyed(uint64_t b, uint64_t ray, int first_draw)
@@ -180,7 +185,7 @@ template <bool DYN> struct KeyedDrawsT : WideChoice<DYN> {
     __device__ inline double next() { const double u = peek(); c += 1ull; return u; }
     template <class T> __device__ inline T peek_as() const
     {
-        if constexpr (DYN) {
+        if constexpr (WM == 1) {
             // ONE hash and one conversion for both streams (the choice is wave-uniform, but a compiler that turns it into
             // selects would otherwise hash twice per draw): x = the draw as a 53-bit integer — v2w: h >> 11; v2: its 32-bit
             // word << 21, and w 2^21 2^-53 = w 2^-32 exactly as bits_to_unit forms it
@@ -189,7 +194,8 @@ template <bool DYN> struct KeyedDrawsT : WideChoice<DYN> {
             const uint64_t x = wd ? h >> 11 : (uint64_t)draw_word(h, (c & 1ull) != 0) << 21;
             if constexpr (sizeof(T) == 8) return T((double)(uint32_t)(x >> 32) * 0x1p-21 + (double)(uint32_t)x * 0x1p-53);
             else return (float)(uint32_t)(x >> 29) * 0x1.0p-24f;         // the top 24 bits of either
-        } else return unit_from<T>(word());
+        } else if constexpr (WM == 2) return wide_unit_from<T>(wide_hash(base, c));
+        else return unit_from<T>(word());
     }
     template <class T> __device__ inline T next_as()
     {
@@ -200,9 +206,10 @@ template <bool DYN> struct KeyedDrawsT : WideChoice<DYN> {
     // two consecutive draws for the lanes `cnd` (a rejection loop's pair, src/random_mod.f90:68-69).  Draws 2j and
     // 2j + 1 are the two halves of ONE hash: when every lane of the wave stands at an even draw — it does in the
     // Box-Muller loops of the crs and isors sources, which start at draw 2 / 0 and consume pairs — one hash serves both
+    // (v2w: one hash per draw)
     template <class T> __device__ inline void next_pair_as(bool cnd, T &u1, T &u2)
     {
-        if (!(DYN && this->wide()) && !wave_any((c & 1ull) != 0)) {
+        if (WM != 2 && !(WM == 1 && this->wide()) && !wave_any((c & 1ull) != 0)) {
             const uint64_t h = mix64(base + kGolden * ((c >> 1) + 1ull));
             u1 = unit_from<T>((uint32_t)(h >> 32));
             u2 = unit_from<T>((uint32_t)h);
@@ -218,51 +225,68 @@ template <bool DYN> struct KeyedDrawsT : WideChoice<DYN> {
     __device__ inline void unpack(uint64_t w, uint64_t b) { c = w; base = b; }
     __device__ inline uint64_t ray_of_packed(uint64_t w, uint64_t) const { return w >> 24; }
 };
-using KeyedDraws = KeyedDrawsT<false>;
+using KeyedDraws = KeyedDrawsT<0>;
+using KeyedDrawsWide = KeyedDrawsT<2>;
 
 // Draw source of the surface-program kernels: every live lane of a wave is at the same draw
 // index K, a compile-time constant of the program step, so nothing is counted per lane: the
 // state is the ray's zray, and at<K>() hashes pair K/2 at the even draw and keeps the hash for
 // the odd one (FRESH: the hash is not at hand — first draw after the queue — and is formed again).
-struct ProgDraws {
+// WIDE: the 53-bit stream ORT-RNG-v2w (kernel variant bit 5) — one hash per draw, h = mix64(zray + GOLDEN (K + 1)) with
+// zray = base + GOLDEN (ray << 24), i.e. wide_hash(base, (ray << 24) + K): the draw the lockstep kernel and the checker hand out
+template <bool WIDE> struct ProgDrawsT {
+    static constexpr int kRayShift = WIDE ? 24 : 23;
     uint64_t zray;
     uint64_t h;
     int k;                 // sequential interface of the emitters: folds to constants in their straight-line code
+    static __host__ __device__ inline uint64_t zray_at(uint64_t base, uint64_t ray) { return base + kGolden * (ray << kRayShift); }
     __device__ inline void init_keyed(uint64_t base, uint64_t ray, int first_draw)
     {
-        zray = zray_of(base, ray);
+        zray = zray_at(base, ray);
         h = 0;
         k = first_draw;
     }
-    // ray `idx` of a launch whose first ray has zray z0 (= zray_of(base, first_ray), wave-uniform):
-    // zray_of(base, first_ray + idx) = z0 + (GOLDEN << 23) idx modulo 2^64 — a 64 x 32-bit product
+    // ray `idx` of a launch whose first ray has zray z0 (= zray_at(base, first_ray), wave-uniform):
+    // zray_at(base, first_ray + idx) = z0 + (GOLDEN << 23) idx modulo 2^64 — a 64 x 32-bit product
     // per lane instead of a 64-bit add, a shift and a 64 x 64-bit product
     __device__ inline void init_index(uint64_t z0, uint32_t idx, int first_draw)
     {
-        zray = z0 + (kGolden << 23) * (uint64_t)idx;
+        zray = z0 + (kGolden << kRayShift) * (uint64_t)idx;
         h = 0;
         k = first_draw;
     }
     template <class T, int K, bool FRESH> __device__ inline T at()
     {
-        if constexpr ((K & 1) == 0 || FRESH) h = mix64(zray + kGolden * (uint64_t)(K / 2 + 1));
-        return unit_from<T>(draw_word(h, (K & 1) != 0));
+        if constexpr (WIDE) {
+            h = mix64(zray + kGolden * (uint64_t)(K + 1));
+            return wide_unit_from<T>(h);
+        } else {
+            if constexpr ((K & 1) == 0 || FRESH) h = mix64(zray + kGolden * (uint64_t)(K / 2 + 1));
+            return unit_from<T>(draw_word(h, (K & 1) != 0));
+        }
     }
     template <class T> __device__ inline T next_as()
     {
-        if ((k & 1) == 0) h = mix64(zray + kGolden * (uint64_t)(k / 2 + 1));
-        const T u = unit_from<T>(draw_word(h, (k & 1) != 0));
+        T u;
+        if constexpr (WIDE) {
+            h = mix64(zray + kGolden * (uint64_t)(k + 1));
+            u = wide_unit_from<T>(h);
+        } else {
+            if ((k & 1) == 0) h = mix64(zray + kGolden * (uint64_t)(k / 2 + 1));
+            u = unit_from<T>(draw_word(h, (k & 1) != 0));
+        }
         k += 1;
         return u;
     }
     __device__ inline uint64_t pack() const { return zray; }
     __device__ inline void unpack(uint64_t w, uint64_t) { zray = w; h = 0; k = 0; }
-    __device__ inline uint64_t ray_of_packed(uint64_t w, uint64_t base) const { return ray_of_zray(w, base); }
+    __device__ inline uint64_t ray_of_packed(uint64_t w, uint64_t base) const { return ((w - base) * kGoldenInv) >> kRayShift; }
     // the dynamic interface is never instantiated for a program (surface_step takes the static one)
     template <class T> __device__ inline T peek_as() const { return T(0.5); }
     __device__ inline void advance(bool) {}
     template <class T> __device__ inline void next_pair_as(bool, T &u1, T &u2) { u1 = u2 = T(0.5); }
 };
+using ProgDraws = ProgDrawsT<false>;
 
 // Division and square root of the traced arithmetic, by type.
 //   double  the compiler's correctly rounded IEEE operations (the reference's arithmetic)
@@ -1520,12 +1544,13 @@ __device__ inline int emit(const Sys &S, int phase, RayT<T> &r, D &draws, uint64
 {
     if constexpr (EMITTER >= 0) {
         bool unused = false;                              // spot and image are literal throughout
-        if constexpr (EMITTER == ORT_EMIT_RING) emit_ring<T, FILT>(S, r, draws, rare);
-        else if constexpr (EMITTER == ORT_EMIT_POINT) emit_point<T, FILT>(S, r, draws, rare);
-        else if constexpr (EMITTER == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray);
-        else if constexpr (EMITTER == ORT_EMIT_CRS) emit_crs<T, FILT>(S, r, draws, rare);
-        else if constexpr (EMITTER == ORT_EMIT_ISORS) return emit_isors<T, FILT>(S, r, draws, rare) ? -1 : ORT_ST_NO_INTERSECTION;
-        else return emit_image<T>(S, cdf, r, draws, ray, img_hint) ? -1 : ORT_ST_LOST_TELESCOPE;
+        // (`strict` is a literal of the program kernel — trace_queue_kernel's STRICT — and folds away after inlining)
+        if constexpr (EMITTER == ORT_EMIT_RING) emit_ring<T, FILT>(S, r, draws, rare, strict);
+        else if constexpr (EMITTER == ORT_EMIT_POINT) emit_point<T, FILT>(S, r, draws, rare, strict);
+        else if constexpr (EMITTER == ORT_EMIT_SPOT) emit_spot<T>(S, r, ray, strict);
+        else if constexpr (EMITTER == ORT_EMIT_CRS) emit_crs<T, FILT>(S, r, draws, rare, strict);
+        else if constexpr (EMITTER == ORT_EMIT_ISORS) return emit_isors<T, FILT>(S, r, draws, rare, strict) ? -1 : ORT_ST_NO_INTERSECTION;
+        else return emit_image<T>(S, cdf, r, draws, ray, img_hint, strict) ? -1 : ORT_ST_LOST_TELESCOPE;
         (void)unused;
         return -1;
     }

@@ -1,32 +1,6 @@
-// ort_hip.hip — HIP kernels (gfx950 / CDNA4, wave64) and the C ABI of include/ort.h.
-//
-// Kernels (device functions: ort_device.h; the arithmetic type T is double = the reference's
-// arithmetic, bit-exact; float = fp32 study path; fastd = opt-in fast fp64, ort_fastd.h)
-//   trace_queue_kernel<MODE, FILT, EXT, T, PROG>   the production kernel.  One wavefront = one ray
-//       bundle over contiguous ranges of global ray indices (plan_ranges); a ray lives in VGPRs
-//       from emission to binning; survivors of the first surface segment are compacted through a
-//       wave-private LDS queue so that the second segment runs on full wavefronts; hits are
-//       binned with global int32 atomics into one of 8 image replicas (fold_kernel adds them
-//       into the image when it is next needed); counters are reduced per workgroup.
-//         MODE_FUSED     emit in-kernel (src/main.f90:90-109 / :127-162 whole loop body)
-//         MODE_RESIDENT  ray bundle read from HBM, SoA fp64 [6][n], coalesced
-//         FILT           filtered predicates (decisions from bounded approximations); a ray that
-//                        lands inside a margin is not decided here: its index goes to the
-//                        re-run list and it leaves the kernel without side effect
-//         EXT (ANYSRC)   also compiles the rarely used emitters (spot, crs, image, isors); SCAT the
-//                        in-bottle scattering walk (213+ VGPRs); the default instantiation
-//                        leaves both out, and a phase is given only what its own list needs
-//         PROG           the surface list as template constants (Prog<P>: the default point /
-//                        ring systems, their iris variants, no bottle, elliptical bottle), steps
-//                        unrolled, the system read through scalar loads from its device copy;
-//                        the ring programs put a segment 0 in front (rays that are certain to
-//                        miss the first aperture are counted, not emitted).  PROG_GENERIC stages
-//                        the 3 KB ort_system into LDS once per workgroup and walks any list
-//   trace_kernel<MODE, FILT, T, EXT>         plain lockstep thread-per-ray walk: the literal
-//       re-run of the listed rays when a group of queued launches closes (normally an empty
-//       list), the parity / debug entry (MODE_DEBUG: per-ray outputs, tracker paths, no side
-//       effect) and the A/B baseline of the queued kernel
-//   fold_kernel, emit_kernel
+// ort_hip.hip — the C ABI of include/ort.h (gfx950 / CDNA4, wave64) and the small kernels around the trace kernels
+// (fold, hit-log binning, emit).  The trace kernels themselves are templates (ort_trace.h, ort_scatter.h over the device
+// functions of ort_device.h) instantiated family by family in ort_k_*.hip and reached through ort_launch.h.
 //
 // No MFMA: there is no contraction anywhere on this path; the kernel is bound by
 // fp64 VALU issue (IEEE divide / sqrt expansions), not by HBM.
@@ -41,196 +15,12 @@
 #include <rccl/rccl.h>       // types and enums only: the library is resolved at run time (ort_allreduce)
 #include "../../include/ort.h"
 #include "ort_device.h"
+#include "ort_launch.h"
 
 using namespace ort;
+using namespace ortk;
 
 namespace {
-
-constexpr int kBlock = 256;
-#ifndef ORT_MIN_WAVES
-#define ORT_MIN_WAVES 1
-#endif
-constexpr int kTimingRing = 64;         // launches kept by ort_kernel_times
-constexpr int kReplicas = 8;            // image replicas, one per XCD
-// A replica stores one layer in 2^18 slots; bin i lives in slot (i * kSlotMul) mod 2^18 (a bijection:
-// the multiplier is odd), so neighbouring bins — the focal blob — land in unrelated 64-byte lines.
-constexpr int kSlotBits = 18;
-constexpr uint32_t kSlots = 1u << kSlotBits;
-constexpr uint32_t kSlotMul = 0x379B1u, kSlotMulInv = 0x32F51u;
-static_assert(((kSlotMul * kSlotMulInv) & (kSlots - 1)) == 1u, "kSlotMulInv must invert kSlotMul modulo 2^18");
-static_assert(ORT_IMAGE_N * ORT_IMAGE_N <= (int)kSlots, "a layer must fit the slot table");
-constexpr size_t kReplicaInts = 2 * (size_t)kSlots;   // both layers of one replica
-constexpr int kMaxBlocks = 256 * 12;    // grid cap of the lockstep kernels and of small queued launches (equal ranges)
-constexpr uint64_t kChunkRaysMax = ORT_MAX_RAYS_PER_LAUNCH;   // rays per launch of the queued kernel (bounds the re-run list: 4 B per ray); see chunk_rays()
-constexpr int kRedoBlocks = 128;        // grid of the literal re-run kernel (it normally finds an empty list and returns)
-
-enum { MODE_FUSED = 0, MODE_RESIDENT = 1, MODE_DEBUG = 2, MODE_CONTINUE = 3 };
-
-struct TraceArgs {
-    const ort_system *sys;       // device copy (DevSystem.sys)
-    const SurfAuxT<double> *aux; // DevSystem.aux[phase - 1]: read by the program kernels through scalar loads
-    const SystemT<float> *sysf;  // the same system and constants in single precision (fp32 path, program kernels)
-    const SurfAuxT<float> *auxf;
-    int32_t *image;              // [2][401][401]
-    int32_t *replicas;           // [kReplicas][2][kSlots] or null: see bin_hit, fold_kernel
-    unsigned long long *counters;
-    unsigned long long *work;    // [ORT_NUM_WORK]: executed-work counters (ort_work_counters), not part of the result
-    uint64_t first_ray, n_rays, rng_base;
-    int phase, draw_base;
-    // ray ranges of the queued kernel's waves (host: plan_ranges): workgroups [0, head_blocks) cut
-    // rays [0, head_rays) into head_chunk per wave, the rest cut the remainder into tail_chunk per wave
-    uint32_t head_blocks;
-    uint64_t head_rays, head_chunk, tail_chunk;
-    // the re-run list of the queued filtered kernel (see trace_queue_kernel): ray indices relative
-    // to first_ray; ctl[0] = entries, ctl[1] = workgroups of the re-run kernel that are done
-    uint32_t *redo_list;
-    unsigned int *redo_ctl;
-    // ring programs (trace_queue_kernel, segment 0): a ring ray whose lens-disc sample rr (its third draw x
-    // ring_lens_r2) exceeds the host's threshold (ring_cull_threshold) misses the plano-convex aperture for certain and is
-    // counted without being emitted.  rr does not decrease with the draw's 32-bit word, so the test is taken on the word:
-    // the ray dies iff word > cull_word (fp32 arithmetic: cull_wordf; host: cull_word_of); 0xffffffff: nothing is culled
-    uint32_t cull_word, cull_wordf;
-    int strict;                  // kernel variant bit 6: the emitters call glibc's own sin / cos / sincos (ort_device.h: sincos_em)
-    int wide;                    // kernel variant bit 5: 53-bit draws (ORT-RNG-v2w, ort_device.h); lockstep kernel only
-    uint64_t defer_base;         // queued kernel: list entry of ray i of this launch = defer_base + i (the entries of all
-                                 // launches of a group are relative to the group's first ray, see close_group)
-    int listed;                  // trace_kernel: iterate redo_list instead of [0, n_rays)
-    // resident / debug inputs
-    uint64_t in_stride;          // component stride of pos_dir_in (the bundle's ray count)
-    const double *pos_dir_in;    // SoA [6][in_stride] or null
-    const double *u;             // [nu][n] or null
-    int nu;
-    // debug outputs (any may be null)
-    double *pos_dir_out, *emitted_out;
-    int32_t *status, *bin_xy, *n_isect, *n_draws;
-    // scattering pipeline (scatter_front_kernel -> trace_queue_kernel<MODE_CONTINUE>): the rays that leave the
-    // scattering surfaces alive: state SoA [6][cont_cap], keyed draw counter (ray << 24) + draws consumed
-    // (kNoRay: the slot holds no ray), intersections evaluated so far.  A wave of the front kernel fills the slots
-    // of its own ray range from the bottom and marks the rest empty: no shared counter (one returning atomic per
-    // hand-over on ONE address serialised the whole kernel: 1.4 ms per 4e6 rays, 73 % of the wave cycles waiting)
-    // A ray is handed over when it ARRIVES at the last scattering wall: the continuation starts with the rest of that
-    // surface's step (back test, move by cont_t, normal, Fresnel) in its own filtered arithmetic.
-    double *cont_pos_dir;
-    double *cont_t;
-    uint64_t *cont_draw;
-    int32_t *cont_nis;
-    uint64_t cont_cap;
-    int cont_k0;                 // first surface of the continuation (= last scattering surface + 1)
-    // work distribution of scatter_front_kernel (kScatCtlWords words, zero before every launch): eight heads, one per
-    // XCD (head x hands out the rays [x scat_share, (x + 1) scat_share) of the launch, scat_grab at a time), and the
-    // count of hand-over slots allocated so far (what the continuation walks)
-    unsigned long long *scat_ctl;
-    uint64_t scat_share;
-    uint32_t scat_grab;
-    const long long *img_cdf;    // image-source table or null
-    // fp32 queued kernels: hits are LOGGED, not binned (see bin_log_kernel).  The log has kBinTiles parts of hit_stride
-    // 16-bit entries, part t for the bins with bin % kBinTiles == t (entry = bin / kBinTiles).  A wave writes its hits to
-    // the bottom of its own region of each part — entries [lo, lo + hits_t) of its ray range [lo, hi): a ray ends at
-    // most once — and leaves hits_0 .. hits_4 and lo in its eight words of the directory
-    uint16_t *hit_log;
-    uint64_t hit_stride;
-    uint32_t hit_base;           // this launch's first entry in every part (the log holds several launches: bin_pending)
-    uint32_t *hit_dir;           // this launch's first directory entry
-    double *path;                // [n][ORT_MAX_PATH][3] or null (tracker)
-    int32_t *npath;
-};
-
-// cooperative copy of the system into LDS, 8 bytes per thread per pass
-__device__ inline void stage_system(ort_system &dst, const ort_system *src)
-{
-    constexpr int words = sizeof(ort_system) / 8;
-    static_assert(sizeof(ort_system) % 8 == 0, "ort_system must be a whole number of 8-byte words");
-    const uint64_t *s = reinterpret_cast<const uint64_t *>(src);
-    uint64_t *d = reinterpret_cast<uint64_t *>(&dst);
-    for (int i = threadIdx.x; i < words; i += blockDim.x) d[i] = s[i];
-    __syncthreads();
-}
-
-// fp32 path: the same system in single precision (each value rounded to nearest once)
-__host__ __device__ inline void convert_surface(SurfaceT<float> &b, const ort_surface &a)
-{
-    b.cx = (float)a.cx; b.cy = (float)a.cy; b.cz = (float)a.cz; b.radius = (float)a.radius;
-    b.radius_b = (float)a.radius_b; b.n1 = (float)a.n1; b.n2 = (float)a.n2; b.eta = (float)a.eta;
-    b.aperture = (float)a.aperture; b.kind = a.kind; b.flags = a.flags;
-    b.mua = (float)a.mua; b.mus = (float)a.mus; b.hgg = (float)a.hgg; b.scat_radius = (float)a.scat_radius;
-}
-__host__ __device__ inline void convert_globals(SystemT<float> &dst, const ort_system &src)
-{
-    dst.n_surfaces[0] = src.n_surfaces[0]; dst.n_surfaces[1] = src.n_surfaces[1];
-    dst.split[0] = src.split[0]; dst.split[1] = src.split[1];
-    dst.ring_ellipse = src.ring_ellipse; dst.pad = 0;
-    dst.cos_theta_max = (float)src.cos_theta_max;
-    dst.ring_r1 = (float)src.ring_r1; dst.ring_r2 = (float)src.ring_r2;
-    dst.ring_lens_r2 = (float)src.ring_lens_r2; dst.ring_lens_z = (float)src.ring_lens_z;
-    dst.ring_bottle_ra = (float)src.ring_bottle_ra; dst.ring_bottle_rb = (float)src.ring_bottle_rb;
-    dst.ring_bottle_z = (float)src.ring_bottle_z;
-    dst.bin_width = (float)src.bin_width; dst.inv_bin_width = (float)src.inv_bin_width;
-    dst.na_cos_min = (float)src.na_cos_min; dst.twopi = (float)src.twopi;
-    dst.spot_dphi = (float)src.spot_dphi; dst.spot_dtheta = (float)src.spot_dtheta;
-    dst.crs_sigma = (float)src.crs_sigma; dst.crs_radius = (float)src.crs_radius;
-    dst.crs_cy = (float)src.crs_cy; dst.crs_cz = (float)src.crs_cz;
-    dst.img_lens_r2 = (float)src.img_lens_r2; dst.img_lens_z = (float)src.img_lens_z;
-    dst.point_offset = (float)src.point_offset;
-    dst.isors_sigma = (float)src.isors_sigma; dst.isors_k = (float)src.isors_k; dst.isors_height = (float)src.isors_height;
-    dst.isors_base_pos = (float)src.isors_base_pos; dst.isors_z = (float)src.isors_z;
-    dst.isors_rad1 = (float)src.isors_rad1; dst.isors_rad2 = (float)src.isors_rad2;
-    dst.isors_cy = (float)src.isors_cy; dst.isors_cz = (float)src.isors_cz;
-    dst.isors_lens_r2 = (float)src.isors_lens_r2; dst.isors_lens_z = (float)src.isors_lens_z;
-    dst.emitter[0] = src.emitter[0]; dst.emitter[1] = src.emitter[1];
-}
-inline void convert_system(SystemT<float> &dst, const ort_system &src)      // host
-{
-    for (int i = 0; i < 2 * ORT_MAX_SURFACES; ++i)
-        convert_surface(dst.surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES], src.surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES]);
-    convert_globals(dst, src);
-}
-// ... and converted once per workgroup while staging (generic kernels)
-__device__ inline void stage_system(SystemT<float> &dst, const ort_system *src)
-{
-    for (int i = threadIdx.x; i < 2 * ORT_MAX_SURFACES; i += blockDim.x)
-        convert_surface(dst.surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES], src->surfaces[i / ORT_MAX_SURFACES][i % ORT_MAX_SURFACES]);
-    if (threadIdx.x == 0) convert_globals(dst, *src);
-    __syncthreads();
-}
-
-// the phase's per-surface derived constants (ort_device.h: SurfAuxT), one thread per surface
-template <class T, class Surf>
-__device__ inline void stage_aux(SurfAuxT<T> *aux, const Surf *surf, int ns)
-{
-    if ((int)threadIdx.x < ns) aux[threadIdx.x] = make_aux<T>(surf[threadIdx.x]);
-    __syncthreads();
-}
-
-// Where this workgroup bins its hits.  With one image, every wave of the chip queues its atomics
-// on the same few thousand 64-byte lines of the focal blob (measured in round 1: +0.19 ms on a
-// 0.75 ms launch).  So the hits go to one of kReplicas private copies, one per XCD, read from the
-// hardware (HW_REG_XCC_ID; blockIdx % 8 only says which blocks share an XCD while the placement is
-// round-robin, which it is not while the tail of a previous kernel occupies some XCDs).
-// A hit is a no-return atomic that the L2 forwards to the memory side (the 8 L2s are not coherent
-// with each other: TCC_EA0_ATOMIC counts one request, and one 32-byte DRAM write, per hit).  The
-// blob is ~17 000 bins, half of the hits on 1000 of them: stored row by row that is ~100 very hot
-// lines per replica, and how those happen to fall on the memory channels decided the launch time
-// — the same kernel took 0.40 or 0.48 ms (fast fp64: 0.34 - 0.55 ms) depending on where the
-// context's buffers lay (TCC_EA0_WRREQ_STALL x 3 in the slow placements).  So within a replica the
-// bins are scattered over 2^18 slots by a multiplicative hash: every hot bin gets a line of its own
-// and the load spreads over all channels, whatever the placement.  fold_kernel undoes the hash.
-// Integer adds commute: the image is bit-identical either way.
-__device__ inline int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7; }   // hwreg(HW_REG_XCC_ID, 0, 4)
-
-__device__ inline void bin_hit(int32_t *layer, int xp, int yp, bool replicated)
-{
-    const uint32_t bin = (uint32_t)((xp + 200) + ORT_IMAGE_N * (yp + 200));         // imageMod.f90:55-56
-#ifdef ORT_DEV_NO_BIN                                                                // A/B build: what the image atomics cost
-    if (xp != 0x7fffffff) return;
-#endif
-    atomicAdd(&layer[replicated ? (bin * kSlotMul) & (kSlots - 1) : bin], 1);
-}
-
-__device__ inline int32_t *hist_layer(const TraceArgs &a)
-{
-    if (a.replicas) return a.replicas + (size_t)xcc_id() * kReplicaInts + (size_t)(a.phase - 1) * kSlots;
-    return a.image + (size_t)(a.phase - 1) * ORT_IMAGE_N * ORT_IMAGE_N;
-}
 
 // image[layer] += sum of the replicas' layer; replicas are left zero for the next launch.
 // Thread j sums slot j of the 8 replicas (coalesced) and adds it to the bin the slot belongs to.
@@ -264,10 +54,6 @@ __global__ __launch_bounds__(256) void fold_kernel(int32_t *image, int32_t *repl
 // then ADDED — plain loads and stores, no atomic — to slab u
 // of the layer, which this workgroup alone touches during the launch (launches are ordered by the stream).
 // fold_slabs_kernel sums the kBinUnits slabs into the image when it is next needed (flush_replicas).
-// Integer adds commute: the image equals the one the atomics would have produced, bit for bit.
-constexpr int kBinUnits = 51, kBinTiles = 5, kBinTile = (ORT_IMAGE_N * ORT_IMAGE_N + kBinTiles - 1) / kBinTiles, kBinDirMax = 2048;
-constexpr int kBinThreads = 1024, kBinDirWords = 8;
-static_assert(kBinTile <= 65536, "a log entry (bin / kBinTiles) must fit 16 bits");
 __global__ __launch_bounds__(kBinThreads) void bin_log_kernel(const uint16_t *log, uint64_t stride, const uint32_t *dir, uint32_t nwaves,
                                                                uint32_t wpu, int32_t *slabs)
 {
@@ -353,1167 +139,6 @@ __global__ __launch_bounds__(256) void fold_slabs_kernel(int32_t *image, int32_t
     }
 }
 
-// One lockstep pass of a wave over surfaces [k0, k1): every lane steps with its `st`
-// predicate; the loop leaves as soon as no lane of the wave is alive (uniform branch).
-// KEEP: see surface_step — false where only st/xp/yp/nis of an ended ray are read afterwards.
-template <bool FILT, class T, bool EXT, bool KEEP, class Sys, class Surf, class D>
-__device__ inline void walk_pass(const Sys &S, const Surf *surf, const SurfAuxT<T> *aux, int k0, int k1,
-                                 RayT<T> &r, D &draws, int &nis, int &st, int &xp, int &yp, bool &rare)
-{
-    for (int k = k0; k < k1; ++k) {
-        if (!wave_any_live(st)) break;
-#ifdef ORT_DBG_RARE
-        const bool before = rare;
-#endif
-        surface_step<FILT, T, EXT, KEEP>(S, surf[k], aux[k], r, draws, nis, st, xp, yp, rare);
-#ifdef ORT_DBG_RARE
-        if (rare && !before && k < 8) atomicAdd(&ort::ort_dbg_rare[8 + k], 1ull);   // first raise, by surface
-#endif
-    }
-}
-
-// What a context keeps on the device: the system as the caller staged it, plus the derived
-// per-surface constants (SurfAuxT; formed on the host by the same IEEE operations).
-struct DevSystem {
-    ort_system sys;
-    SurfAuxT<double> aux[2][ORT_MAX_SURFACES];
-    SystemT<float> sysf;                         // fp32 path: converted once on the host (round to nearest,
-    SurfAuxT<float> auxf[2][ORT_MAX_SURFACES];   // as v_cvt_f32_f64 would), constants formed in fp32
-};
-
-// The program kernels know each step's surface index at compile time, so they read its record
-// straight from the device copy through the CONSTANT address space: uniform address + constant
-// memory = scalar loads (s_load_dwordx*) into SGPRs.  The values then feed the vector
-// instructions as scalar operands instead of occupying VGPRs (an LDS read lands in VGPRs), which
-// is what lets the unrolled kernel fit 128 VGPRs without spilling.
-template <class T> struct ConstPtrs {       // fp64 and fast fp64 read the fp64 records
-    typedef const __attribute__((address_space(4))) ort_system *sys_t;
-    typedef const __attribute__((address_space(4))) ort_surface *surf_t;
-    typedef const __attribute__((address_space(4))) SurfAuxT<double> *aux_t;
-    typedef ort_surface Surf;
-};
-template <> struct ConstPtrs<float> {
-    typedef const __attribute__((address_space(4))) SystemT<float> *sys_t;
-    typedef const __attribute__((address_space(4))) SurfaceT<float> *surf_t;
-    typedef const __attribute__((address_space(4))) SurfAuxT<float> *aux_t;
-    typedef SurfaceT<float> Surf;
-};
-
-template <class T>
-__device__ inline typename ConstPtrs<T>::Surf load_surface(typename ConstPtrs<T>::surf_t p)
-{
-    typename ConstPtrs<T>::Surf s;
-    s.cx = p->cx; s.cy = p->cy; s.cz = p->cz; s.radius = p->radius; s.radius_b = p->radius_b;
-    s.n1 = p->n1; s.n2 = p->n2; s.eta = p->eta; s.aperture = p->aperture;
-    s.mua = p->mua; s.mus = p->mus; s.hgg = p->hgg; s.scat_radius = p->scat_radius;
-    s.kind = p->kind; s.flags = p->flags;
-    return s;
-}
-
-template <class T>
-__device__ inline SurfAuxT<T> load_aux(typename ConstPtrs<T>::aux_t p)
-{
-    SurfAuxT<T> a;
-    a.r2 = T(p->r2); a.ap2 = T(p->ap2); a.ap_tol = T(p->ap_tol); a.eta2 = T(p->eta2);
-    a.ell_sa = T(p->ell_sa); a.ell_sb = T(p->ell_sb);
-    a.rh = T(p->rh); a.rk = T(p->rk); a.r2_tol = T(p->r2_tol);
-    a.ap_lo = T(p->ap_lo); a.ap_hi = T(p->ap_hi);
-    a.ax_ly = T(p->ax_ly); a.ax_lz = T(p->ax_lz); a.ax_c = T(p->ax_c);      // (read by step 0 of the point programs only)
-    return a;
-}
-
-// Surface programs known at compile time.  The reference's two loops walk a fixed list in
-// their default set-up (bottle present, no iris, circular bottle): with the kinds, flags and
-// aperture presence as template constants the per-step dispatch (readfirstlane + scalar
-// branches + the blocks they cut the schedule into) disappears and the steps are laid out
-// back to back: -8 % kernel time.  The host selects a program only when the staged system
-// matches it field for field (match_program); everything else runs the generic walk.
-// A program = a surface LIST (low four bits) + the light source in front of it (bits 4..): 0 the phase's default emitter
-// (ring / point), SRC_* another one.  Every list is instantiated with every source its phase has.
-enum { PROG_GENERIC = 0, PROG_POINT, PROG_RING, PROG_POINT_IRIS_B, PROG_POINT_IRIS_A, PROG_RING_IRIS_B, PROG_RING_IRIS_A,
-       PROG_POINT_BARE, PROG_POINT_ELLIPSE, PROG_LIST_MASK = 15 };
-enum { SRC_CRS = 1 << 4, SRC_ISORS = 2 << 4, SRC_IMAGE = 3 << 4, SRC_HANDED_OVER = 4 << 4 };
-constexpr int PROG_CRS = PROG_RING | SRC_CRS, PROG_ISORS = PROG_RING | SRC_ISORS, PROG_IMAGE = PROG_POINT | SRC_IMAGE,
-              PROG_POINT_WALKED = PROG_POINT | SRC_HANDED_OVER;
-// every list with its phase's default emitter (ring / point): X(name) — instantiated fused and resident, in every arithmetic
-#define ORT_RING_LISTS(X, S) X(PROG_RING | S) X(PROG_RING_IRIS_B | S) X(PROG_RING_IRIS_A | S)
-#define ORT_POINT_LISTS(X, S) X(PROG_POINT | S) X(PROG_POINT_IRIS_B | S) X(PROG_POINT_IRIS_A | S) X(PROG_POINT_BARE | S) X(PROG_POINT_ELLIPSE | S)
-#define ORT_PROGRAMS(X) ORT_POINT_LISTS(X, 0) ORT_RING_LISTS(X, 0)
-// ... and with the other bulk light sources (runner.py's crs / iSORS / Bessel-image experiments, with and without an iris):
-// crs and isors in front of the ring loop's lists, the image source in front of the point loop's; fused, fp64 and fp32
-// (resident bundles and fast fp64 of those sources run the generic walk)
-#define ORT_SOURCE_PROGRAMS(X) ORT_RING_LISTS(X, SRC_CRS) ORT_RING_LISTS(X, SRC_ISORS) ORT_POINT_LISTS(X, SRC_IMAGE)
-
-namespace prog {
-constexpr int CYL = ORT_SURF_CYLINDER, ELL = ORT_SURF_ELLIPSE, PLN = ORT_SURF_PLANE, SPH = ORT_SURF_SPHERE, IRS = ORT_SURF_IRIS, IMG = ORT_SURF_IMAGE;
-constexpr int SK = ORT_F_SKIP_ON_REFLECT, BT = ORT_F_BOTTLE | ORT_F_SKIP_ON_REFLECT, H3 = ORT_F_SKIP_ON_REFLECT | ORT_F_MISS_IS_HELP3;
-}
-template <int P> struct Prog;
-// point loop, src/main.f90:127-162: bottle (2 cylinders), plano-convex (flat, curved), doublet (3 faces), image
-template <> struct Prog<PROG_POINT> {
-    static constexpr int phase = 2, n = 8, split = 5;
-    static constexpr int emitter = ORT_EMIT_POINT;
-    static constexpr int kind[n] = {prog::CYL, prog::CYL, prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
-    static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
-    static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 0};
-};
-// ring loop, src/main.f90:90-109: plano-convex, doublet, image
-template <> struct Prog<PROG_RING> {
-    static constexpr int phase = 1, n = 6, split = 1;
-    static constexpr int emitter = ORT_EMIT_RING;
-    static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
-    static constexpr int flags[n] = {0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
-    static constexpr int ap[n] = {1, 0, 1, 0, 0, 0};
-};
-// the same with the iris in front of the doublet (src/lens.f90:551-565) ...
-template <> struct Prog<PROG_POINT_IRIS_B> {
-    static constexpr int phase = 2, n = 9, split = 6;
-    static constexpr int emitter = ORT_EMIT_POINT;
-    static constexpr int kind[n] = {prog::CYL, prog::CYL, prog::PLN, prog::SPH, prog::IRS, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
-    static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, 0, prog::SK, prog::SK, prog::H3, 0};
-    static constexpr int ap[n] = {0, 0, 1, 0, 1, 1, 0, 0, 0};
-};
-template <> struct Prog<PROG_RING_IRIS_B> {
-    static constexpr int phase = 1, n = 7, split = 1;
-    static constexpr int emitter = ORT_EMIT_RING;
-    static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::IRS, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
-    static constexpr int flags[n] = {0, prog::SK, 0, prog::SK, prog::SK, prog::H3, 0};
-    static constexpr int ap[n] = {1, 0, 1, 1, 0, 0, 0};
-};
-// ... and behind it (src/lens.f90:632-644)
-template <> struct Prog<PROG_POINT_IRIS_A> {
-    static constexpr int phase = 2, n = 9, split = 5;
-    static constexpr int emitter = ORT_EMIT_POINT;
-    static constexpr int kind[n] = {prog::CYL, prog::CYL, prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IRS, prog::IMG};
-    static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, prog::SK, prog::SK, prog::H3, 0, 0};
-    static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 1, 0};
-};
-template <> struct Prog<PROG_RING_IRIS_A> {
-    static constexpr int phase = 1, n = 7, split = 1;
-    static constexpr int emitter = ORT_EMIT_RING;
-    static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IRS, prog::IMG};
-    static constexpr int flags[n] = {0, prog::SK, prog::SK, prog::SK, prog::H3, 0, 0};
-    static constexpr int ap[n] = {1, 0, 1, 0, 0, 1, 0};
-};
-
-// the point loop without the bottle (use_bottle = false, src/main.f90:147)
-template <> struct Prog<PROG_POINT_BARE> {
-    static constexpr int phase = 2, n = 6, split = 3;
-    static constexpr int emitter = ORT_EMIT_POINT;
-    static constexpr int kind[n] = {prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
-    static constexpr int flags[n] = {0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
-    static constexpr int ap[n] = {1, 0, 1, 0, 0, 0};
-};
-
-// the point loop through an elliptical bottle (src/lens.f90:221-225)
-template <> struct Prog<PROG_POINT_ELLIPSE> {
-    static constexpr int phase = 2, n = 8, split = 5;
-    static constexpr int emitter = ORT_EMIT_POINT;
-    static constexpr int kind[n] = {prog::ELL, prog::ELL, prog::PLN, prog::SPH, prog::SPH, prog::SPH, prog::SPH, prog::IMG};
-    static constexpr int flags[n] = {prog::BT, prog::BT, 0, prog::SK, prog::SK, prog::SK, prog::H3, 0};
-    static constexpr int ap[n] = {0, 0, 1, 0, 1, 0, 0, 0};
-};
-
-// a list behind another light source: the crs source (point_on_bottle, src/sourceMod.f90:50-89, src/main.f90:99), the isors
-// source (iSORS, :162-247, main.f90:97), the image source (emit_image, :303-361, main.f90:133) — or, SRC_HANDED_OVER, behind
-// a scattering bottle (trace_queue_kernel<MODE_CONTINUE>: rays handed over by scatter_front_kernel, each at its own draw;
-// whatever source emitted them)
-constexpr int ORT_EMIT_HANDED_OVER = -2;
-constexpr int source_emitter(int src)
-{
-    return src == SRC_CRS ? ORT_EMIT_CRS : src == SRC_ISORS ? ORT_EMIT_ISORS : src == SRC_IMAGE ? ORT_EMIT_IMAGE : ORT_EMIT_HANDED_OVER;
-}
-template <int P> struct Prog : Prog<(P & PROG_LIST_MASK)> {
-    static_assert(P > PROG_LIST_MASK, "a list without a Prog<> specialisation");
-    static constexpr int emitter = source_emitter(P & ~PROG_LIST_MASK);
-};
-
-template <int P> constexpr bool prog_is_ring()             // phase-1 list (plano-convex first)
-{
-    if constexpr (P == PROG_GENERIC) return false;
-    else return Prog<P>::phase == 1;
-}
-// segment 0 (the cull by the third draw) belongs to the ring EMITTER
-template <int P> constexpr bool prog_culls()
-{
-    if constexpr (P == PROG_GENERIC) return false;
-    else return Prog<P>::phase == 1 && Prog<P>::emitter == ORT_EMIT_RING;
-}
-// does every ray reach step K at the same draw index?  ring (4 draws), point (2), image (4): yes; crs and isors
-// draw a variable number (polar Box-Muller, src/random_mod.f90:59-85): their steps count draws per lane
-template <int P> constexpr bool prog_static_draws()
-{
-    if constexpr (P == PROG_GENERIC) return false;
-    else return Prog<P>::emitter == ORT_EMIT_RING || Prog<P>::emitter == ORT_EMIT_POINT || Prog<P>::emitter == ORT_EMIT_IMAGE;
-}
-// the rays of the program start where `point` puts them, in front of a circular cylinder (OPT_AXIAL_START)
-template <int P> constexpr bool prog_starts_on_axis()
-{
-    if constexpr (P == PROG_GENERIC) return false;
-    else return Prog<P>::emitter == ORT_EMIT_POINT && Prog<P>::kind[0] == ORT_SURF_CYLINDER;
-}
-
-// the step the queue point of trace_queue_kernel lies in, + 1.  Prog<P>::split (the host's choice for
-// the list: behind the stop that removes most rays) — except in the fused ring programs: their
-// segment 0 has already removed the rays the first stop would, every ray that reaches segment 1
-// passes it, and the next stop (the doublet's first face, step 2) ends nearly all of them
-template <int P, int MODE> constexpr int queue_step()
-{
-    if constexpr (P == PROG_GENERIC) return 0;
-    else if constexpr (prog_is_ring<P>() && MODE == MODE_FUSED) {
-        for (int k = 1; k < Prog<P>::n; ++k)
-            if (Prog<P>::ap[k] != 0 && Prog<P>::kind[k] != ORT_SURF_IRIS && Prog<P>::kind[k] != ORT_SURF_IMAGE) return k + 1;
-        return Prog<P>::split;
-    } else return Prog<P>::split;
-}
-
-// draws a ray has consumed before step K of program P: the emitter's (point 2, ring 4:
-// src/sourceMod.f90:31-37, :266-286) plus one per refracting surface passed (an iris and the image
-// plane draw nothing)
-template <int P> constexpr int draw_index(int K)
-{
-    if (!prog_static_draws<P>()) return -1;              // surface_step DK < 0: per-lane draw counter
-    int d = Prog<P>::emitter == ORT_EMIT_POINT ? 2 : 4;
-    for (int j = 0; j < K; ++j)
-        if (Prog<P>::kind[j] != ORT_SURF_IRIS && Prog<P>::kind[j] != ORT_SURF_IMAGE) d++;
-    return d;
-}
-
-// steps [K, K1) of program P, each entered only while some lane of the wave is alive.  FRESH: no
-// hash is at hand for the next odd draw (the walk starts behind the queue)
-// OPT: what every step may assume (ort_device.h OPT_*); a step's status carries its intersection count
-// (surface_step NISK)
-// (OPT_COUNT_STEPS: the rays did not start at step 0 with a count of 0 — they are counted per step and lane)
-constexpr int OPT_COUNT_STEPS = 8;
-template <int K, int OPT = 0> constexpr int nisk() { return !(OPT & OPT_COUNT_STEPS) ? K + 1 : -1; }
-
-template <bool FILT, class T, bool KEEP, int P, int K, int K1, bool FRESH, int OPT, class Sys, class D>
-__device__ inline void walk_fixed(const Sys &S, typename ConstPtrs<T>::surf_t surf, typename ConstPtrs<T>::aux_t aux, RayT<T> &r, D &draws,
-                                  int &nis, int &st, int &xp, int &yp, bool &rare)
-{
-    if constexpr (K < K1) {
-        if (wave_any_live(st)) {
-            const typename ConstPtrs<T>::Surf s = load_surface<T>(surf + K);
-            const SurfAuxT<T> ax = load_aux<T>(aux + K);
-#ifdef ORT_ISA_MARKERS      // tools/isa_budget.py: comment lines that delimit the steps in the listing
-            asm volatile("; ORT_STEP_BEGIN %0" ::"n"(K));
-#endif
-            constexpr bool draws_here = Prog<P>::kind[K] != ORT_SURF_IRIS && Prog<P>::kind[K] != ORT_SURF_IMAGE;
-            constexpr int OPTK = K == 0 ? OPT : (OPT & ~OPT_AXIAL_START);       // the emitter's position holds at the first surface only
-            if constexpr (draws_here && Prog<P>::ap[K] != 0 && !KEEP) {
-                // a refracting step with an aperture stop, in halves (surface_step PART): when the stop
-                // ends every ray of the wavefront — the doublet's first face does that to 9 of 10
-                // wavefronts of the ring loop — the normalisation and the Fresnel arithmetic are skipped
-                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 1, nisk<K, OPT>(), OPTK>(
-                    S, s, ax, r, draws, nis, st, xp, yp, rare);
-                if (wave_any_live(st))
-                    surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 2, nisk<K, OPT>(), OPTK>(
-                        S, s, ax, r, draws, nis, st, xp, yp, rare);
-            } else {
-                surface_step<FILT, T, false, KEEP, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), FRESH, 0, nisk<K, OPT>(), OPTK>(
-                    S, s, ax, r, draws, nis, st, xp, yp, rare);
-            }
-#ifdef ORT_ISA_MARKERS
-            asm volatile("; ORT_STEP_END %0" ::"n"(K));
-#endif
-            walk_fixed<FILT, T, KEEP, P, K + 1, K1, FRESH && !draws_here, OPT>(S, surf, aux, r, draws, nis, st, xp, yp, rare);
-        }
-    }
-}
-
-// one half (PART 1 / 2, ort_device.h: surface_step) of step K of program P: the step the queue point
-// of trace_queue_kernel sits in
-template <bool FILT, class T, int P, int K, int PART, int OPT, class Sys, class D>
-__device__ inline void step_part(const Sys &S, typename ConstPtrs<T>::surf_t surf, typename ConstPtrs<T>::aux_t aux, RayT<T> &r, D &draws,
-                                 int &nis, int &st, int &xp, int &yp, bool &rare)
-{
-    if (wave_any_live(st)) {
-        const typename ConstPtrs<T>::Surf s = load_surface<T>(surf + K);
-        const SurfAuxT<T> ax = load_aux<T>(aux + K);
-#ifdef ORT_ISA_MARKERS
-        if (PART == 1) asm volatile("; ORT_STEP_BEGIN %0" ::"n"(K));
-#endif
-        surface_step<FILT, T, false, false, Prog<P>::kind[K], Prog<P>::flags[K], Prog<P>::ap[K], draw_index<P>(K), PART == 2, PART, nisk<K, OPT>(), (K == 0 ? OPT : (OPT & ~OPT_AXIAL_START))>(
-            S, s, ax, r, draws, nis, st, xp, yp, rare);
-#ifdef ORT_ISA_MARKERS
-        if (PART == 2) asm volatile("; ORT_STEP_END %0" ::"n"(K));
-#endif
-    }
-}
-
-// The segment [k0, k1) with the reference's outcome for every lane.  FILT: one pass with the
-// filtered predicates; if any lane raised `rare` (ort_device.h) the wave runs the segment again
-// from its initial state — `restore(r, draws, st)` re-creates it: reloaded or re-emitted, so no
-// register is held for it through the hot pass — with the literal formulas, and the flagged
-// lanes take that run's results.  One rare branch per segment instead of one per predicate.
-template <bool FILT, class T, bool EXT, bool KEEP, class Sys, class Surf, class D, class Restore>
-__device__ inline void walk(const Sys &S, const Surf *surf, const SurfAuxT<T> *aux, int k0, int k1,
-                            RayT<T> &r, D &draws, int &nis, int &st, int &xp, int &yp, Restore restore)
-{
-    bool rare = false;
-    if constexpr (!FILT) {
-        walk_pass<false, T, EXT, KEEP>(S, surf, aux, k0, k1, r, draws, nis, st, xp, yp, rare);
-    } else {
-        const int nis0 = nis, xp0 = xp, yp0 = yp;
-        walk_pass<true, T, EXT, KEEP>(S, surf, aux, k0, k1, r, draws, nis, st, xp, yp, rare);
-        if (!kLoose<T> && wave_rare(rare)) {             // (fp32: the filtered forms stand)
-            RayT<T> r2;
-            D d2 = draws;
-            int st2, nis2 = nis0, xp2 = xp0, yp2 = yp0;
-            bool unused = false;
-            restore(r2, d2, st2);
-            walk_pass<false, T, EXT, KEEP>(S, surf, aux, k0, k1, r2, d2, nis2, st2, xp2, yp2, unused);
-            r.pos = vselect(rare, r2.pos, r.pos);
-            r.dir = vselect(rare, r2.dir, r.dir);
-            draws.take(rare, d2);
-            nis = rare ? nis2 : nis; st = rare ? st2 : st;
-            xp = rare ? xp2 : xp; yp = rare ? yp2 : yp;
-        }
-    }
-}
-
-// FILT: filtered predicates (ort_device.h); false = every predicate evaluated literally.
-template <int MODE, bool FILT, class T, bool ANYSRC>
-__global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs a)
-{
-    __shared__ typename SysTypes<T>::Sys S;
-    __shared__ unsigned int blk[4];       // lost, isect, binned, help3
-    // the re-run launch normally finds its list empty (no workgroup appends while it runs, so
-    // every workgroup reads the same count)
-    if (MODE != MODE_DEBUG && a.listed && a.redo_ctl[0] == 0) return;
-    __shared__ SurfAuxT<T> AUX[ORT_MAX_SURFACES];
-    stage_system(S, a.sys);
-    stage_aux(AUX, S.surfaces[a.phase - 1], S.n_surfaces[a.phase - 1]);
-    if (MODE != MODE_DEBUG) {
-        if (threadIdx.x < 4) blk[threadIdx.x] = 0;
-        __syncthreads();
-    }
-    unsigned int lost = 0, isect = 0, binned = 0, help3 = 0;
-    int32_t *layer = hist_layer(a);
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    // listed: the rays to trace are the entries of the re-run list (the queued filtered kernel
-    // appended the rays that sat on a decision boundary); otherwise all of [0, n_rays)
-    const bool listed = MODE != MODE_DEBUG && a.listed;
-    const uint64_t n = listed ? (uint64_t)a.redo_ctl[0] : a.n_rays;
-    const uint64_t ns_in = a.in_stride;                  // component stride of the input bundle
-
-    const int ns = S.n_surfaces[a.phase - 1];
-    const typename SysTypes<T>::Surf *surf = S.surfaces[a.phase - 1];
-    // whole waves iterate together (the tail wave keeps its out-of-range lanes dead)
-    const uint64_t base0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~63ull;
-    for (uint64_t wbase = base0; wbase < n; wbase += stride) {
-        const uint64_t j = wbase + (threadIdx.x & 63);
-        const bool act = j < n;
-        const uint64_t jc = act ? j : n - 1;             // clamped index for loads of idle lanes
-        const uint64_t ic = listed ? (uint64_t)a.redo_list[jc] : jc;
-        const uint64_t i = ic;                           // output index (debug entry: never listed)
-        RayT<T> r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}}, em;
-        int nis = 0, xp = -9999, yp = -9999, st = act ? -1 : ORT_ST_NA_REJECT;
-        const bool have_in = MODE != MODE_FUSED && a.pos_dir_in;
-        if (have_in) {
-            r.pos = {(T)a.pos_dir_in[0 * ns_in + ic], (T)a.pos_dir_in[1 * ns_in + ic], (T)a.pos_dir_in[2 * ns_in + ic]};
-            r.dir = {(T)a.pos_dir_in[3 * ns_in + ic], (T)a.pos_dir_in[4 * ns_in + ic], (T)a.pos_dir_in[5 * ns_in + ic]};
-        }
-        int kdraws = 0;
-        if (MODE == MODE_DEBUG) {
-            Draws d;
-            if (a.u) d.init_table(a.u + ic, (int64_t)n, a.nu, a.draw_base);
-            else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base, a.wide != 0);
-            if (!have_in) {
-                const Draws d_none = d;
-                const int est = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf, a.strict != 0);
-                st = est < 0 ? st : est;
-                const bool exhausted = est == ORT_ST_LOST_TELESCOPE;
-                d.take(exhausted, d_none);               // an exhausted image source emits nothing and draws nothing
-                if (exhausted) r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(0.)}};
-            }
-            em = r;
-            if (a.path) {
-                // tracker: the walk of `walk`, recording the pushes of src/stackMod.f90
-                int np = 0;
-                double *pp = a.path + (size_t)ic * ORT_MAX_PATH * 3;
-                auto push = [&](bool c) {
-                    if (c && act && np < ORT_MAX_PATH) {
-                        pp[np * 3 + 0] = (double)r.pos.x; pp[np * 3 + 1] = (double)r.pos.y; pp[np * 3 + 2] = (double)r.pos.z;
-                        np++;
-                    }
-                };
-                push(true);                                          // main.f90:103,144
-                for (int k = 0; k < ns; ++k) {
-                    if (!wave_any_live(st)) break;
-                    const bool was_live = st < 0;
-                    bool unused = false;                 // the tracker walks with the literal predicates
-                    surface_step<false, T, true>(S, surf[k], AUX[k], r, d, nis, st, xp, yp, unused);
-                    const bool track = (__builtin_amdgcn_readfirstlane((int)surf[k].flags) & ORT_F_TRACK) != 0;
-                    push(was_live && (st >= 0 || track));   // where it ended, or a tracked surface passed alive
-                }
-                if (act) a.npath[ic] = np;
-            } else {
-                const Draws d0 = d;
-                const int st0 = st;
-                walk<FILT, T, ANYSRC, true>(S, surf, AUX, 0, ns, r, d, nis, st, xp, yp,
-                                            [&](RayT<T> &rr, Draws &dd, int &ss) { rr = em; dd = d0; ss = st0; });
-            }
-            kdraws = d.k;
-        } else {
-            KeyedDrawsT<true> d;
-            d.init_keyed(a.rng_base, a.first_ray + ic, have_in ? a.draw_base : 0);
-            d.set_wide(a.wide != 0);
-            if (!have_in) {
-                const int est = emit<T, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf, a.strict != 0);
-                st = est < 0 ? st : est;
-            }
-            const RayT<T> r0 = r;
-            const KeyedDrawsT<true> d0 = d;
-            const int st0 = st;
-            walk<FILT, T, ANYSRC, false>(S, surf, AUX, 0, ns, r, d, nis, st, xp, yp,
-                                         [&](RayT<T> &rr, KeyedDrawsT<true> &dd, int &ss) { rr = r0; dd = d0; ss = st0; });
-        }
-        if (!act) continue;
-        if (MODE == MODE_DEBUG) {
-            if (a.pos_dir_out) {
-                a.pos_dir_out[0 * n + i] = (double)r.pos.x; a.pos_dir_out[1 * n + i] = (double)r.pos.y;
-                a.pos_dir_out[2 * n + i] = (double)r.pos.z; a.pos_dir_out[3 * n + i] = (double)r.dir.x;
-                a.pos_dir_out[4 * n + i] = (double)r.dir.y; a.pos_dir_out[5 * n + i] = (double)r.dir.z;
-            }
-            if (a.emitted_out) {
-                a.emitted_out[0 * n + i] = (double)em.pos.x; a.emitted_out[1 * n + i] = (double)em.pos.y;
-                a.emitted_out[2 * n + i] = (double)em.pos.z; a.emitted_out[3 * n + i] = (double)em.dir.x;
-                a.emitted_out[4 * n + i] = (double)em.dir.y; a.emitted_out[5 * n + i] = (double)em.dir.z;
-            }
-            if (a.status) a.status[i] = st;
-            if (a.bin_xy) { a.bin_xy[i] = xp; a.bin_xy[n + i] = yp; }
-            if (a.n_isect) a.n_isect[i] = nis;
-            if (a.n_draws) a.n_draws[i] = kdraws;
-        } else {
-            isect += (unsigned)nis;
-            if (st == ORT_ST_BINNED) {
-                binned++;
-                bin_hit(layer, xp, yp, a.replicas != nullptr);
-            } else if (st >= ORT_ST_LOST_BOTTLE) {
-                lost++;                                                       // optics_system.f90:32,42; main.f90:151
-                if (st == ORT_ST_HELP3) help3++;
-            }
-        }
-    }
-    if (MODE != MODE_DEBUG) {
-        atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect);
-        atomicAdd(&blk[2], binned); atomicAdd(&blk[3], help3);
-        __syncthreads();
-        if (threadIdx.x < 4 && blk[threadIdx.x])
-            atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
-        // the last workgroup to finish leaves the list empty for the next launch (every workgroup
-        // has read ctl[0] before it counts itself done)
-        if (listed && threadIdx.x == 0 && atomicAdd(&a.redo_ctl[1], 1u) == gridDim.x - 1) {
-            atomicAdd(&a.work[ORT_W_DEFERRED], (unsigned long long)a.redo_ctl[0]);
-            a.redo_ctl[0] = 0;
-            a.redo_ctl[1] = 0;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Queued variant ("wavefront per ray bundle"): every wave is an independent worker
-// over a contiguous range of global ray indices.  The surface list is cut into two
-// segments at S.split (host-chosen: just after the aperture stop that removes most
-// rays).  Segment 1 runs in lockstep on 64 fresh rays; the survivors are appended to
-// a wave-private ray queue in LDS (SoA: pos, dir in the kernel's precision, draw state; 128 slots).  As soon
-// as 64 rays are queued the wave runs segment 2 on a FULL wavefront.  Dead lanes of
-// segment 1 therefore never ride along through segment 2 — the lanes stay busy
-// although rays die at different surfaces.  No workgroup barrier is involved: a
-// queue is only ever touched by the wave that owns it.  Per-ray arithmetic and draw
-// order are exactly those of the lockstep kernel, so results are bit-identical.
-// With filtered predicates the kernel holds no literal formula at all: see `defer` below.
-// ---------------------------------------------------------------------------
-constexpr uint64_t kNoRay = ~0ull;   // hand-over bundle of the scattering pipeline: a slot without a ray
-// control words of the scattering pipeline (TraceArgs.scat_ctl), each on a 128-byte line of its own
-constexpr int kScatCtlStride = 16, kScatHeads = 8, kScatSlotsWord = kScatHeads * kScatCtlStride, kScatCtlWords = (kScatHeads + 1) * kScatCtlStride;
-constexpr int kScatWaves = 12;              // wavefronts per workgroup of scatter_front_kernel = per CU (LDS and 168 VGPRs allow no more)
-constexpr unsigned kHandChunk = 256;        // hand-over slots a wave allocates at a time
-constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kQueueCap = 128;      // >= 63 leftover + 64 new survivors
-constexpr int kQueueFields = 6;     // px py pz dx dy dz (+ the draw state: its own array)
-
-__device__ inline int lane_prefix(unsigned long long mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-}
-
-template <int MODE, bool FILT, bool ANYSRC, class T, int PROG = PROG_GENERIC, bool SCAT = ANYSRC>
-__global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) void trace_queue_kernel(TraceArgs a)
-{
-    static_assert(PROG == PROG_GENERIC || (!ANYSRC && !SCAT && FILT), "programs exist for the lean kernels only (filtered forms)");
-    // fp32 (kLoose): the filtered forms decide every lane — nothing is deferred, `rare` is not looked at
-    constexpr bool DEFER = FILT && !kLoose<T>;
-    __shared__ typename SysTypes<T>::Sys S;
-    // 26.6 KB per workgroup of a program kernel in fp64 (6 workgroups per CU's 160 KB), 14 KB in fp32
-    constexpr bool fixed = PROG != PROG_GENERIC;        // surface program known at compile time
-    using QT = typename std::conditional<std::is_same<T, float>::value, float, double>::type;
-    constexpr bool sdraws = prog_static_draws<PROG>();  // every lane at the same, compile-time draw index (ProgDraws)
-    using QD = typename std::conditional<sdraws, uint32_t, uint64_t>::type;  // static draws: the ray's index in the launch
-    __shared__ QT Q[kWavesPerBlock][kQueueFields][kQueueCap];
-    __shared__ QD QDRAW[kWavesPerBlock][kQueueCap];
-    // ring programs, fused: segment 0 (below) culls the rays that are certain to miss the first aperture
-    // before anything is emitted; the others wait here (ray index in the launch) for a full wave
-    constexpr bool PRE = prog_culls<PROG>() && MODE == MODE_FUSED;
-    __shared__ uint32_t CQ[kWavesPerBlock][PRE ? kQueueCap : 1];
-    // intersections evaluated before the queue point: `split` for every survivor unless a surface
-    // scatters (extended instantiation), so only that one carries the count through the queue
-    constexpr bool CARRY = SCAT || MODE == MODE_CONTINUE;     // the count differs from ray to ray at the queue point
-    __shared__ int QN[kWavesPerBlock][CARRY ? kQueueCap : 1];
-    __shared__ unsigned int blk[5];       // lost, isect, binned, help3, culled
-    __shared__ SurfAuxT<T> AUX[PROG == PROG_GENERIC ? ORT_MAX_SURFACES : 1];
-    // a program kernel reads everything it needs of the system (surface records, emitter and image
-    // constants) through scalar loads from the device copy: nothing to stage, no barrier at its start
-    if (PROG == PROG_GENERIC) {
-        stage_system(S, a.sys);
-        stage_aux(AUX, S.surfaces[a.phase - 1], S.n_surfaces[a.phase - 1]);
-    }
-    if (threadIdx.x < 5) blk[threadIdx.x] = 0;
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: the wave's range and loop control stay scalar
-    QT (*q)[kQueueCap] = Q[wave];
-    QD *qd = QDRAW[wave];
-    uint32_t *cq = CQ[wave];
-    int *qn = QN[wave];
-    using DrawsT = typename std::conditional<sdraws, ProgDraws, KeyedDraws>::type;
-    int phase = a.phase, ns, split;
-    if constexpr (fixed) {
-        phase = Prog<PROG>::phase; ns = Prog<PROG>::n; split = queue_step<PROG, MODE>();   // host: match_program
-        static_assert(queue_step<PROG, MODE>() < Prog<PROG>::n, "segment 1 of a program must end in front of its image plane (the fp32 hit log relies on it)");
-    } else {
-        ns = S.n_surfaces[phase - 1];
-        split = S.split[phase - 1];
-        if (split <= 0 || split >= ns) split = ns;      // no queue point: one segment
-    }
-    const int ph = phase - 1;
-    const typename SysTypes<T>::Surf *surf = S.surfaces[ph];
-    // program kernels: scalar loads from the device copy in the kernel's own precision
-    typename ConstPtrs<T>::sys_t csys;
-    typename ConstPtrs<T>::surf_t csurf;
-    typename ConstPtrs<T>::aux_t caux;
-    if constexpr (std::is_same<T, float>::value) {
-        csys = (typename ConstPtrs<T>::sys_t)a.sysf;
-        csurf = (typename ConstPtrs<T>::surf_t)a.sysf->surfaces[ph];
-        caux = (typename ConstPtrs<T>::aux_t)a.auxf;
-    } else {
-        csys = (typename ConstPtrs<T>::sys_t)a.sys;
-        csurf = (typename ConstPtrs<T>::surf_t)a.sys->surfaces[ph];
-        caux = (typename ConstPtrs<T>::aux_t)a.aux;
-    }
-    int32_t *layer = hist_layer(a);
-    // MODE_CONTINUE: the slots of the hand-over bundle, one per ray of the launch, some of them empty
-    // MODE_CONTINUE: the hand-over slots the front kernel allocated (a count it left on the device), some of them empty
-    uint64_t n = a.n_rays;
-    if (MODE == MODE_CONTINUE) {
-        const uint64_t used = (uint64_t)a.scat_ctl[kScatSlotsWord];
-        n = used < a.cont_cap ? used : a.cont_cap;
-    }
-    const uint64_t ns_in = MODE == MODE_CONTINUE ? a.cont_cap : a.in_stride;
-    const int k0 = MODE == MODE_CONTINUE ? a.cont_k0 : 0;     // first surface walked here
-    if (MODE == MODE_CONTINUE && split <= k0) split = ns;     // no queue point behind the start: one segment
-
-    // contiguous, 64-aligned range of ray indices for this wave: long ranges for the workgroups of
-    // the first rounds, short ones for the last workgroups (plan_ranges), so that the chip drains evenly
-    uint64_t lo, hi;
-    if (MODE == MODE_CONTINUE) {                            // the slot count is only known here: equal ranges over the grid
-        const uint64_t nw = (uint64_t)gridDim.x * kWavesPerBlock, wid = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
-        const uint64_t chunk = (((n + nw - 1) / nw) + 63) & ~63ull;
-        lo = wid * chunk; if (lo > n) lo = n;
-        hi = lo + chunk;  if (hi > n) hi = n;
-    } else {
-        const bool head = blockIdx.x < a.head_blocks;
-        const uint64_t wid = (uint64_t)(head ? blockIdx.x : blockIdx.x - a.head_blocks) * kWavesPerBlock + wave;
-        const uint64_t chunk = head ? a.head_chunk : a.tail_chunk;
-        const uint64_t end = head ? a.head_rays : n;
-        lo = (head ? 0 : a.head_rays) + wid * chunk; if (lo > end) lo = end;
-        hi = lo + chunk;  if (hi > end) hi = end;
-    }
-
-    // what the steps of a program kernel may assume (ort_device.h): fused rays have unit directions (they
-    // were emitted here), the lens spheres of every program are centred on the axis (host: matches<P>)
-    // (axial start: exact fp64 only — fast fp64 contracts L.L into fmas that the constants of the host do not replay; fp32 keeps its literal steps)
-    constexpr bool axial = MODE == MODE_FUSED && prog_starts_on_axis<PROG>() && FILT && std::is_same<T, double>::value;
-    constexpr int OPT = fixed ? ((MODE == MODE_FUSED ? OPT_UNIT_DIR : 0) | OPT_ON_AXIS | (axial ? OPT_AXIAL_START : 0) |
-                                 (MODE == MODE_CONTINUE ? OPT_COUNT_STEPS : 0)) : 0;
-    constexpr bool tagged = fixed && MODE != MODE_CONTINUE;     // st = ORT_ST_* | intersections << 8
-    // fp32: the hits go to the launch's log instead of the image (bin_log_kernel: the memory-side atomics bound this kernel)
-    constexpr bool LOG = kLoose<T> && MODE != MODE_CONTINUE;
-    const bool logging = LOG && a.hit_log != nullptr;           // the host's choice per launch (launch_trace)
-    unsigned int lost = 0, isect = 0, binned = 0, help3 = 0, culled = 0;
-    unsigned int hits[kBinTiles] = {0, 0, 0, 0, 0};            // LOG: entries this wave has written to each part (wave-uniform)
-    auto finish = [&](int st_in, int nis_in, int xp, int yp) {
-        const int st = tagged ? status_code(st_in) : st_in;
-        const int nis = tagged ? status_isect(st_in) : nis_in;
-        isect += (unsigned)nis;
-        if (st == ORT_ST_BINNED) {
-            binned++;
-            if (!logging) bin_hit(layer, xp, yp, a.replicas != nullptr);
-        } else if (st >= ORT_ST_LOST_BOTTLE) {
-            lost++;                                                          // optics_system.f90:32,42; main.f90:151
-            if (st == ORT_ST_HELP3) help3++;
-        }
-    };
-    // A ray that raised `rare` (ort_device.h: it sat on a decision boundary of a filtered
-    // predicate) leaves this kernel without any side effect: its index goes to the re-run list
-    // and trace_kernel<literal> traces it from the start afterwards.  ~4e-6 of the rays.
-    auto defer = [&](uint64_t i) { a.redo_list[atomicAdd(&a.redo_ctl[0], 1u)] = (uint32_t)(a.defer_base + i); };
-    // LOG: called by the whole wave (uniform control flow) with `hit` = this lane's ray ended binned in this pass
-    auto log_hits = [&](bool hit, int st_in, int xp, int yp) {
-        hit = hit && (tagged ? status_code(st_in) : st_in) == ORT_ST_BINNED;
-        const uint32_t bin = (uint32_t)((xp + 200) + ORT_IMAGE_N * (yp + 200));   // imageMod.f90:55-56
-        const uint32_t part = bin % (uint32_t)kBinTiles, idx = bin / (uint32_t)kBinTiles;
-#pragma unroll
-        for (int t = 0; t < kBinTiles; ++t) {
-            const bool mine = hit && part == (uint32_t)t;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
-            if (mine) a.hit_log[(size_t)t * a.hit_stride + a.hit_base + lo + hits[t] + (unsigned)lane_prefix(m)] = (uint16_t)idx;
-            hits[t] += (unsigned)__popcll(m);
-        }
-    };
-
-    uint64_t next = lo;
-    int img_hint = -1;           // image source: the cell of the previous batch's first ray (emit_image)
-    int qcount = 0, qhead = 0;
-    int ccount = 0, chead = 0;
-    const uint64_t z0 = zray_of(a.rng_base, a.first_ray);      // ProgDraws::init_index (a launch holds < 2^32 rays)
-    // segment 0: zray of ray next + lane = znext (wave-uniform) + zlane
-    uint64_t znext = z0 + (kGolden << 23) * next;
-    const uint64_t zlane = (kGolden << 23) * (uint64_t)lane;
-    unsigned int culled_wave = 0;     // rays segment 0 culled (wave-uniform): each is lost after one intersection
-    for (;;) {
-        const bool have_new = next < hi;
-        const bool cand_ready = PRE && (ccount >= 64 || (!have_new && ccount > 0));
-        if (qcount >= 64 || (!have_new && !cand_ready && qcount > 0)) {
-            // ---- segment 2 on up to 64 queued rays
-            const int m = qcount < 64 ? qcount : 64;
-            const bool act = lane < m;
-            const int slot = (qhead + lane) & (kQueueCap - 1);
-            qhead = (qhead + m) & (kQueueCap - 1);
-            qcount -= m;
-            // (every lane loads: the slots of the lanes beyond m hold rays of earlier passes — or, in a wave's first
-            // partial pass, whatever the LDS held — whose arithmetic is discarded: st >= 0 keeps them out of every
-            // decision, side effect and deferral)
-            RayT<T> r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}};
-            DrawsT d;
-            QD dw = 0;                                   // the queued image of the draw state
-            int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
-            {
-                r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
-                r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
-                dw = qd[slot];
-                nis = CARRY ? qn[slot] : split;
-            }
-            if constexpr (sdraws) d.init_index(z0, dw, 0);
-            else d.unpack(dw, a.rng_base);
-            bool rare = false;
-            if constexpr (fixed) {
-                // the queue point lies INSIDE step split - 1, behind its aperture test (step_part)
-                step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 2, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-                walk_fixed<FILT, T, false, PROG, queue_step<PROG, MODE>(), Prog<PROG>::n, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-            } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, split, ns, r, d, nis, st, xp, yp, rare);
-            if (act) {
-                if (DEFER && rare) defer(sdraws ? (uint64_t)dw : d.ray_of_packed(dw, a.rng_base) - a.first_ray);
-                else finish(st, nis, xp, yp);
-            }
-            if constexpr (LOG) { if (logging) log_hits(act, st, xp, yp); }      // (fp32 defers nothing)
-            __builtin_amdgcn_wave_barrier();
-        } else if (cand_ready || (!PRE && have_new)) {
-            // ---- segment 1 on 64 fresh rays (ring programs: on up to 64 rays that passed segment 0)
-            uint64_t i;
-            bool act;
-            if constexpr (PRE) {
-                const int m = ccount < 64 ? ccount : 64;
-                act = lane < m;
-                i = act ? (uint64_t)cq[(chead + lane) & (kQueueCap - 1)] : lo;
-                chead = (chead + m) & (kQueueCap - 1);
-                ccount -= m;
-            } else {
-                i = next + (uint64_t)lane;
-                act = i < hi;
-                next += 64;
-            }
-            const uint64_t ic = act ? i : (PRE ? lo : hi - 1);   // idle lanes recompute a ray of this wave, unused
-            RayT<T> r;
-            DrawsT d;
-            int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
-            bool rare = false;
-            uint64_t ridx = i;                           // the ray's index in the launch (what a deferral lists)
-            if constexpr (MODE == MODE_CONTINUE) {
-                const uint64_t c0 = a.cont_draw[ic];
-                act = act && c0 != kNoRay;
-                st = act ? -1 : ORT_ST_NA_REJECT;
-                d.unpack(c0, a.rng_base);
-                ridx = (c0 >> 24) - a.first_ray;
-                nis = a.cont_nis[ic];
-                r.pos = {T(a.cont_pos_dir[0 * ns_in + ic]), T(a.cont_pos_dir[1 * ns_in + ic]), T(a.cont_pos_dir[2 * ns_in + ic])};
-                r.dir = {T(a.cont_pos_dir[3 * ns_in + ic]), T(a.cont_pos_dir[4 * ns_in + ic]), T(a.cont_pos_dir[5 * ns_in + ic])};
-                // the rest of the step of surface k0 - 1, where the ray arrived after its walk (lens.f90:283-297, :334-348):
-                // back test, move, normal, Fresnel — surface_step's tail for a wall of the bottle (no aperture stop)
-                typename SysTypes<T>::Surf sw;
-                SurfAuxT<T> axw;
-                if constexpr (fixed) { sw = load_surface<T>(csurf + (k0 - 1)); axw = load_aux<T>(caux + (k0 - 1)); }
-                else { sw = surf[k0 - 1]; axw = AUX[k0 - 1]; }
-                const unsigned wflags = (unsigned)__builtin_amdgcn_readfirstlane((int)sw.flags);
-                const int wlost = (wflags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE;
-                const bool back = act && (wflags & ORT_F_SCATTER) != 0 && r.dir.z < T(0.);
-                const bool on = act && !back;
-                r.pos = vadd(r.pos, vscale(r.dir, T(a.cont_t[ic])));
-                const VecT<T> Nraw = {T(0.0), sw.cy - r.pos.y, sw.cz - r.pos.z};
-                // (a ray that left its walk by the reference's `out` test is not on the wall: no estimate of |N| holds)
-                const VecT<T> Nw = vnormalise_f<FILT, T>(Nraw, on, rare, true);
-                const T uw = d.template peek_as<T>();
-                d.advance(on);
-                const bool refl = reflect_refract<FILT, false, T>(r.dir, Nw, sw.n1, sw.n2, sw.eta, axw.eta2, uw, on, rare);
-                const bool diesw = on && refl && (wflags & ORT_F_SKIP_ON_REFLECT) != 0;
-                st = (back || diesw) ? wlost : st;
-            } else if (MODE == MODE_RESIDENT) {
-                if constexpr (sdraws) d.init_index(z0, (uint32_t)ic, a.draw_base);
-                else d.init_keyed(a.rng_base, a.first_ray + ic, a.draw_base);
-                r.pos = {T(a.pos_dir_in[0 * ns_in + ic]), T(a.pos_dir_in[1 * ns_in + ic]), T(a.pos_dir_in[2 * ns_in + ic])};
-                r.dir = {T(a.pos_dir_in[3 * ns_in + ic]), T(a.pos_dir_in[4 * ns_in + ic]), T(a.pos_dir_in[5 * ns_in + ic])};
-            } else {
-                if constexpr (sdraws) d.init_index(z0, (uint32_t)ic, 0);
-                else d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-                int est;
-                if constexpr (fixed) est = emit<T, false, FILT, Prog<PROG>::emitter>(*csys, phase, r, d, a.first_ray + ic, a.img_cdf, rare, &img_hint);
-                else est = emit<T, ANYSRC, FILT && !ANYSRC>(S, phase, r, d, a.first_ray + ic, a.img_cdf, rare, nullptr, a.strict != 0);
-                st = est < 0 ? st : est;
-            }
-            if constexpr (fixed && MODE == MODE_CONTINUE) {
-                // the list behind the bottle wall the rays were handed over at: its second wall first if only the contents scatter
-                if (k0 == 1) walk_fixed<FILT, T, false, PROG, 1, 2, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-                walk_fixed<FILT, T, false, PROG, 2, queue_step<PROG, MODE>() - 1, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-                step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 1, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-            } else if constexpr (fixed) {
-                walk_fixed<FILT, T, false, PROG, 0, queue_step<PROG, MODE>() - 1, false, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-                step_part<FILT, T, PROG, queue_step<PROG, MODE>() - 1, 1, OPT>(*csys, csurf, caux, r, d, nis, st, xp, yp, rare);
-            } else walk_pass<FILT, T, SCAT, false>(S, surf, AUX, k0, split, r, d, nis, st, xp, yp, rare);
-            const bool deferred = DEFER && rare && act;
-            const bool survive = act && st < 0 && !deferred;
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(survive);
-            if (survive) {
-                const int slot = (qhead + qcount + lane_prefix(mask)) & (kQueueCap - 1);
-                q[0][slot] = (QT)r.pos.x; q[1][slot] = (QT)r.pos.y; q[2][slot] = (QT)r.pos.z;
-                q[3][slot] = (QT)r.dir.x; q[4][slot] = (QT)r.dir.y; q[5][slot] = (QT)r.dir.z;
-                if constexpr (sdraws) qd[slot] = (uint32_t)i;
-                else qd[slot] = d.pack();
-                if (CARRY) qn[slot] = nis;
-            } else if (deferred) {
-                defer(ridx);
-            } else if (act) {
-                finish(st, nis, xp, yp);
-            }
-            // (a surface program's segment 1 ends in front of its image plane: no ray is binned here)
-            if constexpr (LOG && !fixed) { if (logging) log_hits(act && !survive, st, xp, yp); }
-            qcount += __popcll(mask);
-            __builtin_amdgcn_wave_barrier();
-        } else if (PRE && have_new) {
-            // ---- segment 0 (ring programs) on 64 fresh ray indices.  `ring` aims every ray at a point of
-            // the plane z = L2%fb with squared radius rr = ranu(0., (radius + 10e-3)**2), its third draw
-            // (src/sourceMod.f90:283-286), and that plane IS the plano-convex lens's flat face
-            // (centre%z + curve_radius - thickness = fb, src/lens.f90:163, :448): the ray crosses the
-            // face at its aim point up to rounding (host: ring_cull_threshold bounds it by 1e-8 of rr),
-            // so rr > radius^2 (1 + 1e-6) means r > this%radius at lens.f90:451 whatever the other
-            // three draws are: the ray ends there after ONE surface solve.  69 % of the ring rays; they
-            // are counted (lost, one intersection) and never emitted.  Results are unchanged
-            // (tests: with culling == without it, bit for bit, on every system of the parity suite).
-            // The pass is ~30 vector instructions for 64 rays: the ray's hash input is a wave-uniform 64-bit sum (scalar
-            // unit) plus a per-lane constant; the test rr > cull, rr = 0 + u3 (ring_lens_r2 - 0) as emit_ring forms it, is
-            // monotone in the draw's 32-bit word and is taken on the word (cull_word: the largest word that survives, found
-            // by the host with the kernel's own arithmetic); the culled rays are counted per wave, not per lane.
-            if constexpr (PRE) {
-                const uint32_t left = (uint32_t)(hi - next);                  // >= 1, and a launch holds < 2^32 rays
-                const bool act = (uint32_t)lane < left;
-                const uint64_t h = mix64((znext + zlane) + kGolden * 2ull);   // pair 1 of ray next + lane: its draws 2 and 3
-                const uint32_t w = (uint32_t)(h >> 32);                       // draw 2, the third (ProgDraws::at<T, 2>)
-                bool dies;
-                if constexpr (std::is_same<T, float>::value) dies = w > a.cull_wordf;
-                else dies = w > a.cull_word;
-                const bool cand = act && !dies;
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
-                if (cand) cq[(chead + ccount + lane_prefix(mask)) & (kQueueCap - 1)] = (uint32_t)next + (uint32_t)lane;
-                const int passed = __popcll(mask);
-                culled_wave += (unsigned)((left < 64u ? (int)left : 64) - passed);
-                ccount += passed;
-                znext += (kGolden << 23) * 64ull;
-            }
-            next += 64;
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            break;
-        }
-    }
-    if (logging && lane == 0) {
-        uint32_t *e = a.hit_dir + ((size_t)blockIdx.x * kWavesPerBlock + wave) * kBinDirWords;
-#pragma unroll
-        for (int t = 0; t < kBinTiles; ++t) e[t] = hits[t];
-        e[kBinTiles] = a.hit_base + (uint32_t)lo;
-    }
-    if (PRE && lane == 0) { lost += culled_wave; isect += culled_wave; culled = culled_wave; }   // src/optics_system.f90:42 (lost), one intersection each
-    atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect);
-    atomicAdd(&blk[2], binned); atomicAdd(&blk[3], help3);
-    if constexpr (PRE) atomicAdd(&blk[4], culled);
-    __syncthreads();
-    if (threadIdx.x < 4 && blk[threadIdx.x])
-        atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
-    if (PRE && threadIdx.x == 4 && blk[4]) atomicAdd(&a.work[ORT_W_CULLED], (unsigned long long)blk[4]);
-}
-
-
-// ---------------------------------------------------------------------------
-// In-bottle scattering (src/lens.f90:262-282, :312-333, src/surfaces.f90:13-50,
-// src/stokes.f90:7-166) as its own kernel in front of the lean walk.
-//
-// The random walk is a loop of unknown length per ray around ~800 instructions of log / atan2 / acos /
-// sin / cos; compiled INTO the surface walk it costs every lane of every step 200+ VGPRs (2 waves per SIMD)
-// and runs in lockstep until the last of 64 rays has left its walk (lanes busy: ~20 %).  Here the surfaces up to
-// the last scattering one (the bottle's two walls) are cut into three stages, each run on FULL wavefronts fed
-// from wave-private LDS queues — the scheme of trace_queue_kernel with a cycle in it:
-//   E  64 fresh rays: emit, ENTER surface 0
-//   W  64 walking rays: one scattering event (move, absorb?, stokes, next leg by tauint); a ray that goes on
-//      walking returns to the walk queue, one that reaches the wall (or leaves the cylinder) goes to the arrival queue
-//   A  64 arrived rays: the rest of the surface step (back test, move, normal, Fresnel), then ENTER the next
-//      surface, or — behind the last scattering surface — hand the ray over
-//   ENTER surface k: intersect; if the medium in front of it scatters, the first leg (tauint)
-// Rays that survive are appended to the hand-over bundle in HBM (state, keyed draw counter, intersections so far)
-// and trace_queue_kernel<MODE_CONTINUE> walks the remaining surfaces at its own register budget.  Every
-// operation of a ray is the one the monolithic kernel (and the lockstep kernel) performs, in the same order with
-// the same draws.  The quadratics of the walls and of every leg, and the normal + Fresnel step at an inner wall, are
-// evaluated in their filtered forms (ort_device.h: the same bits, or the ray is listed for the literal re-run); the walk
-// itself (stokes, log) is literal — so rays, images and counters are bit-identical to theirs (tests: the pipeline against
-// the lockstep kernel; both against the CPU checker).
-// The transcendental functions of the walk are glibc's own algorithms (ort_libm.h: the reference's results bit for
-// bit); their lookup tables (sin/cos, atan2, acos: 38 KB) are staged ONCE per workgroup into LDS — gathered from
-// constant memory they cost the vector cache ~50 cycles per wavefront-wide load and bound the walk (tools/ubench_libm.hip).
-// One workgroup of kScatWaves = 12 wavefronts per CU (151 KB of LDS: tables + 12 pools of 9 KB + the staged system; the
-// kernel's 168 VGPRs allow 3 waves per SIMD), every wave an independent worker: no barrier after the staging.
-// Work distribution: PERSISTENT waves pull batches of rays from eight heads, one per XCD (HW_REG_XCC_ID; head x hands
-// out an eighth of the launch's ray range, scat_grab rays per returning atomic), and steal from the next head when
-// theirs is dry; a wave ends when all eight are.  With static ranges the 12 waves of a CU ended at 0.51 / 0.81 / 1.13 M
-// cycles (a SIMD serves its oldest wave first) and the last third of every launch ran at one wave per SIMD
-// (profiles/r03/scatbench.log).  Keyed draws make the result independent of which wave traces which ray.
-// Hand-over slots are allocated kHandChunk at a time from one counter (scat_ctl[kScatSlotsWord]); a wave fills its
-// chunk from the bottom and marks what is left empty when it ends, so every allocated slot is written and the
-// continuation walks exactly the allocated count.
-// ---------------------------------------------------------------------------
-constexpr int kSQCap = 128;        // at most 128 rays in flight per wave: stage E runs only while <= 64 are (a power of two)
-// ONE pool of ray slots per wave and three rings of slot numbers over it — walking, arrived, free: a ray keeps its
-// slot from stage to stage, only its number moves between the rings
-struct ScatPool {
-    double f[7][kSQCap];           // px py pz dx dy dz t (length of the next leg)
-    uint64_t c[kSQCap];            // keyed draw counter
-    uint32_t m[kSQCap];            // intersections so far << 8 | surface index
-    uint8_t ring[3][kSQCap];       // slot numbers: RING_WALK, RING_ARRIVED, RING_FREE
-};
-constexpr int RING_WALK = 0, RING_ARRIVED = 1, RING_FREE = 2;
-static_assert(sizeof(ScatPool) * kScatWaves + glibc::kLdsTableWords * 8 + sizeof(ort_system) + 256 <= 160 * 1024, "scatter_front_kernel: LDS of one CU");
-
-// ENTER surface k (per lane) for the lanes `on`: src/lens.f90:255-261 / :303-311 up to the first tauint.
-// Circular walls: the two quadratics in their filtered forms (ort_device.h: the same bits, or the lane raises `rare`);
-// a lane that did is left exactly as it came (`ended` untouched, neither walking nor arrived): the caller defers it.
-__device__ inline void scat_enter(const ort_surface *surf, int k, int kind0, bool on, const Ray &r, KeyedDraws &d,
-                                  int &nis, double &t, bool &walking, bool &arrived, int &ended, bool &rare)
-{
-    const ort_surface &s = surf[k];
-    const int ended0 = ended;
-    nis += on ? 1 : 0;
-    double tt;
-    bool hit, unused = false;
-    if (kind0 == ORT_SURF_ELLIPSE) intersect_ellipse<false, double>(r, s.cy, s.cz, s.radius, s.radius_b, 0., 0., on, tt, hit, unused);
-    else intersect_quadric<true, double>(r, s.cx, s.cy, s.cz, s.radius, s.radius * s.radius, true, on, tt, hit, rare);
-    const unsigned flags = s.flags;
-    const int lost = (flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE;
-    ended = (on && !hit) ? ((flags & ORT_F_MISS_IS_HELP3) ? ORT_ST_HELP3 : lost) : ended;
-    const bool go = on && hit;
-    const bool scat = (flags & ORT_F_SCATTER) != 0;
-    double dist;
-    bool at_wall, ok;
-    tauint<double, KeyedDraws, true>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, go && scat, d, dist, at_wall, ok, nis, &rare);
-    ended = (go && scat && !ok) ? ORT_ST_NO_INTERSECTION : ended;
-    t = go ? (scat ? dist : tt) : t;
-    const bool alive = go && (!scat || ok);
-    const bool bad = on && rare;
-    walking = alive && scat && !at_wall && !bad;
-    arrived = alive && !(alive && scat && !at_wall) && !bad;
-    ended = bad ? ended0 : ended;
-    rare = bad;
-}
-
-#ifdef ORT_SCAT_TIMING
-__device__ unsigned long long g_scat_times[4 * 16384];     // dev builds: start, last emission, end, passes per wave
-#endif
-__device__ inline uint64_t uniform64(uint64_t v)
-{
-    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-// ANYSRC = false: the point source only (the default of the loop the bottle belongs to, src/main.f90:136)
-template <bool ANYSRC>
-__global__ __launch_bounds__(64 * kScatWaves) void scatter_front_kernel(TraceArgs a)
-{
-    __shared__ ort_system S;
-    __shared__ ScatPool POOLS[kScatWaves];
-    __shared__ uint64_t LT[glibc::kLdsTableWords];       // glibc's sin/cos, atan2 and acos tables (ort_libm.h: TabLds)
-    __shared__ double ALB[ORT_MAX_SURFACES];
-    __shared__ unsigned int blk[4];
-    stage_system(S, a.sys);
-    glibc::stage_tables(LT, (int)threadIdx.x, (int)blockDim.x);
-    if (threadIdx.x < 4) blk[threadIdx.x] = 0;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    ScatPool &P = POOLS[wave];
-    for (int j = lane; j < kSQCap; j += 64) P.ring[RING_FREE][j] = (uint8_t)j;      // every slot starts free
-    const int ph = a.phase - 1;
-    const ort_surface *surf = S.surfaces[ph];
-    // albedo of every surface's medium (lens.f90:266, :317), the division done once per workgroup instead of once per event
-    if (threadIdx.x < ORT_MAX_SURFACES) ALB[threadIdx.x] = surf[threadIdx.x].mus / (surf[threadIdx.x].mus + surf[threadIdx.x].mua);
-    __syncthreads();
-    const glibc::TabLds tabs = {(const __attribute__((address_space(3))) uint64_t *)LT};
-    const int kind0 = __builtin_amdgcn_readfirstlane(surf[0].kind);      // host: the same for every surface in front of cont_k0
-    const int klast = a.cont_k0 - 1;
-
-    unsigned int lost = 0, isect = 0, help3 = 0;
-    auto end_ray = [&](int st, int nis) {                 // a ray that ends inside the bottle (nothing is binned here)
-        isect += (unsigned)nis;
-        lost++;                                           // every status a ray can end with here counts as lost
-        if (st == ORT_ST_HELP3) help3++;
-    };
-    // rings: wcount + acount + fcount + (slots held by the lanes of the running stage) = kSQCap
-    int wcount = 0, whead = 0, acount = 0, ahead = 0, fcount = kSQCap, fhead = 0;
-    auto give = [&](int which, int &count, int head, bool cond, int slot) {        // append the slot numbers of the lanes `cond`
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(cond);
-        if (cond) P.ring[which][(head + count + lane_prefix(mask)) & (kSQCap - 1)] = (uint8_t)slot;
-        count += __popcll(mask);
-    };
-    auto take = [&](int which, int &count, int &head, bool &act, int &slot) {      // the first (up to) 64 slot numbers
-        const int m = count < 64 ? count : 64;
-        act = lane < m;
-        slot = act ? (int)P.ring[which][(head + lane) & (kSQCap - 1)] : 0;
-        head = (head + m) & (kSQCap - 1);
-        count -= m;
-    };
-    auto store = [&](bool cond, int slot, const Ray &r, double t, const KeyedDraws &d, int nis, int k) {
-        if (cond) {
-            P.f[0][slot] = r.pos.x; P.f[1][slot] = r.pos.y; P.f[2][slot] = r.pos.z;
-            P.f[3][slot] = r.dir.x; P.f[4][slot] = r.dir.y; P.f[5][slot] = r.dir.z;
-            P.f[6][slot] = t;
-            P.c[slot] = d.c;
-            P.m[slot] = ((uint32_t)nis << 8) | (uint32_t)k;
-        }
-    };
-    auto load = [&](bool act, int slot, Ray &r, double &t, KeyedDraws &d, int &nis, int &k) {
-        r = {{0., 0., 0.}, {0., 0., 1.}};
-        t = 0.; nis = 0; k = 0;
-        d.base = a.rng_base; d.c = 0;
-        if (act) {
-            r.pos = {P.f[0][slot], P.f[1][slot], P.f[2][slot]};
-            r.dir = {P.f[3][slot], P.f[4][slot], P.f[5][slot]};
-            t = P.f[6][slot];
-            d.c = P.c[slot];
-            const uint32_t mm = P.m[slot];
-            nis = (int)(mm >> 8); k = (int)(mm & 0xffu);
-        }
-    };
-    // where the rays of a stage go: back to the walk ring, to the arrival ring (state stored in their own slot), or out
-    // of the pool (ended / handed over: the slot is free again)
-    auto route = [&](bool held, int slot, bool to_walk, bool to_arrived, const Ray &r, double t, const KeyedDraws &d, int nis, int k) {
-        store(to_walk || to_arrived, slot, r, t, d, nis, k);
-        give(RING_WALK, wcount, whead, to_walk, slot);
-        give(RING_ARRIVED, acount, ahead, to_arrived, slot);
-        give(RING_FREE, fcount, fhead, held && !to_walk && !to_arrived, slot);
-    };
-    // behind the last scattering surface: the next free slots of this wave's current chunk of the hand-over bundle; a
-    // full chunk is followed by a new one from the launch-wide counter (one returning atomic per kHandChunk rays)
-    uint64_t hbase = 0;
-    unsigned hused = kHandChunk;                          // no chunk yet
-    auto new_chunk = [&]() {
-        unsigned long long v = 0;
-        if (lane == 0) v = atomicAdd(&a.scat_ctl[kScatSlotsWord], (unsigned long long)kHandChunk);
-        return uniform64(v);
-    };
-    auto hand_over = [&](bool cond, const Ray &r, double t, const KeyedDraws &d, int nis) {
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(cond);
-        const unsigned cnt = (unsigned)__popcll(mask);
-        if (cnt == 0) return;                             // (wave-uniform)
-        uint64_t hnext = hbase;
-        if (hused + cnt > kHandChunk) hnext = new_chunk();        // the batch spills into a new chunk
-        if (cond) {
-            const unsigned pos = hused + (unsigned)lane_prefix(mask);
-            const uint64_t j = pos < kHandChunk ? hbase + pos : hnext + (pos - kHandChunk), cap = a.cont_cap;
-            if (j < cap) {                                // (always: the host sizes the bundle for every chunk a launch can take)
-                a.cont_pos_dir[0 * cap + j] = r.pos.x; a.cont_pos_dir[1 * cap + j] = r.pos.y; a.cont_pos_dir[2 * cap + j] = r.pos.z;
-                a.cont_pos_dir[3 * cap + j] = r.dir.x; a.cont_pos_dir[4 * cap + j] = r.dir.y; a.cont_pos_dir[5 * cap + j] = r.dir.z;
-                a.cont_t[j] = t;
-                a.cont_draw[j] = d.c;
-                a.cont_nis[j] = nis;
-            }
-        }
-        hused += cnt;
-        if (hused > kHandChunk) { hbase = hnext; hused -= kHandChunk; }
-    };
-
-#ifdef ORT_SCAT_TIMING
-    const unsigned long long t_start = __builtin_readcyclecounter();
-    unsigned long long t_emit = t_start, n_pass = 0;
-#endif
-    // a ray that raised `rare` leaves the pipeline without a trace (it has not ended, nothing of it was counted) and is
-    // listed for the literal re-run from its emission, like the deferred rays of trace_queue_kernel
-    auto defer = [&](bool cond, const KeyedDraws &d) {
-        if (cond) a.redo_list[atomicAdd(&a.redo_ctl[0], 1u)] = (uint32_t)(a.defer_base + ((d.c >> 24) - a.first_ray));
-    };
-    // the rays this wave has pulled and not yet emitted, the head it pulls from, and whether all eight heads are dry
-    uint64_t bnext = 0, bhi = 0;
-    int hx = xcc_id() & (kScatHeads - 1), tried = 0;
-    bool dry = false;
-    for (;;) {
-        while (bnext >= bhi && !dry) {                    // (wave-uniform) pull: at most eight failures in a wave's life
-            const uint64_t base = (uint64_t)hx * a.scat_share;
-            uint64_t end = base + a.scat_share;  if (end > a.n_rays) end = a.n_rays;
-            unsigned long long v = 0;
-            if (lane == 0 && base < end) v = atomicAdd(&a.scat_ctl[hx * kScatCtlStride], (unsigned long long)a.scat_grab);
-            const uint64_t got = base + uniform64(v);
-            if (base < end && got < end) {
-                bnext = got;
-                bhi = got + a.scat_grab < end ? got + a.scat_grab : end;
-                tried = 0;
-            } else {
-                hx = (hx + 1) & (kScatHeads - 1);
-                dry = ++tried >= kScatHeads;
-            }
-        }
-        const bool have_new = bnext < bhi;
-#ifdef ORT_SCAT_TIMING
-        n_pass++;
-        if (have_new) t_emit = __builtin_readcyclecounter();
-#endif
-        // a full wavefront of walking rays first, then of arrived ones; fresh rays while at most 64 are in flight (the
-        // pool holds 128); otherwise the fuller ring runs on a partial wavefront
-        const bool may_emit = have_new && wcount + acount <= 64;
-        if (wcount >= 64 || (wcount > 0 && acount < 64 && !may_emit && wcount >= acount)) {
-            // ---- W: one scattering event (src/lens.f90:264-281 / :315-332) for up to 64 walking rays
-            bool act;
-            Ray r;
-            double t;
-            KeyedDraws d;
-            int nis, k;
-            int slot;
-            take(RING_WALK, wcount, whead, act, slot);
-            load(act, slot, r, t, d, nis, k);
-#ifdef ORT_ISA_MARKERS
-            asm volatile("; ORT_STAGE_BEGIN W");
-#endif
-            const ort_surface &s = surf[k];
-            int ended = -1;
-            bool walking = act;
-            r.pos = vselect(walking, vadd(r.pos, vscale(r.dir, t)), r.pos);
-            const double albedo = ALB[k];
-            const double u = d.peek();
-            d.advance(walking);
-            const bool absorbed = walking && !(u < albedo);
-            ended = absorbed ? ORT_ST_LOST_BOTTLE : ended;
-            walking = walking && !absorbed;
-            stokes_hg<double>(r.dir, s.hgg, S.twopi, walking, d, tabs);
-            double dist;
-            bool at_wall, ok, rare = false;
-            tauint<double, KeyedDraws, true>(r, s.mua, s.mus, s.cy, s.cz, s.scat_radius, walking, d, dist, at_wall, ok, nis, &rare);
-            const bool bad = walking && rare;
-            walking = walking && !rare;
-            const bool lostw = walking && !ok;
-            ended = lostw ? ORT_ST_NO_INTERSECTION : ended;
-            t = (walking && ok) ? dist : t;
-            const bool out = sqrt(r.pos.x * r.pos.x + r.pos.z * r.pos.z) >= s.scat_radius;        // sic: x, z
-            const bool still = walking && ok && !out && !at_wall;
-            const bool arrived = walking && ok && !still;
-#ifdef ORT_ISA_MARKERS
-            asm volatile("; ORT_STAGE_END W");
-#endif
-            defer(bad, d);
-            route(act, slot, still, arrived && k < klast, r, t, d, nis, k);
-            hand_over(arrived && k >= klast, r, t, d, nis);
-            if (act && ended >= 0) end_ray(ended, nis);
-            __builtin_amdgcn_wave_barrier();
-        } else if (acount >= 64 || (acount > 0 && !may_emit)) {
-            // ---- A: the rest of the surface step for up to 64 rays that reached the wall, then the next surface
-            bool act;
-            Ray r;
-            double t;
-            KeyedDraws d;
-            int nis, k;
-            int slot;
-            take(RING_ARRIVED, acount, ahead, act, slot);
-            load(act, slot, r, t, d, nis, k);
-            const ort_surface &s = surf[k];
-            const unsigned flags = s.flags;
-            int ended = -1;
-            const bool back = act && (flags & ORT_F_SCATTER) != 0 && r.dir.z < 0.;       // lens.f90:283, :334
-            ended = back ? ORT_ST_LOST_BOTTLE : ended;
-            const bool live = act && !back;
-            r.pos = vselect(live, vadd(r.pos, vscale(r.dir, t)), r.pos);
-            const Vec Nraw = {0.0, s.cy - r.pos.y, s.cz - r.pos.z};                      // lens.f90:288-290
-            // normal and Fresnel step in their filtered forms (a ray that left its walk by the `out` test is not on the wall:
-            // no estimate of |N| holds, hence vnormalise_f)
-            bool rare = false;
-            const Vec N = vnormalise_f<true, double>(Nraw, live, rare, true);
-            const double u = d.peek();
-            d.advance(live);
-            const bool reflected = reflect_refract<true, true, double>(r.dir, N, s.n1, s.n2, s.eta, s.eta * s.eta, u, live, rare);
-            const bool bad1 = live && rare;
-            const bool dies = live && !rare && reflected && (flags & ORT_F_SKIP_ON_REFLECT) != 0;
-            ended = dies ? ((flags & ORT_F_BOTTLE) ? ORT_ST_LOST_BOTTLE : ORT_ST_LOST_TELESCOPE) : ended;
-            const bool enter = live && !rare && !dies;  // (rays arriving at the LAST wall never come here: handed over)
-            bool walking = false, arrived = false, rare2 = false;
-            const int k1 = enter ? k + 1 : k;
-            scat_enter(surf, k1, kind0, enter, r, d, nis, t, walking, arrived, ended, rare2);
-            defer(bad1 || rare2, d);
-            route(act, slot, walking, arrived && k1 < klast, r, t, d, nis, k1);
-            hand_over(arrived && k1 >= klast, r, t, d, nis);
-            if (act && ended >= 0) end_ray(ended, nis);
-            __builtin_amdgcn_wave_barrier();
-        } else if (may_emit) {
-            // ---- E: 64 fresh rays
-            const uint64_t i = bnext + (uint64_t)lane;
-            const bool act = i < bhi;
-            bnext += 64;
-            const uint64_t ic = act ? i : bhi - 1;
-            Ray r;
-            KeyedDraws d;
-            d.init_keyed(a.rng_base, a.first_ray + ic, 0);
-            int ended = emit<double, ANYSRC>(S, a.phase, r, d, a.first_ray + ic, a.img_cdf, a.strict != 0);
-            int nis = 0;
-            double t = 0.;
-            bool walking, arrived, rare = false;
-            scat_enter(surf, 0, kind0, act && ended < 0, r, d, nis, t, walking, arrived, ended, rare);
-            defer(rare, d);
-            bool held;
-            int slot;
-            take(RING_FREE, fcount, fhead, held, slot);      // 64 of them: at most 64 rays are in flight (may_emit)
-            route(held, slot, walking, arrived && klast > 0, r, t, d, nis, 0);
-            hand_over(arrived && klast <= 0, r, t, d, nis);
-            if (act && ended >= 0) end_ray(ended, nis);
-            __builtin_amdgcn_wave_barrier();
-        } else {
-            break;                                           // nothing in flight, every head dry
-        }
-    }
-#ifdef ORT_SCAT_TIMING
-    {
-        const unsigned wid = blockIdx.x * kScatWaves + wave;
-        if (lane == 0 && wid < 16384) {
-            g_scat_times[4 * wid + 0] = t_start; g_scat_times[4 * wid + 1] = t_emit;
-            g_scat_times[4 * wid + 2] = __builtin_readcyclecounter(); g_scat_times[4 * wid + 3] = n_pass;
-        }
-    }
-#endif
-    if (hused < kHandChunk)                                  // what is left of the wave's last chunk holds no ray
-        for (uint64_t j = hbase + hused + (uint64_t)lane; j < hbase + kHandChunk && j < a.cont_cap; j += 64) a.cont_draw[j] = kNoRay;
-    atomicAdd(&blk[0], lost); atomicAdd(&blk[1], isect); atomicAdd(&blk[3], help3);
-    __syncthreads();
-    if (threadIdx.x < 4 && blk[threadIdx.x])
-        atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
-}
-
 __global__ __launch_bounds__(kBlock) void emit_kernel(const ort_system *sys, int phase,
                                                       uint64_t first_ray, uint64_t n, uint64_t rng_base,
                                                       double *pos_dir, const long long *img_cdf, int strict, int wide)
@@ -1551,7 +176,7 @@ int grid_for(uint64_t n)
 {
     static int max_blocks = 0;
     if (!max_blocks) {
-        const char *e = getenv("ORT_MAX_BLOCKS");        // development knob
+        const char *e = getenv("ORT_DEV_MAX_BLOCKS");        // development knob
         max_blocks = (e && atoi(e) > 0) ? atoi(e) : kMaxBlocks;
     }
     uint64_t b = (n + kBlock - 1) / kBlock;
@@ -1568,11 +193,11 @@ int env_int(const char *name, int dflt)
 
 // Rays per launch of the queued kernels: ORT_MAX_RAYS_PER_LAUNCH = 2^27 — every launch pays ~25 us of ramp and drain, and
 // launches of 2^25 rays cost the ring loop 8 % and the 1e9-ray layers 4 % against these (profiles/r04: ring1e8 1.90e11 ->
-// 2.07e11).  ORT_CHUNK_LOG2 (development knob, read once) makes them smaller: the tests cut small traces into several launches.
+// 2.07e11).  ORT_DEV_CHUNK_LOG2 (development knob, read once) makes them smaller: the tests cut small traces into several launches.
 uint64_t chunk_rays()
 {
     static const uint64_t chunk = [] {
-        const int lg = env_int("ORT_CHUNK_LOG2", 27);
+        const int lg = env_int("ORT_DEV_CHUNK_LOG2", 27);
         const uint64_t c = 1ull << (lg < 6 ? 6 : (lg > 27 ? 27 : lg));
         return c < kChunkRaysMax ? c : kChunkRaysMax;
     }();
@@ -1594,8 +219,8 @@ uint64_t chunk_rays()
 constexpr int kHeadBlocks = 1280, kHeadPercent = 86, kTailBatches = 6;
 int plan_ranges(TraceArgs &a)
 {
-    static const int head_blocks = env_int("ORT_HEAD_BLOCKS", kHeadBlocks), head_pct = env_int("ORT_HEAD_PERCENT", kHeadPercent),
-                     tail_batches = env_int("ORT_TAIL_BATCHES", kTailBatches);
+    static const int head_blocks = env_int("ORT_DEV_HEAD_BLOCKS", kHeadBlocks), head_pct = env_int("ORT_DEV_HEAD_PERCENT", kHeadPercent),
+                     tail_batches = env_int("ORT_DEV_TAIL_BATCHES", kTailBatches);
     const uint64_t n = a.n_rays, per_block = 64ull * kWavesPerBlock;
     if (n < (uint64_t)head_blocks * per_block * 4 || head_pct >= 100) {       // equal ranges
         int grid = grid_for(n);
@@ -1621,7 +246,7 @@ int redo_blocks()
 {
     static int n = 0;
     if (!n) {
-        const char *e = getenv("ORT_REDO_BLOCKS");       // development knob
+        const char *e = getenv("ORT_DEV_REDO_BLOCKS");       // development knob
         n = (e && atoi(e) > 0) ? atoi(e) : kRedoBlocks;
     }
     return n;
@@ -1680,6 +305,7 @@ struct ort_ctx {
     int32_t *d_slabs;
     bool slab_pending[2];
     hipEvent_t launch_ev[2];     // start / stop events the next kernel launch carries itself (null: none)
+    char last_kernel[192];       // the instantiation the last trace launch ran (ort_last_kernel_name)
     // deferral group: consecutive fused launches of one phase / seed / system whose deferred rays share
     // the re-run list; the literal re-run is launched when the group closes (close_group)
     bool group_open;
@@ -1710,6 +336,7 @@ struct ort_ctx {
     double ring_cull;            // squared-radius threshold of the staged system (ring_cull_threshold), +inf: no culling
     float ring_cullf;
     uint32_t ring_cull_word, ring_cull_wordf;      // TraceArgs.cull_word / cull_wordf (cull_word_of)
+    uint64_t ring_cull_wide;                       // TraceArgs.cull_wide (cull_wide_of)
     hipEvent_t ev[3][2];
     hipEvent_t ring[kTimingRing][2];   // fused-trace launches, most recent kTimingRing
     unsigned long long ring_count;
@@ -1768,10 +395,31 @@ template <class T> static uint32_t cull_word_of(T r2, T cull)
     return lo;
 }
 
+// the same border for the 53-bit draws of ORT-RNG-v2w (fp64): the largest x = h >> 11 whose ray is not culled, u = x 2^-53
+// formed as unit53 forms it (two exact halves, an exact sum).  ~0 when nothing is culled.
+static uint64_t cull_wide_of(double r2, double cull)
+{
+    auto dies = [&](uint64_t x) {
+        volatile double u = (double)(uint32_t)(x >> 32) * 0x1p-21 + (double)(uint32_t)x * 0x1p-53;
+        volatile double span = r2 - 0.;
+        volatile double prod = u * span;
+        volatile double rr = 0. + prod;
+        return rr > cull;
+    };
+    const uint64_t top = (1ull << 53) - 1ull;
+    if (!dies(top) || dies(0ull)) return ~0ull;
+    uint64_t lo = 0ull, hi = top;                  // lo survives, hi dies
+    while (hi - lo > 1ull) {
+        const uint64_t mid = lo + (hi - lo) / 2ull;
+        if (dies(mid)) hi = mid; else lo = mid;
+    }
+    return lo;
+}
+
 static void ring_cull_threshold(const ort_system *sys, bool is_ring_program, double *cull, float *cullf)
 {
     *cull = HUGE_VAL; *cullf = HUGE_VALF;
-    if (!is_ring_program || getenv("ORT_NO_RING_CULL")) return;
+    if (!is_ring_program || getenv("ORT_DEV_NO_RING_CULL")) return;
     const ort_surface &s0 = sys->surfaces[0][0];
     if (s0.kind != ORT_SURF_PLANE || !(s0.aperture > 0.0)) return;
     const double zt = sys->ring_lens_z, zp = s0.cz, ra = sys->ring_bottle_ra, rb = sys->ring_bottle_rb;
@@ -1825,16 +473,17 @@ static void note_system(ort_ctx *c, const ort_system *sys)
         c->scat_k0[p] = ok ? last + 1 : 0;
         c->cont_prog[p] = false;
     }
-    c->cont_prog[1] = c->scat_k0[1] > 0 && matches_behind<PROG_POINT_WALKED>(sys, c->scat_k0[1]) && !getenv("ORT_NO_PROGRAMS");
+    c->cont_prog[1] = c->scat_k0[1] > 0 && matches_behind<PROG_POINT_WALKED>(sys, c->scat_k0[1]) && !getenv("ORT_DEV_NO_PROGRAMS");
     c->prog[0] = c->prog[1] = PROG_GENERIC;
 #define ORT_MATCH(P) if (matches<P>(sys)) c->prog[Prog<P>::phase - 1] = P;
     ORT_PROGRAMS(ORT_MATCH)
     ORT_SOURCE_PROGRAMS(ORT_MATCH)
 #undef ORT_MATCH
-    if (getenv("ORT_NO_PROGRAMS")) c->prog[0] = c->prog[1] = PROG_GENERIC;      // development knob (A/B)
+    if (getenv("ORT_DEV_NO_PROGRAMS")) c->prog[0] = c->prog[1] = PROG_GENERIC;      // development knob (A/B)
     ring_cull_threshold(sys, c->prog[0] != PROG_GENERIC && sys->emitter[0] == ORT_EMIT_RING, &c->ring_cull, &c->ring_cullf);
     c->ring_cull_word = cull_word_of<double>(sys->ring_lens_r2, c->ring_cull);
     c->ring_cull_wordf = cull_word_of<float>((float)sys->ring_lens_r2, c->ring_cullf);
+    c->ring_cull_wide = cull_wide_of(sys->ring_lens_r2, c->ring_cull);
 }
 
 // system + derived per-surface constants -> the next device slot, asynchronously (the staging copy is the
@@ -1904,32 +553,6 @@ static int flush_replicas(ort_ctx *c)
         c->slab_pending[p] = false;
     }
     return ORT_OK;
-}
-
-// The lean queued kernel (default emitters, no scattering, filtered predicates): specialised for
-// the surface program the staged system matches, generic otherwise.
-template <class T, bool FILT = true>
-static void launch_lean(ort_ctx *c, int mode, const TraceArgs &a, int grid)
-{
-#define ORT_LAUNCH(K) hipExtLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, c->launch_ev[0], c->launch_ev[1], 0, a)
-    // a program's draw indices are compile-time constants: they assume the emitter's own number of
-    // draws in front of the first surface (resident bundles may come with another draw_base)
-    int prog = c->prog[a.phase - 1];
-    if (mode != MODE_FUSED && a.draw_base != (a.phase == 1 ? 4 : 2)) prog = PROG_GENERIC;
-    if (a.strict) prog = PROG_GENERIC;                   // strict libm emitters live in the generic kernels (variant bit 6)
-#define ORT_CASE(P)                                                                                        \
-    case P:                                                                                                \
-        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, FILT, false, T, P>));           \
-        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, FILT, false, T, P>));                           \
-        break;
-    switch (prog) {
-        ORT_PROGRAMS(ORT_CASE)
-    default:
-        if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, FILT, false, T>));
-        else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, FILT, false, T>));
-    }
-#undef ORT_CASE
-#undef ORT_LAUNCH
 }
 
 extern "C" {
@@ -2087,70 +710,32 @@ int ort_flush(ort_ctx *c)
     return flush_replicas(c);
 }
 
-// One kernel of the trace family on `grid` workgroups.
+// One kernel of the trace family on `grid` workgroups: the most specific family that holds a kernel for the request
+// (ort_launch.h) — a surface program the staged system matches, else the generic walk / the lockstep kernel.
 static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool queued, bool filt, bool anysrc)
 {
     const bool scat = c->scatter[a.phase - 1];
-#define ORT_LAUNCH(K) hipExtLaunchKernelGGL(K, dim3(grid), dim3(kBlock), 0, c->stream, c->launch_ev[0], c->launch_ev[1], 0, a)
-    if (c->precision == 2) {
-        // fast fp64 (ort_fastd.h): FMA contraction, Newton divide / Goldschmidt sqrt; ~1e-13 from exact
-        if (mode == MODE_DEBUG) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, fastd, true>));
-        else if (!queued) {                                   // the literal re-run of deferred rays
-            if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, false, fastd, true>));
-            else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, fastd, true>));
-        } else if (anysrc) {
-            if (mode == MODE_FUSED) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true, fastd>));
-            else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true, fastd>));
-        } else {
-            launch_lean<fastd>(c, mode, a, grid);
-        }
-    } else if (c->precision == 1) {
-        // fp32 path (BASELINE configs[4]): always the filtered forms, never a deferral (ort_device.h kLoose) — in every kernel,
-        // so that they agree bit for bit; queued program kernels for the default emitters in clear media, the lockstep
-        // kernel for everything else
-        if (mode == MODE_DEBUG) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, float, true>));
-        else if (queued && !anysrc) launch_lean<float, true>(c, mode, a, grid);
-        else if (queued && mode == MODE_FUSED && !scat && c->prog[a.phase - 1] > PROG_LIST_MASK) {
-            switch (c->prog[a.phase - 1]) {                   // the other bulk light sources: their own program kernels
-#define ORT_CASE(P) case P: ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, float, P>)); break;
-                ORT_SOURCE_PROGRAMS(ORT_CASE)
-#undef ORT_CASE
-            }
-        }
-        else if (mode == MODE_FUSED) ORT_LAUNCH((trace_kernel<MODE_FUSED, true, float, true>));
-        else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true, float, true>));
-    } else if (mode == MODE_DEBUG) {
-        if (filt) ORT_LAUNCH((trace_kernel<MODE_DEBUG, true, double, true>));
-        else ORT_LAUNCH((trace_kernel<MODE_DEBUG, false, double, true>));
-    } else if (anysrc && filt && queued && mode == MODE_FUSED && !scat && c->prog[a.phase - 1] > PROG_LIST_MASK && !a.strict) {
-        // the other bulk light sources in front of a default surface list: their own program kernels
-        switch (c->prog[a.phase - 1]) {
-#define ORT_CASE(P) case P: ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, false, double, P>)); break;
-            ORT_SOURCE_PROGRAMS(ORT_CASE)
-#undef ORT_CASE
-        }
-    } else if (anysrc || !filt || !queued) {
-        // alternate emitters and the A/B variants share the generic instantiations
-        if (mode == MODE_FUSED) {
-            if (queued) {
-                if (filt && !scat) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true, double, PROG_GENERIC, false>));   // other emitters, clear media
-                else if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, true, true, double>));
-                else ORT_LAUNCH((trace_queue_kernel<MODE_FUSED, false, true, double>));
-            }
-            else { if (filt) ORT_LAUNCH((trace_kernel<MODE_FUSED, true, double, true>)); else ORT_LAUNCH((trace_kernel<MODE_FUSED, false, double, true>)); }
-        } else {
-            if (queued) {
-                if (filt && !scat) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true, double, PROG_GENERIC, false>));
-                else if (filt) ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, true, true, double>));
-                else ORT_LAUNCH((trace_queue_kernel<MODE_RESIDENT, false, true, double>));
-            }
-            else { if (filt) ORT_LAUNCH((trace_kernel<MODE_RESIDENT, true, double, true>)); else ORT_LAUNCH((trace_kernel<MODE_RESIDENT, false, double, true>)); }
-        }
-    } else {
-        // the default emitters (ring / point) without scattering have their own, leaner instantiation
-        launch_lean<double>(c, mode, a, grid);
+    const LaunchCfg cfg = {grid, c->stream, c->launch_ev[0], c->launch_ev[1]};
+    const char *name = nullptr;
+    // a program's draw indices are compile-time constants: they assume the emitter's own number of draws in front of the
+    // first surface (resident bundles may come with another draw_base)
+    int prog = c->prog[a.phase - 1];
+    if (mode != MODE_FUSED && a.draw_base != (a.phase == 1 ? 4 : 2)) prog = PROG_GENERIC;
+    const bool program = prog != PROG_GENERIC && queued && mode != MODE_DEBUG && !scat && (filt || c->precision == 1);
+    if (program) {
+        if (c->precision == 2) name = launch_program_fast(prog, mode, cfg, a);
+        else if (c->precision == 1) name = launch_program_f32(prog, mode, cfg, a);
+        else if (a.wide) name = launch_program_f64_wide(prog, mode, a.strict != 0, cfg, a);
+        else if (a.strict) name = launch_program_f64_strict(prog, mode, cfg, a);
+        else name = launch_program_f64(prog, mode, cfg, a);
     }
-#undef ORT_LAUNCH
+    if (!name) {
+        // fp32: always the filtered forms (ort_device.h kLoose); its queued generic walk exists for the default emitters in
+        // clear media only — everything else takes the lockstep kernel
+        const GenericReq q = {c->precision, mode, queued, filt, anysrc, scat, a.wide != 0};
+        name = launch_generic(q, cfg, a);
+    }
+    snprintf(c->last_kernel, sizeof c->last_kernel, "%s", name ? name : "(none)");
 }
 
 // The re-run list holds one entry per ray of a deferral group.  A group must be able to take every
@@ -2183,7 +768,7 @@ static int reserve_list(ort_ctx *c, uint64_t n_rays)
 constexpr int kScatterChunkLog2 = 27;
 static uint64_t scatter_chunk()
 {
-    static const uint64_t chunk = 1ull << env_int("ORT_SCAT_CHUNK_LOG2", kScatterChunkLog2);     // development knob
+    static const uint64_t chunk = 1ull << env_int("ORT_DEV_SCAT_CHUNK_LOG2", kScatterChunkLog2);     // development knob
     return chunk;
 }
 // Workgroups of scatter_front_kernel for a launch of n rays: one per CU (12 persistent wavefronts each), fewer when the
@@ -2192,12 +777,12 @@ static uint64_t scatter_chunk()
 static unsigned scatter_groups(const ort_ctx *c, uint64_t n)
 {
     const uint64_t batches = (n + 63) / 64, want = (batches + kScatWaves - 1) / kScatWaves;
-    const uint64_t most = (uint64_t)env_int("ORT_SCAT_GROUPS", c->n_cus);         // development knob
+    const uint64_t most = (uint64_t)env_int("ORT_DEV_SCAT_GROUPS", c->n_cus);         // development knob
     return (unsigned)(want < most ? (want ? want : 1) : most);
 }
 static uint32_t scatter_grab(uint64_t n, unsigned groups)
 {
-    static const int forced = env_int("ORT_SCAT_GRAB", 0);                        // development knob (batches per pull)
+    static const int forced = env_int("ORT_DEV_SCAT_GRAB", 0);                        // development knob (batches per pull)
     const uint64_t per_wave = (n + 63) / 64 / ((uint64_t)groups * kScatWaves);
     uint64_t g = per_wave / 32;
     if (g < 1) g = 1;
@@ -2296,11 +881,17 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     a0.wide = (c->variant & 32) ? 1 : 0;
     a0.cull_word = culling ? c->ring_cull_word : 0xffffffffu;
     a0.cull_wordf = culling ? c->ring_cull_wordf : 0xffffffffu;
+    a0.cull_wide = culling ? c->ring_cull_wide : ~0ull;
     if (a0.first_ray > ORT_MAX_RAY_INDEX || a0.n_rays > ORT_MAX_RAY_INDEX - a0.first_ray)
         return fail(ORT_E_INVALID, "ray indices reach beyond 2^40 (ORT_MAX_RAY_INDEX): the keyed draw counter holds 40 bits of ray index");
     if (a0.n_rays == 0) return ORT_OK;
-    const bool queued = (c->variant & 1) && mode != MODE_DEBUG && !a0.wide;     // 53-bit draws: the lockstep kernel
     const bool filt = (c->variant & 2) == 0 && c->precision != 1;      // fp32: literal predicates, nothing is deferred
+    // 53-bit draws: the queued kernels of the exact fp64 path have WIDE instantiations (surface programs, the generic filtered
+    // walk in clear media, the scattering pipeline); every other combination takes the lockstep kernel, which chooses its
+    // stream at run time
+    const bool pipeline_ok = c->scat_k0[a0.phase - 1] > 0 && (c->variant & 16) == 0;
+    const bool wide_queued = c->precision == 0 && filt && (!c->scatter[a0.phase - 1] || (pipeline_ok && mode == MODE_FUSED));
+    const bool queued = (c->variant & 1) && mode != MODE_DEBUG && (!a0.wide || wide_queued);
     const bool anysrc_emitter = c->emitter[a0.phase - 1] != (a0.phase == 1 ? ORT_EMIT_RING : ORT_EMIT_POINT);
     const bool anysrc = anysrc_emitter || c->scatter[a0.phase - 1];
     // The queued filtered kernel defers the rays that sit on a decision boundary to a list, which
@@ -2309,12 +900,11 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
     const bool deferring = queued && filt;
     const uint64_t total = a0.n_rays;
     // scattering media, exact fp64, the default kernel variant: the three-stage pipeline (scatter_front_kernel)
-    const bool pipeline = mode == MODE_FUSED && deferring && c->precision == 0 && c->scatter[a0.phase - 1] &&
-                          c->scat_k0[a0.phase - 1] > 0 && (c->variant & 16) == 0;
+    const bool pipeline = mode == MODE_FUSED && deferring && c->precision == 0 && c->scatter[a0.phase - 1] && pipeline_ok;
     // fp32 hit log: worth its second kernel (~10 us + the launch gap) where a large share of the rays is binned — the point loop
-    // (42 % of its rays: -28 % per step); the ring loop bins 1 % of its rays and keeps the atomics.  ORT_HIT_LOG = 1 never,
+    // (42 % of its rays: -28 % per step); the ring loop bins 1 % of its rays and keeps the atomics.  ORT_DEV_HIT_LOG = 1 never,
     // 2 the point loop (default), 3 both loops (development knob; the image is the same bit for bit)
-    static const int hit_log_mode = env_int("ORT_HIT_LOG", 2);
+    static const int hit_log_mode = env_int("ORT_DEV_HIT_LOG", 2);
     const bool logging = fp32_queued_launch(c, mode, a0.phase, queued, anysrc) && hit_log_mode >= (a0.phase == 2 ? 2 : 3);
     // (a queued launch indexes its rays with 32 bits; a logging launch fits the hit log: kHitLogEntries)
     const uint64_t step = pipeline ? scatter_chunk() : (queued ? chunk_rays() : total);
@@ -2373,15 +963,10 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
             a.scat_grab = scatter_grab(a.n_rays, groups);
             a.scat_share = (((a.n_rays + kScatHeads - 1) / kScatHeads) + 63) & ~63ull;
             HIP_TRY(hipMemsetAsync(c->d_scat_ctl, 0, kScatCtlWords * sizeof(unsigned long long), c->stream));
-            if (anysrc_emitter) hipLaunchKernelGGL(scatter_front_kernel<true>, dim3(groups), dim3(64 * kScatWaves), 0, c->stream, a);
-            else hipLaunchKernelGGL(scatter_front_kernel<false>, dim3(groups), dim3(64 * kScatWaves), 0, c->stream, a);
+            const LaunchCfg front = {(int)groups, c->stream, nullptr, nullptr}, cont = {grid, c->stream, nullptr, nullptr};
+            (void)launch_scatter_front(anysrc_emitter, a.wide != 0, front, a);
             HIP_TRY(hipGetLastError());
-            if (c->cont_prog[a.phase - 1])
-                hipLaunchKernelGGL((trace_queue_kernel<MODE_CONTINUE, true, false, double, PROG_POINT_WALKED, false>), dim3(grid), dim3(kBlock), 0,
-                                   c->stream, a);
-            else
-                hipLaunchKernelGGL((trace_queue_kernel<MODE_CONTINUE, true, false, double, PROG_GENERIC, false>), dim3(grid), dim3(kBlock), 0,
-                                   c->stream, a);
+            snprintf(c->last_kernel, sizeof c->last_kernel, "scatter_front_kernel + %s", launch_continue(c->cont_prog[a.phase - 1], a.wide != 0, cont, a));
         } else if (logging) {
             const uint64_t nwaves = (uint64_t)grid * kWavesPerBlock;
             { const int rc = reserve_hit_log(c, a.phase, a.n_rays, nwaves); if (rc) return rc; }
@@ -2596,7 +1181,15 @@ struct Rccl {
     int n;                                   // communicators currently held ...
     int devices[ORT_MAX_DEVICES];            // ... for these devices, in this order
     ncclComm_t comms[ORT_MAX_DEVICES];
+    int fault;                               // tests (ort_debug_fault_allreduce): the next collective is given an invalid datatype
 } g_rccl;
+
+// the communicators this process holds are given back (ort_comm_destroy; a failed collective: the next call starts afresh)
+void rccl_drop()
+{
+    for (int i = 0; i < g_rccl.n; ++i) (void)g_rccl.CommDestroy(g_rccl.comms[i]);
+    g_rccl.n = 0;
+}
 
 int rccl_load()
 {
@@ -2644,8 +1237,7 @@ int ort_allreduce(ort_ctx **ctxs, int n)
     bool same = g_rccl.n == n;
     for (int i = 0; same && i < n; ++i) same = g_rccl.devices[i] == ctxs[i]->device;
     if (!same) {
-        for (int i = 0; i < g_rccl.n; ++i) (void)g_rccl.CommDestroy(g_rccl.comms[i]);
-        g_rccl.n = 0;
+        rccl_drop();
         int devs[ORT_MAX_DEVICES];
         for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
         RCCL_TRY(g_rccl.CommInitAll(g_rccl.comms, n, devs));
@@ -2662,10 +1254,11 @@ int ort_allreduce(ort_ctx **ctxs, int n)
     RCCL_TRY(g_rccl.GroupStart());
     // The group is ENDED on every path: a call that fails inside it (RCCL records the error, ncclGroupEnd then drops what
     // was queued and returns it) must not leave the process with an open group that swallows every later RCCL call.
-    // ORT_FAULT_ALLREDUCE (tests): the first collective is given an invalid datatype.
+    // A failed collective can leave a communicator unusable: the cached ones are destroyed, the next call initialises new ones.
     ncclResult_t bad = ncclSuccess;
     const char *what = nullptr;
-    const bool fault = getenv("ORT_FAULT_ALLREDUCE") != nullptr;
+    const bool fault = g_rccl.fault != 0;      // tests only (ort_debug_fault_allreduce): armed for ONE call
+    g_rccl.fault = 0;
     for (int i = 0; i < n && bad == ncclSuccess; ++i) {
         ort_ctx *c = ctxs[i];
         bad = g_rccl.AllReduce(c->d_image, c->d_image, ORT_IMAGE_BINS, (fault && i == 0) ? (ncclDataType_t)99 : ncclInt32, ncclSum, g_rccl.comms[i], c->stream);
@@ -2674,8 +1267,15 @@ int ort_allreduce(ort_ctx **ctxs, int n)
         if (bad != ncclSuccess) what = "ncclAllReduce(counters)";
     }
     const ncclResult_t end = g_rccl.GroupEnd();
+    if (bad != ncclSuccess || end != ncclSuccess) rccl_drop();
     if (bad != ncclSuccess) return rccl_fail(what, bad);
     if (end != ncclSuccess) return rccl_fail("ncclGroupEnd", end);
+    return ORT_OK;
+}
+
+int ort_comm_destroy(void)
+{
+    if (g_rccl.lib) rccl_drop();
     return ORT_OK;
 }
 
@@ -2731,6 +1331,8 @@ int ort_set_kernel_variant(ort_ctx *c, int variant)
 {
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
     if (variant < 0 || variant > 127) return fail(ORT_E_INVALID, "variant must be in 0..127");
+    if ((variant & 64) && c->precision != 0)
+        return fail(ORT_E_INVALID, "kernel variant bit 6 (strict libm emitters) belongs to the exact fp64 path: ort_set_precision(0) first");
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = close_group(c); if (rc) return rc; }
     c->variant = variant;
@@ -2756,9 +1358,18 @@ int ort_set_precision(ort_ctx *c, int precision)
 {
     if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
     if (precision < 0 || precision > 2) return fail(ORT_E_INVALID, "precision must be 0 (fp64 exact), 1 (fp32) or 2 (fp64 fast)");
+    if (precision != 0 && (c->variant & 64))
+        return fail(ORT_E_INVALID, "strict libm emitters (kernel variant bit 6) are set: they belong to the exact fp64 path — clear the bit first");
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = close_group(c); if (rc) return rc; }     // the re-run uses the arithmetic of its launches
     c->precision = precision;
+    return ORT_OK;
+}
+
+int ort_last_kernel_name(ort_ctx *c, char *buf, int capacity)
+{
+    if (!c || !buf || capacity < 1) return fail(ORT_E_INVALID, "bad argument");
+    snprintf(buf, (size_t)capacity, "%s", c->last_kernel);
     return ORT_OK;
 }
 
@@ -2787,6 +1398,14 @@ int ort_last_kernel_ms(ort_ctx *c, int kind, float *ms)
 }
 
 }  // extern "C"
+
+// TEST HOOK, not part of include/ort.h: the next ort_allreduce of this process hands its first collective an invalid
+// datatype (tests/test_gpu_distributed.py: the group is ended, the error is reported, the call after it works)
+extern "C" int ort_debug_fault_allreduce(int arm)
+{
+    g_rccl.fault = arm != 0;
+    return ORT_OK;
+}
 
 #ifdef ORT_DBG_RARE
 // development build only: per-site counts of raised `rare` flags since the library was loaded

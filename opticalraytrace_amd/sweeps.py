@@ -108,23 +108,39 @@ class Sweep:
         return None
 
     def flush(self) -> None:
-        """Run the queued simulations as one batch, then leave each one's files, in queue order.  If the batch fails
-        (a device error in the middle of it) the queue is re-run one simulation at a time, so that — like runner.py,
-        which runs them one by one — every simulation before the failing one leaves its outputs; the error of the
-        failing one is raised after that."""
+        """Run the queued simulations as one batch, then leave each one's files, in queue order.  If the library reports
+        an error for the batch (OrtError; anything else is a programming error and is raised as it is) the queue is
+        re-run one simulation at a time, so that — like runner.py, which runs them one by one — every simulation before
+        the failing one leaves its outputs; the error of the failing one is raised after that, and what had not run by
+        then stays queued (`_pending`)."""
         if not self._pending:
             return
         from .capi import OrtError
         pending, self._pending = self._pending, []
         tracer = self._tracer_for(pending[0][1])
         try:
-            results = tracer.run_many([system for _, _, system in pending])
-        except (OrtError, RuntimeError):
-            for name, s, system in pending:
-                tracer.set_system(system)
-                res = tracer.run(s.nphotons)
-                write_outputs(system, res, self.data_dir, self.verbose)
-                self.results.append((name, s, res))
+            # (a simulation without images — make_images false, src/main.f90:183 — brings back its counters only)
+            results = tracer.run_many([system for _, _, system in pending], want_images=[s.make_images for _, s, _ in pending])
+        except OrtError as e:
+            # A failed call leaves the queue as it was for the caller to see; the simulations are then run one at a time so
+            # that — like runner.py, which runs them one by one — every simulation before the failing one leaves its files.
+            # After a device fault (ORT_E_HIP) the HIP error is sticky for this context: a new one is built first; if the
+            # device itself is gone that fails too and the sweep ends there with what had run.
+            done = 0
+            self._pending = pending
+            try:
+                if "ORT_E_HIP" in str(e):
+                    tracer.close()
+                    self.tracer = None
+                    tracer = self._tracer_for(pending[0][1])
+                for name, s, system in pending:
+                    tracer.set_system(system)
+                    res = tracer.run(s.nphotons)
+                    write_outputs(system, res, self.data_dir, self.verbose)
+                    self.results.append((name, s, res))
+                    done += 1
+            finally:
+                self._pending = pending[done:]      # what did not run is still queued
             return
         for (name, s, system), res in zip(pending, results):
             write_outputs(system, res, self.data_dir, self.verbose)

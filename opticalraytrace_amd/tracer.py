@@ -44,7 +44,7 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 @dataclass
 class RunResult:
-    image: np.ndarray             # int32 [2][401][401]; [0] ring, [1] point
+    image: Optional[np.ndarray]   # int32 [2][401][401]; [0] ring, [1] point (None: a batched simulation whose image nobody asked for)
     counters: np.ndarray          # uint64 [8], see include/ort.h ORT_C_*
     nphotons: int
 
@@ -125,7 +125,8 @@ class ShardedRun:
         return self.result(nphotons)
 
     # ---- a batch of simulations (a sweep): hooks for where the accumulators live and how a system is staged
-    def _new_accumulators(self, n: int):
+    def _new_accumulators(self, n_images: int, n: int):
+        """(images [n_images][2][401][401] int32, counters [n][8] int64), zero-filled, where the traces write."""
         raise NotImplementedError
 
     def _begin_simulation(self, system, image, counters) -> None:
@@ -134,21 +135,37 @@ class ShardedRun:
     def _end_batch(self) -> None:
         pass
 
-    def run_many(self, systems, seed: int = DEFAULT_SEED, phases=(1, 2)):
+    def _to_host(self, images, counters):
+        """The batch's accumulators as numpy arrays (GPU tracer: through pinned staging buffers)."""
+        return images.cpu().numpy(), counters.cpu().numpy()
+
+    def run_many(self, systems, seed: int = DEFAULT_SEED, phases=(1, 2), want_images=True):
         """A batch of simulations (a sweep: runner.py starts one process per settings file, :26-47) queued
         back to back: per simulation the system is staged (`_begin_simulation`: on the GPU asynchronously,
         ort_set_system), the accumulators are that simulation's slice of ONE array [n_sim][2][401][401]
         (+ [n_sim][8] counters) and this rank's shard of both loops is launched; then ONE sum over the ranks of
         the whole arrays, one wait, one copy back.  Returns one RunResult per system, each bit-identical to
-        `set_system(s); run()` done one at a time, on every rank."""
+        `set_system(s); run()` done one at a time, on every rank.
+        `want_images`: True, False, or one flag per system — a simulation whose image nobody reads (the reference's
+        `make_images = .false.`, src/main.f90:183: only the transmission row is written) bins into ONE scratch image
+        shared by all such simulations and comes back with `image = None`: nothing of it is allocated per simulation,
+        summed over ranks or copied to the host (75 x 1.29 MB in runner.py's lens experiment)."""
         n = len(systems)
         if n == 0:
             return []
+        flags = [bool(want_images)] * n if isinstance(want_images, (bool, int)) else [bool(w) for w in want_images]
+        if len(flags) != n:
+            raise ValueError("want_images: one flag per system")
+        slot = {}                                   # simulation -> its image in the batch array; the last one is the scratch
+        for i, w in enumerate(flags):
+            if w:
+                slot[i] = len(slot)
+        n_img = len(slot)
         with self._on_stream():                 # zero-filled on the stream the traces into them run on
-            images, counters = self._new_accumulators(n)
+            images, counters = self._new_accumulators(n_img + (1 if n_img < n else 0), n)
         try:
             for i, system in enumerate(systems):
-                self._begin_simulation(system, images[i], counters[i])
+                self._begin_simulation(system, images[slot.get(i, n_img)], counters[i])
                 lo, cnt = shard_range(system.settings.nphotons, self.rank, self.world)
                 for phase in phases:
                     self._trace_shard(phase, lo, cnt, seed)
@@ -157,12 +174,12 @@ class ShardedRun:
         with self._on_stream():
             if self.world > 1:
                 import torch.distributed as dist
-                dist.all_reduce(images, op=dist.ReduceOp.SUM, group=self.group)
+                if n_img:
+                    dist.all_reduce(images[:n_img], op=dist.ReduceOp.SUM, group=self.group)
                 dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=self.group)
-            self._synchronize()
-            h_img = images.cpu().numpy()
-            h_cnt = counters.cpu().numpy().astype(np.uint64)
-        return [RunResult(h_img[i], h_cnt[i], s.settings.nphotons) for i, s in enumerate(systems)]
+            h_img, h_cnt = self._to_host(images[:n_img], counters)
+        h_cnt = h_cnt.astype(np.uint64)
+        return [RunResult(h_img[slot[i]] if i in slot else None, h_cnt[i], s.settings.nphotons) for i, s in enumerate(systems)]
 
 
 class RayTracer(ShardedRun):
@@ -190,6 +207,7 @@ class RayTracer(ShardedRun):
         self.stream = torch.cuda.current_stream(self.device)
         self.ctx = Context(system, device=device, stream=self.stream.cuda_stream)
         self.ctx.attach_buffers(self.image.data_ptr(), self.counters.data_ptr())
+        self._pinned = {}
 
     def _on_stream(self):
         return self.torch.cuda.stream(self.stream)
@@ -218,10 +236,25 @@ class RayTracer(ShardedRun):
         return super().run(n, seed, phases)
 
     # ---- hooks of ShardedRun.run_many
-    def _new_accumulators(self, n: int):
-        images = self.torch.zeros((n, 2, IMAGE_N, IMAGE_N), dtype=self.torch.int32, device=self.device)
+    def _new_accumulators(self, n_images: int, n: int):
+        images = self.torch.zeros((n_images, 2, IMAGE_N, IMAGE_N), dtype=self.torch.int32, device=self.device)
         counters = self.torch.zeros((n, NUM_COUNTERS), dtype=self.torch.int64, device=self.device)
         return images, counters
+
+    def _to_host(self, images, counters):
+        # pinned staging buffers, kept between batches (a pageable copy goes through the runtime's own bounce buffers page
+        # by page — and a first-time 97 MB host array is 24 000 page faults); one wait for both copies
+        t = self.torch
+        out = []
+        for k, src in enumerate((images, counters)):
+            pin = self._pinned.get(k)
+            if pin is None or pin.numel() < src.numel():
+                pin = self._pinned[k] = t.empty(max(src.numel(), 1), dtype=src.dtype, pin_memory=True)
+            dst = pin[:src.numel()].view(src.shape)
+            dst.copy_(src, non_blocking=True)
+            out.append(dst)
+        self.stream.synchronize()
+        return out[0].numpy().copy(), out[1].numpy().copy()
 
     def _begin_simulation(self, system: OpticalSystem, image, counters) -> None:
         self.set_system(system)                                          # asynchronous: the next slot of the ring

@@ -47,6 +47,8 @@ class FullSizeReport:
     counter_delta: List[int] = field(default_factory=lambda: [0] * 8)
     divergences: List[Divergence] = field(default_factory=list)
     chunks_differing: int = 0
+    want_image: object = None          # the checker's layer image (int64 [401][401]) and counters (int64 [8]) of the range
+    want_counters: object = None
 
     @property
     def defects(self):
@@ -113,6 +115,7 @@ def compare_full_size(got, want, phase: int, lo: int, n: int, got_total, chunk: 
         kept.append((a, m, wi.copy(), wc.copy()))
         total += wi
         ctot += wc.astype(np.int64)
+    rep.want_image, rep.want_counters = total, ctot
     gi, gc = got_total
     rep.image_l1 = int(np.abs(gi.astype(np.int64) - total).sum())
     rep.counter_delta = (gc.astype(np.int64) - ctot).tolist()

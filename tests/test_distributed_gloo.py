@@ -32,8 +32,8 @@ def _oracle_run(osys, rank=0, world=1):
                            self.counters.numpy().view(np.uint64), nthreads=2)
 
         # hooks of run_many (a batch of simulations): host arrays, a fresh oracle per system
-        def _new_accumulators(self, n):
-            return torch.zeros((n, 2, 401, 401), dtype=torch.int32), torch.zeros((n, 8), dtype=torch.int64)
+        def _new_accumulators(self, n_images, n):
+            return torch.zeros((n_images, 2, 401, 401), dtype=torch.int32), torch.zeros((n, 8), dtype=torch.int64)
 
         def _begin_simulation(self, system, image, counters):
             self.orc = Oracle(system)

@@ -126,9 +126,10 @@ def test_c_abi_allreduce(plain):
 
 
 def test_c_abi_allreduce_ends_its_group_on_a_failed_collective(plain):
-    """A collective that fails INSIDE ncclGroupStart ... ncclGroupEnd (here: an invalid datatype planted by
-    ORT_FAULT_ALLREDUCE) is reported — and the group is ended all the same: the next ort_allreduce of the process works
-    and leaves the right sums.  (Round 3's ort_allreduce returned from inside the open group.)"""
+    """A collective that fails INSIDE ncclGroupStart ... ncclGroupEnd (here: an invalid datatype planted through the test
+    hook ort_debug_fault_allreduce, armed for one call) is reported — and the group is ended all the same, the cached
+    communicators are dropped: the next ort_allreduce of the process initialises new ones, works and leaves the right sums.
+    (Round 3's ort_allreduce returned from inside the open group.)"""
     import ctypes as C
     from opticalraytrace_amd import capi
     osys, want = plain
@@ -138,13 +139,17 @@ def test_c_abi_allreduce_ends_its_group_on_a_failed_collective(plain):
         for phase in (1, 2):
             a.trace(phase, 0, N, SEED)
         arr = (C.c_void_p * 1)(a._h)
-        os.environ["ORT_FAULT_ALLREDUCE"] = "1"
-        try:
-            rc = lib.ort_allreduce(arr, 1)
-        finally:
-            del os.environ["ORT_FAULT_ALLREDUCE"]
+        capi.allreduce([a])                         # communicators exist
+        assert capi.allreduce_ranks() == 1
+        lib.ort_debug_fault_allreduce(1)
+        rc = lib.ort_allreduce(arr, 1)
         assert rc != 0 and b"ncclAllReduce" in lib.ort_last_error(), (rc, lib.ort_last_error())
-        capi.allreduce([a])                         # the group was ended: this one goes through
+        assert capi.allreduce_ranks() == 0          # ... and were dropped by the failure
+        capi.allreduce([a])                         # the group was ended: this one goes through, on new communicators
+        assert capi.allreduce_ranks() == 1
+        capi.comm_destroy()                         # ort_comm_destroy: given back; the next reduce would make new ones
+        assert capi.allreduce_ranks() == 0
+        capi.comm_destroy()                         # (idempotent)
         img, cnt = a.read()
     assert np.array_equal(img, want.image)
     assert np.array_equal(cnt, want.counters)

@@ -187,7 +187,7 @@ np.savez(sys.argv[2], **out)
 
 @pytest.mark.parametrize("name,n", [("large", (1 << 25) + 4321), ("large_crs", 400_000), ("large_image", 50_000), ("small_scatter_bc", 200_000)])
 def test_hit_log_and_atomics_give_the_same_image(hip_library, tmp_path, name, n):
-    """The fp32 queued kernels either bin the point loop's hits with atomics or log them for bin_log_kernel (ORT_HIT_LOG:
+    """The fp32 queued kernels either bin the point loop's hits with atomics or log them for bin_log_kernel (ORT_DEV_HIT_LOG:
     1 never, 2 — the default — log; read once per process): integer adds commute, so the images and counter sets are
     identical — for 3.4e7 rays, for a source program, for the image source, and for a scattering bottle (lockstep kernel
     in fp32); the fp64 arithmetics, which keep the atomics, ride along unchanged (launch boundaries:
@@ -197,7 +197,7 @@ def test_hit_log_and_atomics_give_the_same_image(hip_library, tmp_path, name, n)
     got = []
     for mode in ("1", "2"):
         out = str(tmp_path / f"m{mode}.npz")
-        env = {**os.environ, "ORT_HIT_LOG": mode}
+        env = {**os.environ, "ORT_DEV_HIT_LOG": mode}
         r = subprocess.run([sys.executable, "-c", _HIT_LOG_CHILD, ROOT, out, name, str(n)], env=env, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         got.append(np.load(out))

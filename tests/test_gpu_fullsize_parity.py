@@ -28,6 +28,7 @@ from parity import SEED
 pytestmark = pytest.mark.gpu
 
 EMISSION_BUDGET = 4          # rays per run; observed: 0 at every size
+STRICT = 1 | 64              # the same production kernels with the strict libm emitters (kernel variant bit 6): NO budget
 
 
 @pytest.fixture(scope="module")
@@ -57,6 +58,21 @@ def _check(ctx, got, want, phase, calls, record_property):
     assert not rep.defects, rep.summary()
     assert len(rep.divergences) <= EMISSION_BUDGET, rep.summary()
     assert rep.image_l1 <= 2 * EMISSION_BUDGET and max(abs(d) for d in rep.counter_delta) <= 8 * EMISSION_BUDGET, rep.summary()
+    # The same calls on the SURFACE-PROGRAM kernels with strict libm emitters: the emitted rays are the checker's bit for
+    # bit, so there is no budget — the layer and all 8 counters equal the checker's exactly.
+    ctx.set_kernel_variant(STRICT)
+    try:
+        ctx.reset()
+        for a, m in calls:
+            ctx.trace(phase, a, m, SEED)
+        kname = ctx.last_kernel_name()
+        simg, scnt = ctx.read()
+    finally:
+        ctx.set_kernel_variant(1)
+    assert "trace_queue_kernel<MODE_FUSED, double, PROG_" in kname and "strict=1, wide=0" in kname, kname
+    record_property("strict_kernel", kname)
+    assert np.array_equal(simg[phase - 1].astype(np.int64), rep.want_image), int(np.abs(simg[phase - 1].astype(np.int64) - rep.want_image).sum())
+    assert np.array_equal(scnt.astype(np.int64), rep.want_counters), (scnt, rep.want_counters)
     return rep, img, cnt
 
 

@@ -10,7 +10,7 @@ from conftest import make_system
 from parity import SEED, load_golden, merge_status, rel_err
 from stats_util import assert_same_distribution
 
-WIDE = 1 | 32                 # default kernels + 53-bit draws (the lockstep kernel takes over)
+WIDE = 1 | 32                 # default kernels + 53-bit draws: the WIDE instantiations of the queued kernels (csrc/ort_k_wide.hip)
 WIDE_STRICT = 1 | 32 | 64     # ... + the emitters through glibc's own sin / cos: bit for bit against the checker
 
 
@@ -105,9 +105,21 @@ def test_image_on_the_wide_stream_equals_the_checkers(hip_library, wide_oracle, 
     orc = wide_oracle(osys)
     n = 200_003 if osys.settings.light_source != "image" else 50_000
     with Context(osys) as ctx:
+        names = {}
+        for phase in (1, 2):
+            ctx.trace(phase, 5, n, SEED)
+            names[phase] = ctx.last_kernel_name()
+        ctx.reset()
         ctx.set_kernel_variant(WIDE_STRICT)
         for phase in (1, 2):
             ctx.trace(phase, 5, n, SEED)
+            # the stream is a template flag of the production kernels: a surface program stays a surface program, the
+            # scattering pipeline stays the pipeline (round 4 sent every launch to the lockstep kernel)
+            kname = ctx.last_kernel_name()
+            if "strict=0, wide=0" in names[phase]:
+                assert kname == names[phase].replace("strict=0, wide=0", "strict=1, wide=1"), (names[phase], kname)
+            else:
+                assert ("scatter_front_kernel" in kname) == ("scatter_front_kernel" in names[phase]) and "trace_kernel<" not in kname, (names[phase], kname)
         img, cnt = ctx.read()
         wimg = np.zeros((2, 401, 401), np.int32); wc = np.zeros(8, np.uint64)
         for phase in (1, 2):

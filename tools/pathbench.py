@@ -67,7 +67,7 @@ def main():
         # the generic walk needs the development knob in the environment before the library loads: child process
         from opticalraytrace_amd import capi
         print(f"# library build {capi.build_id()}; mean kernel time of {args.reps} launches behind 2 warm-up launches")
-        for tag, env in (("main", {}), ("generic", {"ORT_NO_PROGRAMS": "1"})):
+        for tag, env in (("main", {}), ("generic", {"ORT_DEV_NO_PROGRAMS": "1"})):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rays", str(args.rays), "--reps", str(args.reps),
                                 "--only", tag], env={**os.environ, **env})
             if r.returncode:
