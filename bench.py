@@ -250,6 +250,7 @@ def main() -> int:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast", action="store_true", help="skip the informational fast-fp64 leg")
     ap.add_argument("--no-fp32", action="store_true", help="skip the informational fp32 leg (configs[4])")
+    ap.add_argument("--no-strict", action="store_true", help="skip the strict-libm / 53-bit-draw legs of the exact fp64 path")
     ap.add_argument("--sweep", action="store_true",
                     help="also time runner.py's lens experiment (75 systems): batched / one by one / process per simulation, "
                          "at 1e6 and 1e9 photons; adds the `sweep` object (several extra seconds)")
@@ -422,14 +423,24 @@ def main() -> int:
     value = isect_total / elapsed
 
     # ---- informational legs (outside `value`): the same rays in the other arithmetics -----------
+    # strict / wide / strict_wide: the exact fp64 path with the reference's own bits in front of the surfaces — glibc's
+    # sin / cos / sincos in the emitters (kernel variant bit 6, src/sourceMod.f90:12-47, :250-300 through the platform libm)
+    # and 53-bit uniforms (bit 5, src/random_mod.f90:39-46) — as template flags of the same surface programs
     legs = {}
-    for name, prec, skip in (("fp32", 1, args.no_fp32), ("fast_fp64", 2, args.no_fast)):
+    for name, prec, variant, skip in (("strict", 0, 1 | 64, args.no_strict), ("wide", 0, 1 | 32, args.no_strict),
+                                      ("strict_wide", 0, 1 | 32 | 64, args.no_strict),
+                                      ("fp32", 1, 1, args.no_fp32), ("fast_fp64", 2, 1, args.no_fast)):
         if skip:
             continue
+        ctx.set_kernel_variant(1)
         ctx.set_precision(prec)
+        ctx.set_kernel_variant(variant)
+        for ph in phases:                                   # the variant's code object (set-up, as above)
+            ctx.trace(ph, 0, 64, DEFAULT_SEED)
         el, kms = timed_run(args.steps, args.warmup)
         r = tracer.result(total_rays * args.steps)
-        legs[name] = (el, kms, r, timed_run.culled)
+        legs[name] = (el, kms, r, timed_run.culled, ctx.last_kernel_name())
+    ctx.set_kernel_variant(1)
     ctx.set_precision(0)
 
     # ---- N > 1 proves itself (outside every timed region): ONE extra step traced the way the timed steps are — every rank
@@ -617,8 +628,23 @@ def main() -> int:
             "note": "each scattered int32 atomic is one 32-byte memory-side write",
         } if traffic else None),
     }
+    for name, text_ in (("strict", "kernel variant bit 6: the light sources call glibc 2.35's own sin / cos / sincos — every emitted ray, state, "
+                                   "image and counter equals the reference's bit for bit (tests: budget 0 at full size)"),
+                        ("wide", "kernel variant bit 5: 53-bit uniforms (ORT-RNG-v2w, one hash per draw) — another stream, the same statistics"),
+                        ("strict_wide", "bits 5 + 6: glibc emitters on 53-bit uniforms")):
+        if name not in legs:
+            continue
+        el, kms, r, cul, kname = legs[name]
+        i_s, b_s = isect_binned(r)
+        out[name] = {
+            "value": i_s / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3, "dtype": "f64",
+            "roofline": fp_roofline(kms, r, cul, FP64_VEC_PEAK_TFLOPS, "valu_fp64", kernels_per_call),
+            "kernel": kname, "vs_default": (i_s / el) / value,
+            "image_l1_vs_default": (int(abs(r.image.astype("int64") - res.image.astype("int64")).sum()) if name == "strict" else None),
+            "binned": b_s, "intersections": i_s, "note": text_,
+        }
     if "fp32" in legs:
-        el, kms, r, cul = legs["fp32"]
+        el, kms, r, cul, _ = legs["fp32"]
         i32, b32 = isect_binned(r)
         out["fp32"] = {
             "value": i32 / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3, "dtype": "f32",
@@ -634,7 +660,7 @@ def main() -> int:
                     "the trace kernel, ms_per_step holds everything",
         }
     if "fast_fp64" in legs:
-        el, kms, r, cul = legs["fast_fp64"]
+        el, kms, r, cul, _ = legs["fast_fp64"]
         i2, _ = isect_binned(r)
         out["fast_fp64"] = {
             "value": i2 / el, "unit": "intersections/s", "ms_per_step": el / args.steps * 1e3,

@@ -144,7 +144,7 @@ def library_path() -> str:
 
 # csrc/Makefile SOURCES, in its order: the translation units, then the headers
 KERNEL_UNITS = ("ort_hip", "ort_k_prog64", "ort_k_strict", "ort_k_wide", "ort_k_prog32", "ort_k_fast", "ort_k_generic", "ort_k_scatter",
-                "ort_k_batch")
+                "ort_k_batch", "ort_k_exp")
 KERNEL_SOURCES = tuple(u + ".hip" for u in KERNEL_UNITS) + (
     "ort_device.h", "ort_fastd.h", "ort_libm.h", "ort_libm_tables.h", os.path.join("..", "..", "include", "ort.h"),
     "ort_trace.h", "ort_scatter.h", "ort_launch.h", "ort_k_program.h")

@@ -337,6 +337,12 @@ struct ort_ctx {
     float ring_cullf;
     uint32_t ring_cull_word, ring_cull_wordf;      // TraceArgs.cull_word / cull_wordf (cull_word_of)
     uint64_t ring_cull_wide;                       // TraceArgs.cull_wide (cull_wide_of)
+    // development (ort_debug_set_exp, ort_k_exp.hip): experiment on the fused point program, 0 = none; the pulled variants'
+    // static share of a launch (percent), pull bounds (batches of 64 rays), workgroups per CU; their work heads: a ring of
+    // kPullSets sets of eight 128-byte lines, zero when handed to a launch
+    int exp_which, exp_static_pct, exp_min, exp_max, exp_wg_per_cu;
+    unsigned int *d_pull_ctl;
+    int pull_set;
     hipEvent_t ev[3][2];
     hipEvent_t ring[kTimingRing][2];   // fused-trace launches, most recent kTimingRing
     unsigned long long ring_count;
@@ -660,6 +666,7 @@ int ort_destroy(ort_ctx *c)
     (void)hipFree(c->d_cont_pos_dir); (void)hipFree(c->d_cont_draw); (void)hipFree(c->d_cont_nis); (void)hipFree(c->d_cont_t);
     (void)hipFree(c->d_scat_ctl);
     (void)hipFree(c->d_hit_log); (void)hipFree(c->d_hit_dir); (void)hipFree(c->d_slabs);
+    (void)hipFree(c->d_pull_ctl);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ORT_OK;
@@ -710,6 +717,46 @@ int ort_flush(ort_ctx *c)
     return flush_replicas(c);
 }
 
+// development: does the experiment armed by ort_debug_set_exp apply to this launch (the fused point program, exact fp64, ORT-RNG-v2)?
+static bool exp_applies(const ort_ctx *c, int mode, const TraceArgs &a)
+{
+    return c->exp_which > 0 && mode == MODE_FUSED && c->precision == 0 && c->prog[a.phase - 1] == PROG_POINT && !a.strict && !a.wide &&
+           !a.listed && (c->variant & 3) == 1 && !c->scatter[a.phase - 1];
+}
+
+// the pulled variants' plan of a launch: kWavesPerBlock x wg_per_cu x CUs persistent waves, each with a static first range
+// (static_pct of the launch in equal shares), the rest handed out by eight heads (TraceArgs.pull_*)
+constexpr int kPullSets = 256;
+static int plan_pull(ort_ctx *c, TraceArgs &a, int *grid)
+{
+    if (!c->d_pull_ctl) {
+        HIP_TRY(hipMalloc(&c->d_pull_ctl, (size_t)kPullSets * 8 * 128));
+        HIP_TRY(hipMemsetAsync(c->d_pull_ctl, 0, (size_t)kPullSets * 8 * 128, c->stream));
+        c->pull_set = 0;
+    }
+    if (c->pull_set == kPullSets) {
+        HIP_TRY(hipMemsetAsync(c->d_pull_ctl, 0, (size_t)kPullSets * 8 * 128, c->stream));
+        c->pull_set = 0;
+    }
+    const uint64_t n = a.n_rays, batches = (n + 63) / 64;
+    uint64_t blocks = (uint64_t)c->n_cus * (uint64_t)c->exp_wg_per_cu;
+    if (blocks * kWavesPerBlock > batches) blocks = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint64_t nwaves = blocks * kWavesPerBlock;
+    a.head_blocks = (uint32_t)blocks;
+    a.head_chunk = ((n / 100 * (uint64_t)c->exp_static_pct / nwaves) + 63) & ~63ull;
+    if (c->exp_static_pct == 0) a.head_chunk = 0;
+    a.head_rays = a.head_chunk * nwaves < n ? a.head_chunk * nwaves : n;
+    a.tail_chunk = 64;
+    const uint64_t rest_b = (n - a.head_rays + 63) / 64;
+    a.pull_share_b = (uint32_t)((rest_b + 7) / 8);
+    a.pull_wph = (uint32_t)((nwaves + 7) / 8);
+    a.pull_min = (uint32_t)c->exp_min; a.pull_max = (uint32_t)c->exp_max;
+    a.pull_ctl = c->d_pull_ctl + (size_t)c->pull_set * 8 * 32;
+    c->pull_set++;
+    *grid = (int)blocks;
+    return ORT_OK;
+}
+
 // One kernel of the trace family on `grid` workgroups: the most specific family that holds a kernel for the request
 // (ort_launch.h) — a surface program the staged system matches, else the generic walk / the lockstep kernel.
 static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool queued, bool filt, bool anysrc)
@@ -722,7 +769,8 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
     int prog = c->prog[a.phase - 1];
     if (mode != MODE_FUSED && a.draw_base != (a.phase == 1 ? 4 : 2)) prog = PROG_GENERIC;
     const bool program = prog != PROG_GENERIC && queued && mode != MODE_DEBUG && !scat && (filt || c->precision == 1);
-    if (program) {
+    if (program && exp_applies(c, mode, a)) name = launch_exp(c->exp_which, cfg, a);
+    else if (program) {
         if (c->precision == 2) name = launch_program_fast(prog, mode, cfg, a);
         else if (c->precision == 1) name = launch_program_f32(prog, mode, cfg, a);
         else if (a.wide) name = launch_program_f64_wide(prog, mode, a.strict != 0, cfg, a);
@@ -735,7 +783,8 @@ static void launch_one(ort_ctx *c, int mode, const TraceArgs &a, int grid, bool 
         const GenericReq q = {c->precision, mode, queued, filt, anysrc, scat, a.wide != 0};
         name = launch_generic(q, cfg, a);
     }
-    snprintf(c->last_kernel, sizeof c->last_kernel, "%s", name ? name : "(none)");
+    // (the literal re-run that closes a group is not "the kernel the trace ran": the name stays the queued launch's)
+    if (!a.listed) snprintf(c->last_kernel, sizeof c->last_kernel, "%s", name ? name : "(none)");
 }
 
 // The re-run list holds one entry per ray of a deferral group.  A group must be able to take every
@@ -936,7 +985,8 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
         a.first_ray = a0.first_ray + off;
         if (a.pos_dir_in) a.pos_dir_in += off;              // same component stride (in_stride)
         // queued: every wave walks 64-aligned contiguous ranges (plan_ranges); lockstep: grid-stride
-        const int grid = queued ? plan_ranges(a) : grid_for(a.n_rays);
+        int grid = queued ? plan_ranges(a) : grid_for(a.n_rays);
+        if (queued && c->exp_which >= 2 && exp_applies(c, mode, a)) { const int rc = plan_pull(c, a, &grid); if (rc) return rc; }
         if (deferring && mode == MODE_FUSED) {
             // fused launches share the re-run list of their group; the literal re-run comes when the
             // group closes (close_group)
@@ -1404,6 +1454,18 @@ int ort_last_kernel_ms(ort_ctx *c, int kind, float *ms)
 extern "C" int ort_debug_fault_allreduce(int arm)
 {
     g_rccl.fault = arm != 0;
+    return ORT_OK;
+}
+
+// DEVELOPMENT HOOK, not part of include/ort.h (tools/expbench.py): arm one of ort_k_exp.hip's experiments on the fused
+// point program of this context (which = 0: none)
+extern "C" int ort_debug_set_exp(ort_ctx *c, int which, int static_pct, int pull_min, int pull_max, int wg_per_cu)
+{
+    if (!c || which < 0 || which > 5 || static_pct < 0 || static_pct > 100 || pull_min < 1 || pull_max < pull_min || wg_per_cu < 1 || wg_per_cu > 8)
+        return fail(ORT_E_INVALID, "bad experiment");
+    HIP_TRY(hipSetDevice(c->device));
+    { const int rc = close_group(c); if (rc) return rc; }
+    c->exp_which = which; c->exp_static_pct = static_pct; c->exp_min = pull_min; c->exp_max = pull_max; c->exp_wg_per_cu = wg_per_cu;
     return ORT_OK;
 }
 

@@ -37,6 +37,9 @@ const char *launch_generic_fast(const GenericReq &q, const LaunchCfg &cfg, const
 const char *launch_scatter_front(bool anysrc, bool wide, const LaunchCfg &cfg, const TraceArgs &a);
 const char *launch_continue(bool program, bool wide, const LaunchCfg &cfg, const TraceArgs &a);
 
+// development experiments on the fused point program (ort_k_exp.hip; ort_debug_set_exp)
+const char *launch_exp(int which, const LaunchCfg &cfg, const TraceArgs &a);
+
 #define ORT_KLAUNCH(K) (hipExtLaunchKernelGGL(K, dim3(cfg.grid), dim3(kBlock), 0, cfg.stream, cfg.ev0, cfg.ev1, 0, a), #K)
 
 }  // namespace ortk

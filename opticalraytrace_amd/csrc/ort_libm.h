@@ -1,3 +1,9 @@
+// SPDX-License-Identifier: LGPL-2.1-or-later
+// Derived from the GNU C Library 2.35 (sysdeps/ieee754/dbl-64: s_sin.c, s_sincos.c, e_log.c, e_atan2.c, e_asin.c and their
+// tables — IBM Accurate Mathematical Library, Copyright (C) 2001-2022 Free Software Foundation, Inc.), restated for HIP.
+// This file is free software under the GNU Lesser General Public License, version 2.1 or any later version: see
+// THIRD_PARTY_NOTICES.md and LICENSES/LGPL-2.1.txt at the repository root.
+//
 // ort_libm.h — the reference's transcendental functions, bit for bit.
 //
 // The reference (Fortran, all `real` fp64) calls sin / cos / log / atan2 / acos of the platform's libm:

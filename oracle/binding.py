@@ -62,12 +62,79 @@ SOURCE_CODES = {"point": 0, "spot": 1, "crs": 2, "isors": 3, "image": 4}
 ISORS_NO_RING = 5      # test-only source code: iSORS(ring = .false.) in phase 1 (pins bottle_backward_sub)
 
 
-def build_oracle(force: bool = False) -> str:
-    if force or not os.path.exists(ORACLE_SO) or \
-            os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(os.path.join(HERE, f))
-                                              for f in ("ort_oracle.c", "ort_oracle.h")):
-        subprocess.run(["make", "-C", HERE, "oracle"], check=True, capture_output=True)
-    return ORACLE_SO
+PINNED_SO = os.path.join(HERE, "libort_oracle_pinned.so")
+LIBM_GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden", "libm_glibc235.npz")
+_HOST_LIBM_PINNED: Optional[bool] = None
+
+
+def host_libm_mismatches() -> list:
+    """Which of the host libm's sin / cos / sincos / log / atan2 / acos do NOT return glibc 2.35's (x86-64, FMA variants)
+    committed known answers (tests/golden/libm_glibc235.npz, a sample of each) — empty on the machine the device code
+    was pinned on.  The device reproduces glibc 2.35 wherever it runs; the oracle and oracle/_ref call the HOST's libm."""
+    g = np.load(LIBM_GOLD)
+    libm = C.CDLL("libm.so.6")
+    for f in ("sin", "cos", "log", "acos"):
+        getattr(libm, f).restype = C.c_double
+        getattr(libm, f).argtypes = [C.c_double]
+    libm.atan2.restype = C.c_double
+    libm.atan2.argtypes = [C.c_double, C.c_double]
+    libm.sincos.restype = None
+    libm.sincos.argtypes = [C.c_double, _DP, _DP]
+
+    def same(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return bool(((a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))).all())
+    bad = []
+    idx = np.arange(0, 12000, 7)
+    for f, x, w in (("sin", g["ang"], g["sin"]), ("cos", g["ang"], g["cos"]), ("log", g["log_x"], g["log"]), ("acos", g["acos_x"], g["acos"])):
+        i = idx[idx < len(x)]
+        if not same([getattr(libm, f)(float(v)) for v in x[i]], w[i]):
+            bad.append(f)
+    i = idx[idx < len(g["atan2"])]
+    if not same([libm.atan2(float(y), float(x)) for y, x in zip(g["atan2_y"][i], g["atan2_x"][i])], g["atan2"][i]):
+        bad.append("atan2")
+    i = idx[idx < len(g["ang"])]
+    sv, cv = C.c_double(), C.c_double()
+    got = []
+    for v in g["ang"][i]:
+        libm.sincos(float(v), C.byref(sv), C.byref(cv))
+        got.append((sv.value, cv.value))
+    got = np.array(got)
+    if not (same(got[:, 0], g["sincos_s"][i]) and same(got[:, 1], g["sincos_c"][i])):
+        bad.append("sincos")
+    return bad
+
+
+def host_libm_is_pinned() -> bool:
+    global _HOST_LIBM_PINNED
+    if _HOST_LIBM_PINNED is None:
+        _HOST_LIBM_PINNED = not host_libm_mismatches()
+    return _HOST_LIBM_PINNED
+
+
+def oracle_libm() -> str:
+    """'host' or 'pinned': which libm the oracle this process loads is built on.  ORT_ORACLE_LIBM=host|pinned decides;
+    unset (auto): the host's libm where it IS glibc 2.35's (then oracle == oracle/_ref == the reference built here, bit
+    for bit), else the pinned build (oracle/pinned_libm.cpp: csrc/ort_libm.h compiled for the host) — so that the GPU
+    parity suite does not go red for the host's reason on a box with another libm."""
+    want = os.environ.get("ORT_ORACLE_LIBM", "auto")
+    if want in ("host", "pinned"):
+        return want
+    return "host" if host_libm_is_pinned() else "pinned"
+
+
+def build_oracle(force: bool = False, libm: Optional[str] = None) -> str:
+    """Path of the checker to load: ORT_ORACLE_SO (an explicit build, e.g. the sanitizer one), else the host-libm or the
+    pinned-libm build (oracle_libm(); `libm` overrides), (re)built by oracle/Makefile when older than its sources."""
+    explicit = os.environ.get("ORT_ORACLE_SO")
+    if explicit and libm is None:
+        return explicit
+    pinned = (libm or oracle_libm()) == "pinned"
+    so = PINNED_SO if pinned else ORACLE_SO
+    deps = ["ort_oracle.c", "ort_oracle.h"] + (["pinned_libm.cpp", os.path.join("..", "opticalraytrace_amd", "csrc", "ort_libm.h")] if pinned else [])
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(os.path.join(HERE, f)) for f in deps):
+        subprocess.run(["make", "-C", HERE, "pinned" if pinned else "oracle"], check=True, capture_output=True)
+    return so
 
 
 def fill_system(osys) -> OrcSystem:
@@ -113,8 +180,12 @@ def _ip(a):
 
 
 class Oracle:
-    def __init__(self, osys=None, source_override=None):
-        self.lib = C.CDLL(build_oracle())
+    def __init__(self, osys=None, source_override=None, libm: Optional[str] = None):
+        """`libm`: None = the session's choice (oracle_libm()), "host" / "pinned" = that build (tests that compare the
+        oracle with oracle/_ref — the reference compiled here, on the host's libm — ask for "host")."""
+        self.lib = C.CDLL(build_oracle(libm=libm))
+        self.lib.orc_pinned_libm.restype = C.c_int
+        self.pinned_libm = bool(self.lib.orc_pinned_libm())
         L = self.lib
         L.orc_sellmeier.restype = C.c_double
         L.orc_sellmeier.argtypes = [C.c_double] * 7

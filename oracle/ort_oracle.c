@@ -10,6 +10,25 @@
 #include <stddef.h>
 #include <string.h>
 #include <stdlib.h>
+#ifdef ORC_PINNED_LIBM
+/* libort_oracle_pinned.so (oracle/Makefile `pinned`): the six libm entries of the trace path come from pinned_libm.cpp —
+ * csrc/ort_libm.h, glibc 2.35's algorithms restated and pinned to committed known answers, compiled for the host —
+ * instead of the machine's libm, for a machine whose libm is another one (oracle/binding.py decides; the default build
+ * calls the host's libm, which is what the reference compiled here calls).  The set-up constants' atan / tan / asin
+ * (src/sourceMod.f90:177-180, src/imageMod.f90:41) stay the host's in either build: the product's host side forms the
+ * same constants with the same library. */
+double ortp_sin(double), ortp_cos(double), ortp_log(double), ortp_atan2(double, double), ortp_acos(double);
+void ortp_sincos(double, double *, double *);
+#define sin ortp_sin
+#define cos ortp_cos
+#define sincos ortp_sincos
+#define log ortp_log
+#define atan2 ortp_atan2
+#define acos ortp_acos
+int orc_pinned_libm(void) { return 1; }
+#else
+int orc_pinned_libm(void) { return 0; }
+#endif
 #ifdef _OPENMP
 #include <omp.h>
 #endif

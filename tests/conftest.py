@@ -135,3 +135,15 @@ def make_system(name: str, **over):
 @pytest.fixture(scope="session", params=list(CONFIGS))
 def config_name(request):
     return request.param
+
+
+def pytest_report_header(config):
+    """Which libm the session's oracle is built on (oracle/binding.py: the host's where it is glibc 2.35's — the library
+    the device code reproduces — else the pinned build on csrc/ort_libm.h compiled for the host)."""
+    try:
+        from oracle.binding import host_libm_mismatches, oracle_libm
+        bad = host_libm_mismatches()
+        return (f"oracle libm: {oracle_libm()}" + (f" (host libm differs from glibc 2.35 in {bad})" if bad else
+                                                   " (host libm == glibc 2.35 x86-64 FMA variants: oracle == oracle/_ref == device)"))
+    except Exception as e:                       # the header never fails a session
+        return f"oracle libm: unknown ({e!r})"

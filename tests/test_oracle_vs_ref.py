@@ -20,7 +20,7 @@ def test_oracle_equals_reference_bit_for_bit(name):
     settings, osys = make_system(name)
     res = res_dir_with_image(resource_dir()) if needs_extended_res(settings) else resource_dir()
     ref = Reference(settings, res)
-    orc = Oracle(osys)
+    orc = Oracle(osys, libm="host")      # against oracle/_ref, which calls the host's libm
     n = min(settings.nphotons, 30000)
     rng = np.random.default_rng(sum(map(ord, name)))
     u = rng.random((160, n))
@@ -61,7 +61,7 @@ def test_isors_and_bottle_backward_equal_the_reference(bottle, ring):
     n = 20000
     rng = np.random.default_rng(3)
     u = isors_safe_uniforms(rng.random((24, n)), rng)
-    a = Oracle(osys, source_override=over).trace_rays(1, n, u=u)
+    a = Oracle(osys, source_override=over, libm="host").trace_rays(1, n, u=u)
     b = Reference(s, resource_dir(), source_override=over).trace_rays(1, n, u=u)
     assert np.array_equal(a["emitted"], b["emitted"])
     assert np.array_equal(a["pos_dir"], b["pos_dir"])
@@ -74,7 +74,7 @@ def test_isors_reflecting_rays_end_where_the_reference_aborts():
     (sourceMod.f90:216-218); the oracle ends exactly those rays as ORC_NO_INTERSECTION after
     rang + one draw, and counts them as lost."""
     _, osys = make_system("small_isors")
-    orc = Oracle(osys)
+    orc = Oracle(osys, libm="host")      # against oracle/_ref, which calls the host's libm
     n = 50000
     r = orc.trace_rays(1, n, seed=123456789)
     gone = r["status"] == 6
@@ -102,7 +102,7 @@ def test_oracle_equals_reference_on_random_systems(seed):
     settings, res = random_system(seed)
     osys = OpticalSystem.from_settings(settings, res)
     ref = Reference(settings, res)
-    orc = Oracle(osys)
+    orc = Oracle(osys, libm="host")      # against oracle/_ref, which calls the host's libm
     c = ref.constants()               # the host model derives the same run constants from these files
     assert osys.cos_theta_max == c[33] and osys.r1 == c[34] and osys.r2 == c[35]
     assert osys.img_plane == c[36] and osys.na_angle == c[39] and osys.bin_width == c[40]
