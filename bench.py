@@ -677,7 +677,7 @@ def main() -> int:
         from opticalraytrace_amd.sweeps import lens_experiment_rates
         tracer.close()
         out["sweep"] = {"1e6": lens_experiment_rates(1_000_000, local_rank, process_samples=3),
-                        "1e9": lens_experiment_rates(1_000_000_000, local_rank, process_samples=2)}
+                        "1e9": lens_experiment_rates(1_000_000_000, local_rank, process_samples=2, repeats=1)}
         if cpu is not None and cpu.get("reference_program"):
             out["sweep"]["reference_program"] = cpu["reference_program"]
     if os.environ.get("ORT_BENCH_DUMP_KERNEL_MS"):               # development: the per-launch series

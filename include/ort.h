@@ -211,6 +211,25 @@ int ort_flush(ort_ctx *ctx);
  * Asynchronous on the context's stream. */
 int ort_trace(ort_ctx *ctx, int phase, uint64_t first_ray, uint64_t n_rays, uint64_t seed);
 
+/* A BATCH of simulations in few launches — runner.py's experiment loops (:113-133 -s, :136-155 -p, :158-186 -i, :189-208 -o,
+ * :232-261 -l: 75 systems), which the reference runs as one `./install.sh -n 32 -f <settings>` process per settings file
+ * (runner.py:26-47).  Loop `phase` over the rays [first_ray, first_ray + n_rays) of EACH of the n systems, simulation i into
+ * its own accumulators: d_images[i] (device, int32 [ORT_IMAGE_BINS]; NULL — or d_images itself NULL — = this simulation's
+ * image is not wanted, `make_images = .false.`, src/main.f90:183: its hits are counted, not binned) and d_counters[i]
+ * (device, uint64 [ORT_NUM_COUNTERS], required).  The accumulators are added to, not zeroed.  Means exactly, for every i:
+ *     ort_set_system(ctx, &systems[i]); ort_attach_buffers(ctx, d_images[i], d_counters[i]); ort_trace(ctx, phase, ...)
+ * — and that is bit for bit what it accumulates — but the simulations whose list is a surface program (every set-up of
+ * runner.py's loops with the ring, point, crs or isors source, clear media) share MULTI-SYSTEM LAUNCHES: one kernel launch
+ * per program over all of them (workgroup -> simulation, ray range), their systems and arguments staged in one copy, and
+ * one literal re-run launch for what they deferred; at 1e6 rays a simulation alone is ~40 us of work inside ~25 us of ramp
+ * and drain.  Everything else (a list no program matches, scattering media, another precision or kernel variant, more than
+ * 2^24 rays — such a simulation fills the chip by itself) is traced one by one inside the call.  The context's staged
+ * system, attached buffers and own accumulators are as before when it returns.  The `image` light source (one table per
+ * context, ort_set_image_source) is refused with ORT_E_INVALID.  Asynchronous on the context's stream; complete results
+ * (deferred rays included) need no further call than waiting for the stream. */
+int ort_trace_batch(ort_ctx *ctx, int n, const ort_system *systems, int phase, uint64_t first_ray, uint64_t n_rays,
+                    uint64_t seed, void *const *d_images, void *const *d_counters);
+
 /* Same loop with the ray bundle resident in HBM (device pointer, SoA fp64
  * [6][n]) instead of emitted in-kernel: replaces the loop body after the emitter
  * call (src/main.f90:104-108, :145-161).  Ray i consumes draws

@@ -150,6 +150,14 @@ KERNEL_SOURCES = tuple(u + ".hip" for u in KERNEL_UNITS) + (
     "ort_trace.h", "ort_scatter.h", "ort_launch.h", "ort_k_program.h")
 
 
+def pack_systems(systems):
+    """A contiguous array of ort_system records (ort_trace_batch) from OpticalSystem objects."""
+    arr = (OrtSystem * len(systems))()
+    for i, osys in enumerate(systems):
+        arr[i] = pack_system(osys)
+    return arr
+
+
 def source_build_id() -> str:
     """What ort_build_id() of a library built from the sources in this tree returns
     (csrc/Makefile BUILD_ID: SHA-256 over the kernel sources, first 16 hex digits)."""
@@ -208,6 +216,7 @@ def load_library(path: Optional[str] = None, no_torch: Optional[bool] = None) ->
         "ort_flush": (C.c_int, [vp]),
         "ort_set_image_source": (C.c_int, [vp, C.POINTER(C.c_int64)]),
         "ort_trace": (C.c_int, [vp, i32, u64, u64, u64]),
+        "ort_trace_batch": (C.c_int, [vp, i32, C.POINTER(OrtSystem), i32, u64, u64, u64, C.POINTER(vp), C.POINTER(vp)]),
         "ort_emit": (C.c_int, [vp, i32, u64, u64, u64, vp]),
         "ort_trace_resident": (C.c_int, [vp, i32, u64, u64, u64, i32, vp]),
         "ort_trace_rays": (C.c_int, [vp, i32, i64, _DP, i32, _DP, i32, u64, u64,
@@ -246,7 +255,7 @@ def torch_safe() -> bool:
 
 
 EXPORTED_SYMBOLS = ["ort_abi_version", "ort_build_id", "ort_allreduce", "ort_allreduce_ranks", "ort_comm_destroy", "ort_last_kernel_name", "ort_last_error", "ort_device_count", "ort_create",
-                    "ort_destroy", "ort_set_system", "ort_set_image_source", "ort_reset", "ort_flush", "ort_trace", "ort_emit",
+                    "ort_destroy", "ort_set_system", "ort_set_image_source", "ort_reset", "ort_flush", "ort_trace", "ort_trace_batch", "ort_emit",
                     "ort_trace_resident", "ort_trace_rays", "ort_trace_paths", "ort_read", "ort_attach_buffers",
                     "ort_device_image",
                     "ort_device_counters", "ort_synchronize", "ort_work_counters", "ort_reserve", "ort_last_kernel_ms",
@@ -325,6 +334,16 @@ class Context:
 
     def trace(self, phase: int, first_ray: int, n_rays: int, seed: int) -> None:
         _check(self.lib, self.lib.ort_trace(self._h, phase, first_ray, n_rays, seed), "ort_trace")
+
+    def trace_batch(self, packed, phase: int, first_ray: int, n_rays: int, seed: int, image_ptrs, counter_ptrs) -> None:
+        """ort_trace_batch: loop `phase` of every system of `packed` (pack_systems) over the same ray range, simulation i into
+        the device accumulators image_ptrs[i] (0 / None: no image wanted) and counter_ptrs[i] — the simulations whose lists are
+        surface programs share multi-system launches (include/ort.h).  Asynchronous."""
+        n = len(packed)
+        vp = C.c_void_p
+        imgs = (vp * n)(*[vp(int(p)) if p else vp(None) for p in image_ptrs])
+        cnts = (vp * n)(*[vp(int(p)) for p in counter_ptrs])
+        _check(self.lib, self.lib.ort_trace_batch(self._h, n, packed, phase, first_ray, n_rays, seed, imgs, cnts), "ort_trace_batch")
 
     def emit(self, phase: int, first_ray: int, n_rays: int, seed: int, d_pos_dir: int) -> None:
         _check(self.lib, self.lib.ort_emit(self._h, phase, first_ray, n_rays, seed,

@@ -337,6 +337,20 @@ struct ort_ctx {
     float ring_cullf;
     uint32_t ring_cull_word, ring_cull_wordf;      // TraceArgs.cull_word / cull_wordf (cull_word_of)
     uint64_t ring_cull_wide;                       // TraceArgs.cull_wide (cull_wide_of)
+    // multi-system launches (ort_trace_batch): per-simulation systems and arguments (device tables + pinned staging), the
+    // simulations' re-run lists (bat_list_stride entries each) and control words, a scratch image for the simulations that
+    // want none when they are traced one by one, the event that guards the staging buffers
+    DevSystem *d_bat_sys, *h_bat_sys;
+    TraceArgs *d_bat_args, *h_bat_args;
+    int bat_cap;
+    uint32_t *d_bat_list;
+    uint64_t bat_list_cap;
+    unsigned int *d_bat_ctl;
+    int bat_ctl_cap;
+    int32_t *d_bat_scratch;
+    hipEvent_t bat_ev;
+    bool bat_ev_set;
+    ort_system cur_sys;          // host copy of the staged system (ort_trace_batch restages it behind simulations it runs one by one)
     // development (ort_debug_set_exp, ort_k_exp.hip): experiment on the fused point program, 0 = none; the pulled variants'
     // static share of a launch (percent), pull bounds (batches of 64 rays), workgroups per CU; their work heads: a ring of
     // kPullSets sets of eight 128-byte lines, zero when handed to a launch
@@ -457,14 +471,46 @@ static bool matches_behind(const ort_system *sys, int k0)
     return true;
 }
 
+static bool list_scatters(const ort_system *sys, int p)
+{
+    for (int k = 0; k < sys->n_surfaces[p]; ++k)
+        if (sys->surfaces[p][k].flags & ORT_F_SCATTER) return true;
+    return false;
+}
+
+// the surface program the list of `phase` (1 / 2) matches field for field, PROG_GENERIC if none
+static int program_of(const ort_system *sys, int phase)
+{
+    if (getenv("ORT_DEV_NO_PROGRAMS")) return PROG_GENERIC;                        // development knob (A/B)
+    int prog = PROG_GENERIC;
+#define ORT_MATCH(P) if (Prog<P>::phase == phase && matches<P>(sys)) prog = P;
+    ORT_PROGRAMS(ORT_MATCH)
+    ORT_SOURCE_PROGRAMS(ORT_MATCH)
+#undef ORT_MATCH
+    return prog;
+}
+
+// segment 0 of the ring programs: the borders of the cull in the three arithmetics' draw words
+struct RingCull {
+    double cull; float cullf;
+    uint32_t word, wordf;
+    uint64_t wide;
+};
+static RingCull ring_cull_of(const ort_system *sys, int prog_ring)
+{
+    RingCull r;
+    ring_cull_threshold(sys, prog_ring != PROG_GENERIC && sys->emitter[0] == ORT_EMIT_RING, &r.cull, &r.cullf);
+    r.word = cull_word_of<double>(sys->ring_lens_r2, r.cull);
+    r.wordf = cull_word_of<float>((float)sys->ring_lens_r2, r.cullf);
+    r.wide = cull_wide_of(sys->ring_lens_r2, r.cull);
+    return r;
+}
+
 static void note_system(ort_ctx *c, const ort_system *sys)
 {
+    c->cur_sys = *sys;
     c->emitter[0] = sys->emitter[0]; c->emitter[1] = sys->emitter[1];
-    for (int p = 0; p < 2; ++p) {
-        c->scatter[p] = false;
-        for (int k = 0; k < sys->n_surfaces[p]; ++k)
-            if (sys->surfaces[p][k].flags & ORT_F_SCATTER) c->scatter[p] = true;
-    }
+    for (int p = 0; p < 2; ++p) c->scatter[p] = list_scatters(sys, p);
     // the scattering pipeline takes the surfaces up to the last scattering one: they must be the walls of one
     // bottle (one kind — circular or elliptical cylinder —, no aperture stop) with something left behind them
     for (int p = 0; p < 2; ++p) {
@@ -480,21 +526,28 @@ static void note_system(ort_ctx *c, const ort_system *sys)
         c->cont_prog[p] = false;
     }
     c->cont_prog[1] = c->scat_k0[1] > 0 && matches_behind<PROG_POINT_WALKED>(sys, c->scat_k0[1]) && !getenv("ORT_DEV_NO_PROGRAMS");
-    c->prog[0] = c->prog[1] = PROG_GENERIC;
-#define ORT_MATCH(P) if (matches<P>(sys)) c->prog[Prog<P>::phase - 1] = P;
-    ORT_PROGRAMS(ORT_MATCH)
-    ORT_SOURCE_PROGRAMS(ORT_MATCH)
-#undef ORT_MATCH
-    if (getenv("ORT_DEV_NO_PROGRAMS")) c->prog[0] = c->prog[1] = PROG_GENERIC;      // development knob (A/B)
-    ring_cull_threshold(sys, c->prog[0] != PROG_GENERIC && sys->emitter[0] == ORT_EMIT_RING, &c->ring_cull, &c->ring_cullf);
-    c->ring_cull_word = cull_word_of<double>(sys->ring_lens_r2, c->ring_cull);
-    c->ring_cull_wordf = cull_word_of<float>((float)sys->ring_lens_r2, c->ring_cullf);
-    c->ring_cull_wide = cull_wide_of(sys->ring_lens_r2, c->ring_cull);
+    c->prog[0] = program_of(sys, 1); c->prog[1] = program_of(sys, 2);
+    const RingCull rc = ring_cull_of(sys, c->prog[0]);
+    c->ring_cull = rc.cull; c->ring_cullf = rc.cullf;
+    c->ring_cull_word = rc.word; c->ring_cull_wordf = rc.wordf; c->ring_cull_wide = rc.wide;
 }
 
 // system + derived per-surface constants -> the next device slot, asynchronously (the staging copy is the
 // slot's own pinned host buffer).  A slot is reused kSysSlots systems later; by then the event recorded when it
 // was retired has normally long passed.
+// what a context keeps of a system on the device: the caller's record, the derived per-surface constants, both once more in fp32
+static void fill_dev_system(DevSystem &h, const ort_system *sys)
+{
+    h.sys = *sys;
+    for (int p = 0; p < 2; ++p)
+        for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.aux[p][k] = make_aux<double>(sys->surfaces[p][k]);
+    axial_start<double>(h.aux[1][0], sys->surfaces[1][0], sys->point_offset);           // OPT_AXIAL_START (point programs, step 0)
+    convert_system(h.sysf, *sys);
+    for (int p = 0; p < 2; ++p)
+        for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.auxf[p][k] = make_aux<float>(h.sysf.surfaces[p][k]);
+    axial_start<float>(h.auxf[1][0], h.sysf.surfaces[1][0], h.sysf.point_offset);
+}
+
 static int upload_system(ort_ctx *c, const ort_system *sys, bool first = false)
 {
     int slot = 0;
@@ -505,14 +558,7 @@ static int upload_system(ort_ctx *c, const ort_system *sys, bool first = false)
         if (c->sys_ev_set[slot]) HIP_TRY(hipEventSynchronize(c->sys_ev[slot]));
     }
     DevSystem &h = c->h_sys_ring[slot];
-    h.sys = *sys;
-    for (int p = 0; p < 2; ++p)
-        for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.aux[p][k] = make_aux<double>(sys->surfaces[p][k]);
-    axial_start<double>(h.aux[1][0], sys->surfaces[1][0], sys->point_offset);           // OPT_AXIAL_START (point programs, step 0)
-    convert_system(h.sysf, *sys);
-    for (int p = 0; p < 2; ++p)
-        for (int k = 0; k < ORT_MAX_SURFACES; ++k) h.auxf[p][k] = make_aux<float>(h.sysf.surfaces[p][k]);
-    axial_start<float>(h.auxf[1][0], h.sysf.surfaces[1][0], h.sysf.point_offset);
+    fill_dev_system(h, sys);
     c->sys_slot = slot;
     c->d_sys = c->d_sys_ring + slot;
     HIP_TRY(hipMemcpyAsync(c->d_sys, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
@@ -667,6 +713,9 @@ int ort_destroy(ort_ctx *c)
     (void)hipFree(c->d_scat_ctl);
     (void)hipFree(c->d_hit_log); (void)hipFree(c->d_hit_dir); (void)hipFree(c->d_slabs);
     (void)hipFree(c->d_pull_ctl);
+    (void)hipFree(c->d_bat_sys); (void)hipHostFree(c->h_bat_sys); (void)hipFree(c->d_bat_args); (void)hipHostFree(c->h_bat_args);
+    (void)hipFree(c->d_bat_list); (void)hipFree(c->d_bat_ctl); (void)hipFree(c->d_bat_scratch);
+    if (c->bat_ev) (void)hipEventDestroy(c->bat_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ORT_OK;
@@ -1064,6 +1113,177 @@ int ort_trace(ort_ctx *c, int phase, uint64_t first_ray, uint64_t n_rays, uint64
     a.first_ray = first_ray; a.n_rays = n_rays; a.rng_base = stream_base(seed, phase);
     a.phase = phase;
     return launch_trace(c, MODE_FUSED, a, 0);
+}
+
+// ---- multi-system launches ------------------------------------------------------------------------------------------
+// A simulation of the batch goes into a multi-system launch when the context runs the default exact path (fp64, queued,
+// filtered, ORT-RNG-v2, default emitters' arithmetic), its list of `phase` is a surface program ort_k_batch.hip holds, clear
+// media, not the image source (one table per context) and at most kBatchRaysMax rays (a simulation's re-run list holds
+// every ray of it).  Everything else is traced one by one through ort_set_system / ort_attach_buffers / ort_trace, which is
+// also what the batch means.
+constexpr uint64_t kBatchRaysMax = 1ull << 24;        // beyond it a simulation fills the chip by itself
+constexpr uint64_t kBatchListMax = 1ull << 28;        // re-run list entries of one multi-system launch (1 GB)
+constexpr int kBatchTargetBlocks = 256 * 6 * 4;       // workgroups of a launch: four rounds of six per CU
+constexpr int kBatchRedoBlocks = 4;                   // workgroups per simulation of the batched re-run (normally they read a zero count and return)
+
+static int reserve_batch(ort_ctx *c, int n_sys, uint64_t list_stride)
+{
+    if (n_sys > c->bat_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_bat_sys); (void)hipHostFree(c->h_bat_sys); (void)hipFree(c->d_bat_args); (void)hipHostFree(c->h_bat_args);
+        c->d_bat_sys = c->h_bat_sys = nullptr; c->d_bat_args = c->h_bat_args = nullptr; c->bat_cap = 0;
+        const int cap = n_sys < 64 ? 64 : n_sys;
+        HIP_TRY(hipMalloc(&c->d_bat_sys, (size_t)cap * sizeof(DevSystem)));
+        HIP_TRY(hipHostMalloc(&c->h_bat_sys, (size_t)cap * sizeof(DevSystem), hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&c->d_bat_args, (size_t)cap * sizeof(TraceArgs)));
+        HIP_TRY(hipHostMalloc(&c->h_bat_args, (size_t)cap * sizeof(TraceArgs), hipHostMallocDefault));
+        c->bat_cap = cap;
+    }
+    if (n_sys > c->bat_ctl_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_bat_ctl); c->d_bat_ctl = nullptr; c->bat_ctl_cap = 0;
+        const int cap = n_sys < 64 ? 64 : n_sys;
+        HIP_TRY(hipMalloc(&c->d_bat_ctl, (size_t)cap * 2 * sizeof(unsigned int)));
+        HIP_TRY(hipMemsetAsync(c->d_bat_ctl, 0, (size_t)cap * 2 * sizeof(unsigned int), c->stream));   // the re-run leaves them zero
+        c->bat_ctl_cap = cap;
+    }
+    const uint64_t want = (uint64_t)n_sys * list_stride;
+    if (want > c->bat_list_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_bat_list); c->d_bat_list = nullptr; c->bat_list_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_bat_list, want * sizeof(uint32_t)));
+        c->bat_list_cap = want;
+    }
+    if (!c->bat_ev) HIP_TRY(hipEventCreateWithFlags(&c->bat_ev, hipEventDisableTiming));
+    return ORT_OK;
+}
+
+int ort_trace_batch(ort_ctx *c, int n, const ort_system *systems, int phase, uint64_t first_ray, uint64_t n_rays, uint64_t seed,
+                    void *const *d_images, void *const *d_counters)
+{
+    if (!c) return fail(ORT_E_INVALID, "ctx is NULL");
+    if (phase != 1 && phase != 2) return fail(ORT_E_INVALID, "phase must be 1 (ring) or 2 (point)");
+    if (n < 0 || (n > 0 && (!systems || !d_counters))) return fail(ORT_E_INVALID, "bad batch: n < 0, or systems / d_counters NULL");
+    if (first_ray > ORT_MAX_RAY_INDEX || n_rays > ORT_MAX_RAY_INDEX - first_ray)
+        return fail(ORT_E_INVALID, "ray indices reach beyond 2^40 (ORT_MAX_RAY_INDEX): the keyed draw counter holds 40 bits of ray index");
+    for (int i = 0; i < n; ++i) {
+        const int rc = check_system(&systems[i]);
+        if (rc) { char msg[sizeof g_err]; snprintf(msg, sizeof msg, "system %d of the batch: %.400s", i, g_err); return fail(rc, msg); }
+        if (!d_counters[i]) return fail(ORT_E_INVALID, "d_counters[i] is NULL: every simulation of a batch has counters of its own");
+        if (systems[i].emitter[phase - 1] == ORT_EMIT_IMAGE)
+            return fail(ORT_E_INVALID, "the image source holds ONE table per context (ort_set_image_source): trace such simulations with ort_set_system + ort_trace");
+    }
+    if (n == 0 || n_rays == 0) return ORT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int p = phase - 1;
+    const bool ctx_ok = c->precision == 0 && (c->variant & ~4) == 1 && n_rays <= kBatchRaysMax && !c->exp_which;
+    // the program of every simulation (PROG_GENERIC: it is traced one by one), batched ones in the order of their programs
+    int *prog = (int *)malloc((size_t)n * 2 * sizeof(int)), *order = prog + n;
+    if (!prog) return fail(ORT_E_NOMEM, "host allocation failed");
+    int nb = 0;
+    for (int i = 0; i < n; ++i) {
+        prog[i] = (ctx_ok && !list_scatters(&systems[i], p)) ? program_of(&systems[i], phase) : PROG_GENERIC;
+        if (!batch_has_program(prog[i])) prog[i] = PROG_GENERIC;
+        if (prog[i] != PROG_GENERIC) order[nb++] = i;
+    }
+    for (int a = 1; a < nb; ++a) {                                        // stable insertion sort by program (n is a few hundred at most)
+        const int v = order[a];
+        int b = a;
+        while (b > 0 && prog[order[b - 1]] > prog[v]) { order[b] = order[b - 1]; --b; }
+        order[b] = v;
+    }
+    int rc = ORT_OK;
+#define BATCH_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(ORT_E_HIP, #expr, e_); goto done; } } while (0)
+    if (c->timing) BATCH_TRY(hipEventRecord(c->ev[1][0], c->stream));
+    if (nb > 0) {
+        const uint64_t stride = (n_rays + 63) & ~63ull;                   // a simulation's re-run list: every ray of it can be deferred
+        const int per_launch = (int)((kBatchListMax / stride) < (uint64_t)nb ? (kBatchListMax / stride) : (uint64_t)nb);
+        const uint64_t rng_base = stream_base(seed, phase);
+        for (int at = 0; at < nb; at += per_launch) {
+            const int m = nb - at < per_launch ? nb - at : per_launch;
+            rc = reserve_batch(c, m, stride);
+            if (rc) goto done;
+            if (c->bat_ev_set) BATCH_TRY(hipEventSynchronize(c->bat_ev));          // the staging buffers' last copies have been read
+            for (int j = 0; j < m; ++j) {
+                const int i = order[at + j];
+                const ort_system *sys = &systems[i];
+                fill_dev_system(c->h_bat_sys[j], sys);
+                DevSystem *d = c->d_bat_sys + j;
+                TraceArgs &a = c->h_bat_args[j];
+                memset(&a, 0, sizeof a);
+                a.sys = &d->sys; a.aux = d->aux[p]; a.sysf = &d->sysf; a.auxf = d->auxf[p];
+                a.image = (int32_t *)(d_images ? d_images[i] : nullptr);      // NULL: the hit is counted, not binned
+                a.replicas = nullptr;
+                a.counters = (unsigned long long *)d_counters[i];
+                a.work = c->d_work;
+                a.first_ray = first_ray; a.n_rays = n_rays; a.rng_base = rng_base;
+                a.phase = phase; a.in_stride = n_rays;
+                a.redo_list = c->d_bat_list + (uint64_t)j * stride;
+                a.redo_ctl = c->d_bat_ctl + 2 * j;
+                const RingCull cull = phase == 1 ? ring_cull_of(sys, prog[i]) : RingCull{HUGE_VAL, HUGE_VALF, 0xffffffffu, 0xffffffffu, ~0ull};
+                a.cull_word = cull.word; a.cull_wordf = cull.wordf; a.cull_wide = cull.wide;
+            }
+            // equal, 64-aligned ranges over bx workgroups per simulation; every launch aims at kBatchTargetBlocks workgroups
+            for (int g0 = 0; g0 < m;) {
+                int g1 = g0;
+                while (g1 < m && prog[order[at + g1]] == prog[order[at + g0]]) ++g1;
+                const int cnt = g1 - g0;
+                const uint64_t batches = (n_rays + 63) / 64, blocks_most = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
+                uint64_t bx = ((uint64_t)kBatchTargetBlocks + cnt - 1) / cnt;
+                if (bx > blocks_most) bx = blocks_most;
+                if (bx > (uint64_t)kMaxBlocks) bx = kMaxBlocks;
+                if (bx < 1) bx = 1;
+                const uint64_t nwaves = bx * kWavesPerBlock;
+                for (int j = g0; j < g1; ++j) {
+                    TraceArgs &a = c->h_bat_args[j];
+                    a.head_blocks = (uint32_t)bx; a.head_rays = n_rays;
+                    a.head_chunk = (((n_rays + nwaves - 1) / nwaves) + 63) & ~63ull;
+                    a.tail_chunk = 64;
+                }
+                g0 = g1;
+            }
+            BATCH_TRY(hipMemcpyAsync(c->d_bat_sys, c->h_bat_sys, (size_t)m * sizeof(DevSystem), hipMemcpyHostToDevice, c->stream));
+            BATCH_TRY(hipMemcpyAsync(c->d_bat_args, c->h_bat_args, (size_t)m * sizeof(TraceArgs), hipMemcpyHostToDevice, c->stream));
+            BATCH_TRY(hipEventRecord(c->bat_ev, c->stream));
+            c->bat_ev_set = true;
+            for (int g0 = 0; g0 < m;) {
+                int g1 = g0;
+                while (g1 < m && prog[order[at + g1]] == prog[order[at + g0]]) ++g1;
+                const LaunchCfg cfg = {(int)c->h_bat_args[g0].head_blocks, c->stream, nullptr, nullptr};
+                const char *name = launch_batch(prog[order[at + g0]], cfg, g1 - g0, c->d_bat_args + g0);
+                BATCH_TRY(hipGetLastError());
+                snprintf(c->last_kernel, sizeof c->last_kernel, "%s x %d", name ? name : "(none)", g1 - g0);
+                g0 = g1;
+            }
+            const LaunchCfg redo = {kBatchRedoBlocks, c->stream, nullptr, nullptr};
+            (void)launch_batch_rerun(redo, m, c->d_bat_args);
+            BATCH_TRY(hipGetLastError());
+        }
+    }
+    if (nb < n) {
+        // the others one by one, as the batch is defined; then the context's own system and accumulators again
+        const ort_system saved = c->cur_sys;
+        int32_t *img = c->d_image == c->own_image ? nullptr : c->d_image;
+        unsigned long long *cnt = c->d_counters == c->own_counters ? nullptr : c->d_counters;
+        for (int i = 0; i < n && !rc; ++i) {
+            if (prog[i] != PROG_GENERIC) continue;
+            void *image = d_images ? d_images[i] : nullptr;
+            if (!image) {
+                if (!c->d_bat_scratch) BATCH_TRY(hipMalloc(&c->d_bat_scratch, ORT_IMAGE_BINS * sizeof(int32_t)));
+                image = c->d_bat_scratch;            // (nobody reads it: whatever it holds)
+            }
+            rc = ort_set_system(c, &systems[i]);
+            if (!rc) rc = ort_attach_buffers(c, image, d_counters[i]);
+            if (!rc) rc = ort_trace(c, phase, first_ray, n_rays, seed);
+        }
+        if (!rc) rc = ort_set_system(c, &saved);
+        if (!rc) rc = ort_attach_buffers(c, img, cnt);
+    }
+    if (!rc && c->timing) { BATCH_TRY(hipEventRecord(c->ev[1][1], c->stream)); c->ev_valid[1] = true; }
+done:
+#undef BATCH_TRY
+    free(prog);
+    return rc;
 }
 
 int ort_trace_resident(ort_ctx *c, int phase, uint64_t first_ray, uint64_t n_rays, uint64_t seed,

@@ -37,6 +37,12 @@ const char *launch_generic_fast(const GenericReq &q, const LaunchCfg &cfg, const
 const char *launch_scatter_front(bool anysrc, bool wide, const LaunchCfg &cfg, const TraceArgs &a);
 const char *launch_continue(bool program, bool wide, const LaunchCfg &cfg, const TraceArgs &a);
 
+// multi-system launches (ort_k_batch.hip): `d_batch` = n_sys TraceArgs on the device, one per simulation; cfg.grid = workgroups
+// per simulation.  batch_has_program: does the unit hold trace_batch_kernel<prog>?
+bool batch_has_program(int prog);
+const char *launch_batch(int prog, const LaunchCfg &cfg, int n_sys, const TraceArgs *d_batch);
+const char *launch_batch_rerun(const LaunchCfg &cfg, int n_sys, const TraceArgs *d_batch);
+
 // development experiments on the fused point program (ort_k_exp.hip; ort_debug_set_exp)
 const char *launch_exp(int which, const LaunchCfg &cfg, const TraceArgs &a);
 

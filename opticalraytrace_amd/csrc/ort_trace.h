@@ -557,8 +557,8 @@ __device__ inline void walk(const Sys &S, const Surf *surf, const SurfAuxT<T> *a
 }
 
 // FILT: filtered predicates (ort_device.h); false = every predicate evaluated literally.
-template <int MODE, bool FILT, class T, bool ANYSRC>
-__global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs a)
+template <int MODE, bool FILT, class T, bool ANYSRC, bool BATCH = false>
+__device__ __forceinline__ void trace_body(const TraceArgs &a)
 {
     __shared__ typename SysTypes<T>::Sys S;
     __shared__ unsigned int blk[4];       // lost, isect, binned, help3
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             isect += (unsigned)nis;
             if (st == ORT_ST_BINNED) {
                 binned++;
-                bin_hit(layer, xp, yp, a.replicas != nullptr);
+                if (!BATCH || a.image != nullptr) bin_hit(layer, xp, yp, a.replicas != nullptr);
             } else if (st >= ORT_ST_LOST_BOTTLE) {
                 lost++;                                                       // optics_system.f90:32,42; main.f90:151
                 if (st == ORT_ST_HELP3) help3++;
@@ -694,6 +694,12 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
             a.redo_ctl[1] = 0;
         }
     }
+}
+
+template <int MODE, bool FILT, class T, bool ANYSRC>
+__global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs a)
+{
+    trace_body<MODE, FILT, T, ANYSRC, false>(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -734,9 +740,11 @@ constexpr int RNG_STRICT = 1, RNG_WIDE = 2;
 // lgkmcnt, independent of the vector memory queue).  NOBIN: the image atomic is left out (what the hits cost; the upper
 // bound of what logging them instead could gain).
 constexpr int SCHED_STATIC = 0, SCHED_PULL_V = 1, SCHED_PULL_S = 2;
+// BATCH (trace_batch_kernel below): the arguments are ONE simulation's of a multi-system launch — hits go straight into that
+// simulation's image (no replicas), or nowhere when it wants none (image == nullptr: the hit is counted, not binned)
 template <int MODE, bool FILT, bool ANYSRC, class T, int PROG = PROG_GENERIC, bool SCAT = ANYSRC, int RNG = 0, int SCHED = SCHED_STATIC,
-          bool NOBIN = false>
-__global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) void trace_queue_kernel(TraceArgs a)
+          bool NOBIN = false, bool BATCH = false>
+__device__ __forceinline__ void trace_queue_body(const TraceArgs &a)
 {
     static_assert(SCHED == SCHED_STATIC || (MODE == MODE_FUSED && PROG != PROG_GENERIC), "pulled ranges: fused program kernels");
     static_assert(PROG == PROG_GENERIC || (!ANYSRC && !SCAT && FILT), "programs exist for the lean kernels only (filtered forms)");
@@ -856,7 +864,7 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
         isect += (unsigned)nis;
         if (st == ORT_ST_BINNED) {
             binned++;
-            if constexpr (!NOBIN) { if (!logging) bin_hit(layer, xp, yp, a.replicas != nullptr); }
+            if constexpr (!NOBIN) { if (!logging && (!BATCH || a.image != nullptr)) bin_hit(layer, xp, yp, a.replicas != nullptr); }
         } else if (st >= ORT_ST_LOST_BOTTLE) {
             lost++;                                                          // optics_system.f90:32,42; main.f90:151
             if (st == ORT_ST_HELP3) help3++;
@@ -1109,6 +1117,36 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
     if (threadIdx.x < 4 && blk[threadIdx.x])
         atomicAdd(&a.counters[2 * threadIdx.x + (a.phase - 1)], (unsigned long long)blk[threadIdx.x]);
     if (PRE && threadIdx.x == 4 && blk[4]) atomicAdd(&a.work[ORT_W_CULLED], (unsigned long long)blk[4]);
+}
+
+template <int MODE, bool FILT, bool ANYSRC, class T, int PROG = PROG_GENERIC, bool SCAT = ANYSRC, int RNG = 0, int SCHED = SCHED_STATIC,
+          bool NOBIN = false>
+__global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) void trace_queue_kernel(TraceArgs a)
+{
+    trace_queue_body<MODE, FILT, ANYSRC, T, PROG, SCAT, RNG, SCHED, NOBIN, false>(a);
+}
+
+// ---------------------------------------------------------------------------
+// Multi-system launches (runner.py:113-261 runs one PROCESS per settings file): ONE launch traces one loop of
+// MANY simulations that share a surface program.  gridDim.y = simulations of the launch, blockIdx.y -> that simulation's
+// TraceArgs in a device table (its own staged system, image, counters, re-run list, ray ranges over blockIdx.x), read through
+// scalar loads like a kernel argument; everything per ray is the fused program kernel's (the same body).  At 1e6 rays a
+// simulation is ~40 us of work inside ~25 us of ramp and drain of a launch of its own: batched, the chip sees one launch of
+// n x 1e6 rays.  The rays a simulation defers go to ITS list; trace_batch_rerun_kernel closes all of them in one launch.
+// ---------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) TraceArgs *batch_args_t;
+__device__ __forceinline__ void load_batch_args(TraceArgs &a, const TraceArgs *batch)
+{
+    const batch_args_t p = (batch_args_t)batch + blockIdx.y;
+    __builtin_memcpy(&a, p, sizeof(TraceArgs));
+}
+
+template <int PROG>
+__global__ __launch_bounds__(kBlock, 4) void trace_batch_kernel(const TraceArgs *batch)
+{
+    TraceArgs a;
+    load_batch_args(a, batch);
+    trace_queue_body<MODE_FUSED, true, false, double, PROG, false, 0, SCHED_STATIC, false, true>(a);
 }
 
 }  // namespace ortk

@@ -63,10 +63,11 @@ class Sweep:
 
     def __init__(self, nphotons: int = 1_000_000_000, res_dir: Optional[str] = None,
                  data_dir: str = "data", device: int = 0, verbose: bool = False,
-                 settings_dir: Optional[str] = None, batched: bool = True):
+                 settings_dir: Optional[str] = None, batched: bool = True, multi_system: bool = True):
         self.nphotons, self.res_dir, self.data_dir = nphotons, res_dir or resource_dir(), data_dir
         self.device, self.verbose, self.settings_dir = device, verbose, settings_dir
         self.batched = batched
+        self.multi_system = multi_system     # a batch goes through ort_trace_batch (multi-system launches); False: queued one after the other
         self.tracer: Optional[RayTracer] = None
         self.results: List[Tuple[str, Settings, RunResult]] = []
         self._pending: List[Tuple[str, Settings, object]] = []     # (name, settings, the system built from them)
@@ -83,6 +84,7 @@ class Sweep:
         if self.tracer is None:
             from .system import OpticalSystem
             self.tracer = RayTracer(OpticalSystem.from_settings(s, self.res_dir), device=self.device)
+            self.tracer.multi_system_launches = self.multi_system
         return self.tracer
 
     def run(self, name: str, **over) -> Optional[RunResult]:
@@ -252,29 +254,37 @@ class Sweep:
                              L2_file=f"planoConvex-f{f2}mm.params")
 
 
-def lens_experiment_rates(nphotons: int, device: int = 0, modes=("batched", "one_by_one"), process_samples: int = 0) -> dict:
-    """Simulations per second of runner.py's lens experiment (75 systems, :232-261) on one GPU: queued as one
-    batch, one `run_settings` at a time on a reused context, and — `process_samples` simulations of it — one
-    `python -m opticalraytrace_amd <settings>` PROCESS per simulation, which is runner.py's own model (:26-47).
-    Outputs (the stats rows; the lens experiment writes no images) go to a scratch directory."""
+def lens_experiment_rates(nphotons: int, device: int = 0, modes=("batched", "queued", "one_by_one"), process_samples: int = 0, repeats: int = 3) -> dict:
+    """Simulations per second of runner.py's lens experiment (75 systems, :232-261) on one GPU: `batched` = queued as one
+    batch through ort_trace_batch (multi-system launches: one launch per surface program and loop over all 75), `queued` =
+    the same batch queued one simulation after the other on the context (asynchronous ort_set_system / ort_attach_buffers /
+    ort_trace, one wait), `one_by_one` = one `run_settings` at a time on a reused context, and — `process_samples`
+    simulations of it — one `python -m opticalraytrace_amd <settings>` PROCESS per simulation, which is runner.py's own model
+    (:26-47).  Per mode: the FIRST experiment of a fresh context (`first_call_*`: scratch allocation, the other bottles'
+    code objects, clocks coming out of idle) and the median of `repeats` more (`simulations_per_s`).  Outputs (the stats
+    rows; the lens experiment writes no images) go to a scratch directory."""
     import subprocess
     import tempfile
     import time
     out = {"experiment": "lens_experiment (runner.py:232-261): 5 doublets x 5 plano-convex lenses x 3 bottles", "nphotons": nphotons}
     with tempfile.TemporaryDirectory(prefix="ort_sweep_") as tmp:
         for mode in modes:
-            sw = Sweep(nphotons=nphotons, data_dir=os.path.join(tmp, mode), device=device, batched=(mode == "batched"))
+            sw = Sweep(nphotons=nphotons, data_dir=os.path.join(tmp, mode), device=device, batched=(mode != "one_by_one"),
+                       multi_system=(mode == "batched"))
+            times = []
             try:
                 sw.run("warm.params", light_source="point", make_images=False, data_folder="warm")   # context, code objects
                 sw.flush()
-                t0 = time.perf_counter()
-                sw.lens_experiment()
-                el = time.perf_counter() - t0
+                for _ in range(1 + max(repeats, 0)):
+                    t0 = time.perf_counter()
+                    sw.lens_experiment()
+                    times.append(time.perf_counter() - t0)
             finally:
                 sw.close()
-            n = len(sw.results) - 1
-            out[mode] = {"simulations": n, "seconds": el, "simulations_per_s": n / el,
-                         "rays_per_s": 2.0 * nphotons * n / el}
+            n = (len(sw.results) - 1) // len(times)
+            steady = sorted(times[1:])[len(times[1:]) // 2] if len(times) > 1 else times[0]
+            out[mode] = {"simulations": n, "seconds": steady, "simulations_per_s": n / steady, "rays_per_s": 2.0 * nphotons * n / steady,
+                         "first_call_seconds": times[0], "first_call_simulations_per_s": n / times[0], "all_seconds": times}
         if process_samples:
             sw = Sweep(nphotons=nphotons, data_dir=os.path.join(tmp, "p"), settings_dir=os.path.join(tmp, "settings"), batched=True)
             sw.tracer = None

@@ -139,6 +139,18 @@ class ShardedRun:
         """The batch's accumulators as numpy arrays (GPU tracer: through pinned staging buffers)."""
         return images.cpu().numpy(), counters.cpu().numpy()
 
+    def _trace_many(self, items, seed: int, phases) -> None:
+        """items: (system, its image or None, the scratch image if it wants none, its counters).  Here: one simulation after
+        the other; the GPU tracer hands the batch to ort_trace_batch (multi-system launches)."""
+        try:
+            for system, image, scratch, counters in items:
+                self._begin_simulation(system, image if image is not None else scratch, counters)
+                lo, cnt = shard_range(system.settings.nphotons, self.rank, self.world)
+                for phase in phases:
+                    self._trace_shard(phase, lo, cnt, seed)
+        finally:
+            self._end_batch()
+
     def run_many(self, systems, seed: int = DEFAULT_SEED, phases=(1, 2), want_images=True):
         """A batch of simulations (a sweep: runner.py starts one process per settings file, :26-47) queued
         back to back: per simulation the system is staged (`_begin_simulation`: on the GPU asynchronously,
@@ -163,14 +175,8 @@ class ShardedRun:
         n_img = len(slot)
         with self._on_stream():                 # zero-filled on the stream the traces into them run on
             images, counters = self._new_accumulators(n_img + (1 if n_img < n else 0), n)
-        try:
-            for i, system in enumerate(systems):
-                self._begin_simulation(system, images[slot.get(i, n_img)], counters[i])
-                lo, cnt = shard_range(system.settings.nphotons, self.rank, self.world)
-                for phase in phases:
-                    self._trace_shard(phase, lo, cnt, seed)
-        finally:
-            self._end_batch()
+        self._trace_many([(system, images[slot[i]] if i in slot else None, images[n_img] if i not in slot else None, counters[i])
+                          for i, system in enumerate(systems)], seed, phases)
         with self._on_stream():
             if self.world > 1:
                 import torch.distributed as dist
@@ -255,6 +261,30 @@ class RayTracer(ShardedRun):
             out.append(dst)
         self.stream.synchronize()
         return out[0].numpy().copy(), out[1].numpy().copy()
+
+    multi_system_launches = True      # run_many through ort_trace_batch; False: one simulation after the other (tests, A/B)
+
+    def _trace_many(self, items, seed: int, phases) -> None:
+        """ort_trace_batch per loop and per group of simulations with the same shard of rays: the simulations whose lists are
+        surface programs share multi-system launches, the library traces the rest one by one (include/ort.h).  The image
+        source brings its own table per simulation (ort_set_image_source): those go through the one-by-one path here."""
+        if not self.multi_system_launches:
+            return super()._trace_many(items, seed, phases)
+        from .capi import pack_systems
+        groups, single = {}, []
+        for it in items:
+            if it[0].settings.light_source == "image":
+                single.append(it)
+            else:
+                groups.setdefault(shard_range(it[0].settings.nphotons, self.rank, self.world), []).append(it)
+        for (lo, cnt), its in groups.items():
+            packed = pack_systems([it[0] for it in its])
+            imgs = [it[1].data_ptr() if it[1] is not None else 0 for it in its]
+            cnts = [it[3].data_ptr() for it in its]
+            for phase in phases:
+                self.ctx.trace_batch(packed, phase, lo, cnt, seed, imgs, cnts)
+        if single:
+            super()._trace_many(single, seed, phases)
 
     def _begin_simulation(self, system: OpticalSystem, image, counters) -> None:
         self.set_system(system)                                          # asynchronous: the next slot of the ring

@@ -42,7 +42,10 @@ def test_runner_sweeps_on_one_context(hip_library, tmp_path):
         orc = Oracle(osys)
         img = np.zeros((2, 401, 401), np.int32); cnt = np.zeros(8, np.uint64)
         orc.trace(1, 0, n, SEED, img, cnt); orc.trace(2, 0, n, SEED, img, cnt)
-        assert np.abs(res.image.astype(np.int64) - img).sum() <= 4, name
+        if s.make_images:
+            assert np.abs(res.image.astype(np.int64) - img).sum() <= 4, name
+        else:
+            assert res.image is None, name        # make_images false (src/main.f90:183): the counters are the result
         assert np.abs(res.counters.astype(np.int64) - cnt.astype(np.int64)).max() <= 2, name
     # a smaller iris never transmits more (same rays, same draws)
     by = {(s.bottle_file, s.use_bottle, s.iris, s.iris_size): r for _, s, r in sw.results if s.data_folder == "iris"}

@@ -71,6 +71,8 @@ if __name__ == "__main__":
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
     print(f"build {build_id()}  nphotons {n}")
     r = sweeps.lens_experiment_rates(n)
-    for mode in ("batched", "one_by_one"):
-        print(f"{mode:12s} {r[mode]['simulations_per_s']:8.1f} simulations/s  ({r[mode]['seconds'] * 1e3:.2f} ms for {r[mode]['simulations']})")
+    for mode in ("batched", "queued", "one_by_one"):
+        m = r[mode]
+        print(f"{mode:12s} {m['simulations_per_s']:8.1f} simulations/s  ({m['seconds'] * 1e3:.2f} ms for {m['simulations']}); "
+              f"first call of a fresh context {m['first_call_simulations_per_s']:8.1f} /s ({m['first_call_seconds'] * 1e3:.2f} ms)")
     sections(n)
