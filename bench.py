@@ -120,16 +120,30 @@ def single_process(args, phases, rays_gpu, text) -> int:
         for c, (lo, cnt) in zip(ctxs, shards):
             c.trace(phases[k % len(phases)], k * cnt, cnt, DEFAULT_SEED)
 
+    pool = None
+    if args.host_threads and world > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=world)
+
     def run(steps, first):
         for c in ctxs:
             c.reset()
         for c in ctxs:
             c.synchronize()
         t0 = time.perf_counter()
-        for k in range(steps):
-            for c, (lo, cnt) in zip(ctxs, shards):
-                for ph in phases:
-                    c.trace(ph, (first + k) * total_rays + lo, cnt, DEFAULT_SEED)
+        if pool is None:
+            for k in range(steps):
+                for c, (lo, cnt) in zip(ctxs, shards):
+                    for ph in phases:
+                        c.trace(ph, (first + k) * total_rays + lo, cnt, DEFAULT_SEED)
+        else:                                       # --host-threads: one issuing thread per device (ctypes releases the GIL in the call)
+            def issue(j):
+                c, (lo, cnt) = ctxs[j], shards[j]
+                for k in range(steps):
+                    for ph in phases:
+                        c.trace(ph, (first + k) * total_rays + lo, cnt, DEFAULT_SEED)
+            list(pool.map(issue, range(world)))
+        run.issue_s = time.perf_counter() - t0
         for c in ctxs:
             c.flush()
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -183,6 +197,8 @@ def single_process(args, phases, rays_gpu, text) -> int:
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "value_executed": (isect - culled) / elapsed, "reduce_ms": reduce_ms,
+        # wall of the issue loop / ort_trace calls in it: ONE host thread serves all devices unless --host-threads
+        "host_us_per_trace_call": run.issue_s / (args.steps * world * len(phases)) * 1e6, "host_threads": world if pool else 1,
         "reduce_verified": reduce_verified, "ranks_seen": capi.allreduce_ranks() if (world > 1 or args.force_dist) else 1,
         "kernel_ms_per_step_over_ranks": (lambda v: {"min": min(v), "max": max(v)})(
             [sum(k) / len(k) * len(phases) for k in (c.kernel_times(min(args.steps * len(phases), 64)) for c in ctxs)]),
@@ -256,6 +272,8 @@ def main() -> int:
                          "at 1e6 and 1e9 photons; adds the `sweep` object (several extra seconds)")
     ap.add_argument("--single-process", action="store_true",
                     help="one process, one context per GPU, ort_allreduce (the Fortran host's layout, INTEGRATION.md §C)")
+    ap.add_argument("--host-threads", action="store_true",
+                    help="--single-process: issue every device's launches from its own host thread (the C ABI serialises per context)")
     ap.add_argument("--rehearse", action="store_true",
                     help="development: run the N-rank flow on ONE GPU (every rank on device 0, gloo instead of RCCL); "
                          "the line says so in config.rehearsal and is not a scaling measurement")
@@ -362,6 +380,7 @@ def main() -> int:
         t0 = time.perf_counter()
         for k in range(steps):
             step(args.warmup + k)
+        timed_run.issue_s = time.perf_counter() - t0   # the host's share: K x phases ort_trace calls issued, nothing waited for
         tracer.flush()                              # the group's literal re-run + the fold, then the reduce
         if use_dist:                                # reduce_ms: an event pair around the all-reduce alone
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -413,6 +432,7 @@ def main() -> int:
     # ---- the leg `value` reports: exact fp64 — first, straight after the set-up ------------------
     elapsed, kernel_ms = timed_run(args.steps, args.warmup)
     reduce_ms, culled_total, deferred_total = timed_run.reduce_ms, timed_run.culled, timed_run.deferred
+    host_us_per_call = timed_run.issue_s / (args.steps * len(phases)) * 1e6
     res = tracer.result(total_rays * args.steps)   # counters of the whole timed run, summed over ranks
     isect_total, binned_total = isect_binned(res)
     for ph in phases:
@@ -546,6 +566,10 @@ def main() -> int:
         # solve (segment 0 of the ring programs; 0 for the point loop), and the all-reduce on its own
         "value_executed": isect_exec_per_step * args.steps / elapsed,
         "reduce_ms": reduce_ms,
+        # wall time of the loop that ISSUES the timed steps / ort_trace calls in it (nothing is waited for inside it; when the
+        # runtime's launch queue fills, it includes the wait for a free slot): what the host costs per call — at 8 GPUs the
+        # per-GPU step of configs[1] is 0.3 ms, so this must stay far below it
+        "host_us_per_trace_call": host_us_per_call,
         # N > 1 (or --force-dist): one extra sharded + reduced step == the same rays on rank 0 alone, image and 8 counters
         "reduce_verified": reduce_verified,
         "ranks_seen": (dist.get_world_size() if use_dist else 1),

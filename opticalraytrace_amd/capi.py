@@ -71,7 +71,7 @@ def pack_system(osys: OpticalSystem) -> OrtSystem:
     for ph in (1, 2):
         surfs = osys.surfaces(ph)
         cs.n_surfaces[ph - 1] = len(surfs)
-        cs.split[ph - 1] = osys.queue_split(ph)
+        cs.split[ph - 1] = osys.queue_split_of(surfs, ph)
         for k, s in enumerate(surfs):
             d = cs.surfaces[ph - 1][k]
             d.cx, d.cy, d.cz = s.cx, s.cy, s.cz

@@ -231,11 +231,17 @@ int plan_ranges(TraceArgs &a)
         a.head_rays = n;
         a.head_chunk = (((n + nwaves - 1) / nwaves) + 63) & ~63ull;
         a.tail_chunk = 64;
+        if (a.head_chunk > kMaxRange) {                      // (development knobs only: a small ORT_DEV_MAX_BLOCKS) more workgroups
+            grid = (int)((n + kMaxRange * kWavesPerBlock - 1) / (kMaxRange * kWavesPerBlock));
+            a.head_blocks = (uint32_t)grid;
+            a.head_chunk = kMaxRange;
+        }
         return grid;
     }
     const uint64_t hw = (uint64_t)head_blocks * kWavesPerBlock;
     a.head_blocks = (uint32_t)head_blocks;
     a.head_chunk = ((n / 100 * (uint64_t)head_pct / hw) + 63) & ~63ull;
+    if (a.head_chunk > kMaxRange) a.head_chunk = kMaxRange;          // (2^27 rays over 1 280 workgroups: 22 592)
     a.head_rays = a.head_chunk * hw < n ? a.head_chunk * hw : n;
     a.tail_chunk = 64ull * (uint64_t)tail_batches;
     const uint64_t rest = n - a.head_rays, tb = a.tail_chunk * kWavesPerBlock;
@@ -851,7 +857,18 @@ static int reserve_list(ort_ctx *c, uint64_t n_rays)
         HIP_TRY(hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_redo_list);
         c->d_redo_list = nullptr; c->redo_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_redo_list, want * sizeof(uint32_t)));
+        // (several launches' worth is a convenience — one re-run launch per eight queued ones; a device short of memory
+        // gets the list of ONE launch, which is all a group needs)
+        if (hipMalloc(&c->d_redo_list, want * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->d_redo_list = nullptr;
+            want = chunk;
+            if (hipMalloc(&c->d_redo_list, want * sizeof(uint32_t)) != hipSuccess) {
+                (void)hipGetLastError();
+                c->d_redo_list = nullptr;
+                return fail(ORT_E_NOMEM, "device memory: the re-run list of one launch (4 bytes per ray) does not fit");
+            }
+        }
         c->redo_cap = want;
     }
     return ORT_OK;
@@ -888,8 +905,8 @@ static uint32_t scatter_grab(uint64_t n, unsigned groups)
     if (forced > 0) g = (uint64_t)forced;
     return (uint32_t)(64 * g);
 }
-// fp32 queued launches.  The hit log holds the launches since the last binning (kHitLogEntries 16-bit entries per part:
-// 1.34 GB of the 288 GB), the directory eight words per traced
+// fp32 queued launches.  The hit log holds the launches since the last binning (eight launches of the largest size seen so
+// far, at most kHitLogEntries 16-bit entries per part: 1.34 GB of the 288 GB), the directory eight words per traced
 // wave, the slabs (2 layers x kBinUnits x 643 KB = 66 MB) what bin_log_kernel has accumulated since the last fold.
 // Binning is LAZY like the fold: bin_log_kernel costs ~20 us whatever the log holds (a chain of memory round trips, and
 // one scattered store per non-empty bin and unit), so the launches of a run append to the log and one kernel bins them
@@ -924,10 +941,24 @@ static int reserve_hit_log(ort_ctx *c, int phase, uint64_t rays, uint64_t nwaves
         HIP_TRY(hipStreamSynchronize(c->stream));            // (the log is empty here; a kernel may still be reading the old buffers)
         if (rays + 8 > c->hit_log_cap) {
             (void)hipFree(c->d_hit_log); c->d_hit_log = nullptr; c->hit_log_cap = 0;
-            const uint64_t want = rays + 8 > kHitLogEntries ? rays + 8 : kHitLogEntries;
+            // room for eight launches of the largest size seen (one binning per eight launches), at most kHitLogEntries per part:
+            // a 1 000-ray run holds a log of kilobytes, not the 1.34 GB of a 2^27-ray launch
+            uint64_t want = 8 * (rays + 64);
+            if (want > kHitLogEntries) want = kHitLogEntries;
+            if (want < rays + 8) want = rays + 8;
             const uint64_t cap = (want + 63) & ~63ull;          // (+8: bin_log_kernel reads eight entries at a time)
-            HIP_TRY(hipMalloc(&c->d_hit_log, (size_t)kBinTiles * cap * sizeof(uint16_t)));
-            c->hit_log_cap = cap;
+            uint64_t got = cap;
+            if (hipMalloc(&c->d_hit_log, (size_t)kBinTiles * got * sizeof(uint16_t)) != hipSuccess) {
+                (void)hipGetLastError();                           // short of memory: the log of this one launch
+                c->d_hit_log = nullptr;
+                got = (rays + 8 + 63) & ~63ull;
+                if (hipMalloc(&c->d_hit_log, (size_t)kBinTiles * got * sizeof(uint16_t)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    c->d_hit_log = nullptr;
+                    return fail(ORT_E_NOMEM, "device memory: the fp32 hit log of one launch (10 bytes per ray) does not fit");
+                }
+            }
+            c->hit_log_cap = got;
         }
         if (!c->d_hit_dir) HIP_TRY(hipMalloc(&c->d_hit_dir, kHitDirEntries * kBinDirWords * sizeof(uint32_t)));
         if (!c->d_slabs) {
@@ -1232,6 +1263,8 @@ int ort_trace_batch(ort_ctx *c, int n, const ort_system *systems, int phase, uin
                 uint64_t bx = ((uint64_t)kBatchTargetBlocks + cnt - 1) / cnt;
                 if (bx > blocks_most) bx = blocks_most;
                 if (bx > (uint64_t)kMaxBlocks) bx = kMaxBlocks;
+                const uint64_t bx_least = (n_rays + kMaxRange * kWavesPerBlock - 1) / (kMaxRange * kWavesPerBlock);   // a wave's range holds < 2^16 rays
+                if (bx < bx_least) bx = bx_least;
                 if (bx < 1) bx = 1;
                 const uint64_t nwaves = bx * kWavesPerBlock;
                 for (int j = g0; j < g1; ++j) {

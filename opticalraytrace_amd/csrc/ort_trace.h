@@ -718,10 +718,14 @@ __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_kernel(TraceArgs 
 constexpr uint64_t kNoRay = ~0ull;   // hand-over bundle of the scattering pipeline: a slot without a ray
 // control words of the scattering pipeline (TraceArgs.scat_ctl), each on a 128-byte line of its own
 constexpr int kScatCtlStride = 16, kScatHeads = 8, kScatSlotsWord = kScatHeads * kScatCtlStride, kScatCtlWords = (kScatHeads + 1) * kScatCtlStride;
-constexpr int kScatWaves = 12;              // wavefronts per workgroup of scatter_front_kernel = per CU (LDS and 168 VGPRs allow no more)
+#ifndef ORT_SCAT_WAVES
+#define ORT_SCAT_WAVES 12
+#endif
+constexpr int kScatWaves = ORT_SCAT_WAVES;              // wavefronts per workgroup of scatter_front_kernel = per CU (LDS and 168 VGPRs allow no more)
 constexpr unsigned kHandChunk = 256;        // hand-over slots a wave allocates at a time
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kQueueCap = 128;      // >= 63 leftover + 64 new survivors
+constexpr uint64_t kMaxRange = 65472;   // rays of one wave's static range (a queued ray index is 16 bits relative to the range's first ray)
 constexpr int kQueueFields = 6;     // px py pz dx dy dz (+ the draw state: its own array)
 
 __device__ inline int lane_prefix(unsigned long long mask)
@@ -758,13 +762,18 @@ __device__ __forceinline__ void trace_queue_body(const TraceArgs &a)
     constexpr bool fixed = PROG != PROG_GENERIC;        // surface program known at compile time
     using QT = typename std::conditional<std::is_same<T, float>::value, float, double>::type;
     constexpr bool sdraws = prog_static_draws<PROG>();  // every lane at the same, compile-time draw index (ProgDraws)
-    using QD = typename std::conditional<sdraws, uint32_t, uint64_t>::type;  // static draws: the ray's index in the launch
+    // static draws: what is queued of a ray's draw state is its index — as 16 bits RELATIVE to the wave's range where the range is
+    // static (plan_ranges keeps a range below kMaxRange rays): 1 KB less per queue, which is what lets a CU hold six
+    // workgroups of a ring program (two queues: 28.7 KB -> 26.6 KB) instead of five
+    constexpr bool SHORTQ = sdraws && SCHED == SCHED_STATIC && MODE != MODE_CONTINUE;
+    using QI = typename std::conditional<SHORTQ, uint16_t, uint32_t>::type;
+    using QD = typename std::conditional<sdraws, QI, uint64_t>::type;
     __shared__ QT Q[kWavesPerBlock][kQueueFields][kQueueCap];
     __shared__ QD QDRAW[kWavesPerBlock][kQueueCap];
     // ring programs, fused: segment 0 (below) culls the rays that are certain to miss the first aperture
     // before anything is emitted; the others wait here (ray index in the launch) for a full wave
     constexpr bool PRE = prog_culls<PROG>() && MODE == MODE_FUSED;
-    __shared__ uint32_t CQ[kWavesPerBlock][PRE ? kQueueCap : 1];
+    __shared__ QI CQ[kWavesPerBlock][PRE ? kQueueCap : 1];
     // intersections evaluated before the queue point: `split` for every survivor unless a surface
     // scatters (extended instantiation), so only that one carries the count through the queue
     constexpr bool CARRY = SCAT || MODE == MODE_CONTINUE;     // the count differs from ray to ray at the queue point
@@ -784,7 +793,7 @@ __device__ __forceinline__ void trace_queue_body(const TraceArgs &a)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: the wave's range and loop control stay scalar
     QT (*q)[kQueueCap] = Q[wave];
     QD *qd = QDRAW[wave];
-    uint32_t *cq = CQ[wave];
+    QI *cq = CQ[wave];
     int *qn = QN[wave];
     using PD = ProgDrawsT<WIDE>;
     using DrawsT = typename std::conditional<sdraws, PD, KeyedDrawsT<WIDE ? 2 : 0>>::type;
@@ -949,12 +958,13 @@ __device__ __forceinline__ void trace_queue_body(const TraceArgs &a)
             // decision, side effect and deferral)
             RayT<T> r = {{T(0.), T(0.), T(0.)}, {T(0.), T(0.), T(1.)}};
             DrawsT d;
-            QD dw = 0;                                   // the queued image of the draw state
+            typename std::conditional<sdraws, uint32_t, uint64_t>::type dw = 0;      // the queued image of the draw state (static draws: the index in the launch)
             int nis = 0, xp = 0, yp = 0, st = act ? -1 : ORT_ST_NA_REJECT;
             {
                 r.pos = {T(q[0][slot]), T(q[1][slot]), T(q[2][slot])};
                 r.dir = {T(q[3][slot]), T(q[4][slot]), T(q[5][slot])};
-                dw = qd[slot];
+                if constexpr (SHORTQ) dw = (uint32_t)lo + (uint32_t)qd[slot];
+                else dw = qd[slot];
                 nis = CARRY ? qn[slot] : split;
             }
             if constexpr (sdraws) d.init_index(z0, dw, 0);
@@ -978,7 +988,7 @@ __device__ __forceinline__ void trace_queue_body(const TraceArgs &a)
             if constexpr (PRE) {
                 const int m = ccount < 64 ? ccount : 64;
                 act = lane < m;
-                i = act ? (uint64_t)cq[(chead + lane) & (kQueueCap - 1)] : lo;
+                i = act ? (SHORTQ ? lo : 0ull) + (uint64_t)cq[(chead + lane) & (kQueueCap - 1)] : lo;
                 chead = (chead + m) & (kQueueCap - 1);
                 ccount -= m;
             } else {
@@ -1049,7 +1059,7 @@ __device__ __forceinline__ void trace_queue_body(const TraceArgs &a)
                 const int slot = (qhead + qcount + lane_prefix(mask)) & (kQueueCap - 1);
                 q[0][slot] = (QT)r.pos.x; q[1][slot] = (QT)r.pos.y; q[2][slot] = (QT)r.pos.z;
                 q[3][slot] = (QT)r.dir.x; q[4][slot] = (QT)r.dir.y; q[5][slot] = (QT)r.dir.z;
-                if constexpr (sdraws) qd[slot] = (uint32_t)i;
+                if constexpr (sdraws) qd[slot] = (QI)(SHORTQ ? i - lo : i);
                 else qd[slot] = d.pack();
                 if (CARRY) qn[slot] = nis;
             } else if (deferred) {
@@ -1091,7 +1101,7 @@ __device__ __forceinline__ void trace_queue_body(const TraceArgs &a)
                 }
                 const bool cand = act && !dies;
                 const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
-                if (cand) cq[(chead + ccount + lane_prefix(mask)) & (kQueueCap - 1)] = (uint32_t)next + (uint32_t)lane;
+                if (cand) cq[(chead + ccount + lane_prefix(mask)) & (kQueueCap - 1)] = (QI)((SHORTQ ? (uint32_t)(next - lo) : (uint32_t)next) + (uint32_t)lane);
                 const int passed = __popcll(mask);
                 culled_wave += (unsigned)((left < 64u ? (int)left : 64) - passed);
                 ccount += passed;

@@ -16,6 +16,7 @@ are legal, everything after it is a free-text comment.  All `real` are fp64
 """
 from __future__ import annotations
 
+import functools
 import math
 import os
 import re
@@ -29,6 +30,7 @@ class ParamsError(ValueError):
     """Bad or truncated input file (the reference dies with a Fortran I/O `error stop`)."""
 
 
+@functools.lru_cache(maxsize=8192)        # (a sweep parses the same few hundred tokens for every one of its systems)
 def parse_real(tok: str) -> float:
     """Fortran list-directed real: `785d-9`, `1.d-2`, `5`, `0.`."""
     t = tok.strip()

@@ -201,7 +201,12 @@ class OpticalSystem:
         ring source (69 % of ring rays miss it), the first doublet face for the point
         source (a third of the remaining rays miss it).  Scheduling only; results are identical
         for any value."""
-        names = [s.name for s in self.surfaces(phase)]
+        return self.queue_split_of(self.surfaces(phase), phase)
+
+    @staticmethod
+    def queue_split_of(surfaces, phase: int) -> int:
+        """queue_split for a list `surfaces(phase)` has already built (pack_system: one list per phase, not two)."""
+        names = [s.name for s in surfaces]
         stop = "L2 flat" if phase == 1 else "L3 face 1"
         return names.index(stop) + 1
 

@@ -43,6 +43,8 @@ def main():
         c = Ctx(lib, osys)
         c.set_timing(True)
         c.reserve(args.rays)
+        lib.ort_build_id.restype = C.c_char_p
+        print(f"# {os.path.basename(p)}: library build {lib.ort_build_id().decode()}")
         ctxs.append((os.path.basename(p), c))
     res = {}
 

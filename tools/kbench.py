@@ -27,6 +27,7 @@ def main():
     VARIANTS = [int(v) for v in args.variants.split(',')]
     s = Settings(nphotons=args.rays, bottle_file=args.bottle)
     osys = OpticalSystem.from_settings(s)
+    print(f"# library build {capi.build_id()}")
     ctx = capi.Context(osys)
     ctx.set_timing(True)
     ctx.set_precision(args.precision)

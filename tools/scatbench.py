@@ -25,6 +25,7 @@ def main():
     from conftest import res_dir_with_image
     s = Settings(nphotons=1000, make_images=True, bottle_file=args.bottle)
     osys = OpticalSystem.from_settings(s, res_dir_with_image(resource_dir()))
+    print(f"# library build {capi.build_id()}  ({os.environ.get('ORT_HIP_LIB', 'in-tree')})", flush=True)
     with capi.Context(osys, device=0) as c:
         for n in [int(x) for x in args.rays.split(",")]:
             for v in [int(x) for x in args.variants.split(",")]:

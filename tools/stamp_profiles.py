@@ -8,7 +8,13 @@ the figures bench.py quotes, stamped with the library's build id and the commit:
       gfx950 correction of MI355X_MICROARCH.md; separate --pmc passes) of the dominant kernel
   valu_busy_frac       = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)
   valu_lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
-usage: python tools/stamp_profiles.py r02 [gpurun_out/prof]"""
+A bench line whose config.build_id is not the build id of the sources in this tree is REFUSED (exit status 2): figures are
+quoted for the final build only.
+usage: python tools/stamp_profiles.py r02 [gpurun_out/prof]
+       python tools/stamp_profiles.py --check profiles/r05     every log / json of the directory that names a library build
+                                                               ("library build <id>", "build <id>", "build_id": "<id>") must name THIS one;
+                                                               files listed in <dir>/OTHER_BUILDS (one name per line, with the reason) are
+                                                               A/B records of other builds and are skipped"""
 import collections
 import csv
 import glob
@@ -21,20 +27,50 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-DOMINANT = {"point1e7": "trace_queue_kernel<0, true, false, double, 1, false>",
-            "ring1e8": "trace_queue_kernel<0, true, false, double, 2, false>",
-            "full1e9": "trace_queue_kernel<0, true, false, double, 1, false>"}
+# (template arguments: MODE, FILT, ANYSRC, T, PROG, SCAT, RNG (1 strict libm emitters, 2 53-bit draws), SCHED, NOBIN)
+DOMINANT = {"point1e7": "trace_queue_kernel<0, true, false, double, 1, false, 0, 0, false>",
+            "ring1e8": "trace_queue_kernel<0, true, false, double, 2, false, 0, 0, false>",
+            "full1e9": "trace_queue_kernel<0, true, false, double, 1, false, 0, 0, false>"}
 # the informational legs of a workload: their program kernels (bench.py `fp32` / `fast_fp64`)
-LEGS = {"point1e7": {"fp32": "trace_queue_kernel<0, true, false, float, 1, false>",
-                     "fast_fp64": "trace_queue_kernel<0, true, false, ort::fastd, 1, false>"}}
+LEGS = {"point1e7": {"fp32": "trace_queue_kernel<0, true, false, float, 1, false, 0, 0, false>",
+                     "fast_fp64": "trace_queue_kernel<0, true, false, ort::fastd, 1, false, 0, 0, false>",
+                     "strict": "trace_queue_kernel<0, true, false, double, 1, false, 1, 0, false>",
+                     "wide": "trace_queue_kernel<0, true, false, double, 1, false, 2, 0, false>",
+                     "strict_wide": "trace_queue_kernel<0, true, false, double, 1, false, 3, 0, false>"}}
 
 
 def short(name):
-    m = re.search(r"(trace_queue_kernel|trace_kernel|fold_kernel|emit_kernel)(<[^>]*>)?", name)
+    m = re.search(r"(trace_queue_kernel|trace_batch_kernel|trace_batch_rerun_kernel|trace_kernel|scatter_front_kernel|bin_log_kernel|fold_slabs_kernel|fold_kernel|emit_kernel)(<[^>]*>)?", name)
     return (m.group(1) + (m.group(2) or "")) if m else None
 
 
+def check(directory):
+    from opticalraytrace_amd import capi
+    build = capi.source_build_id()
+    skip = set()
+    other = os.path.join(directory, "OTHER_BUILDS")
+    if os.path.exists(other):
+        skip = {ln.split()[0] for ln in open(other).read().splitlines() if ln.strip() and not ln.startswith("#")}
+    bad, seen = [], 0
+    for root, _, files in os.walk(directory):
+        for f in sorted(files):
+            rel = os.path.relpath(os.path.join(root, f), directory)
+            if rel in skip or f == "OTHER_BUILDS" or not f.endswith((".log", ".json", ".csv", ".txt")):
+                continue
+            text = open(os.path.join(root, f), errors="replace").read()
+            ids = set(re.findall(r'(?:library build|^build|"build_id":)\s*"?([0-9a-f]{16})', text, re.M))
+            seen += bool(ids)
+            if ids - {build}:
+                bad.append((rel, sorted(ids - {build})))
+    for rel, ids in bad:
+        print(f"REFUSED {rel}: taken on build {', '.join(ids)}, the sources here are {build}")
+    print(f"{directory}: {seen} files name a build, {len(bad)} of them another one than {build}")
+    return 2 if bad else 0
+
+
 def main():
+    if sys.argv[1] == "--check":
+        sys.exit(check(sys.argv[2]))
     rnd = sys.argv[1]
     src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "prof")
     dst = os.path.join(ROOT, "profiles", rnd)
@@ -53,7 +89,11 @@ def main():
             if os.path.exists(os.path.join(d, f)):
                 lines = [ln for ln in open(os.path.join(d, f)).read().splitlines() if ln.startswith("{")]
                 if lines:
-                    json.dump(json.loads(lines[-1]), open(os.path.join(dst, name), "w"), indent=1)
+                    line = json.loads(lines[-1])
+                    if line.get("config", {}).get("build_id") != build:
+                        print(f"REFUSED {os.path.join(d, f)}: bench line of build {line.get('config', {}).get('build_id')}, the sources here are {build}")
+                        sys.exit(2)
+                    json.dump(line, open(os.path.join(dst, name), "w"), indent=1)
         ks = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
         if ks:
             shutil.copy(ks[0], os.path.join(dst, f"{w}_kernel_stats.csv"))
