@@ -47,10 +47,12 @@ def main(argv=None) -> int:
     # beyond the reference's program (which has none of these: fp64, its runtime's draws, its libm):
     ap.add_argument("--fp32", action="store_true", help="trace in single precision (BASELINE configs[4]; ~2 x the rate, images within shot noise)")
     ap.add_argument("--strict-libm", action="store_true",
-                    help="the light sources call glibc's own sin / cos: emitted rays equal the compiled reference's bit for bit (~1.5 x the time)")
+                    help="the light sources call glibc's own sin / cos: emitted rays equal the compiled reference's bit for bit (fp64 only; ~1.07 x the time)")
     ap.add_argument("--wide-draws", action="store_true",
-                    help="53-bit uniforms, as random_number fills ran2's real(8) (src/random_mod.f90:39-46), instead of 32-bit ones (~2.5 x the time)")
+                    help="53-bit uniforms, as random_number fills ran2's real(8) (src/random_mod.f90:39-46), instead of 32-bit ones (~1.09 x the time in fp64)")
     args = ap.parse_args(argv)
+    if args.fp32 and args.strict_libm:
+        ap.error("--strict-libm belongs to the exact fp64 path (the reference's arithmetic): not with --fp32")
 
     path, res_dir = _locate(args.settings, args.res)
     data_dir = args.data or (os.path.join("..", "data") if args.res is None and not os.path.exists(args.settings)

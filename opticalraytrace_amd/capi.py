@@ -170,7 +170,7 @@ def source_build_id() -> str:
     return h.hexdigest()[:16]
 
 
-def load_library(path: Optional[str] = None, no_torch: Optional[bool] = None) -> C.CDLL:
+def load_library(path: Optional[str] = None, no_torch: Optional[bool] = None, older_build: bool = False) -> C.CDLL:
     """Load libort_hip.so and declare every symbol of include/ort.h.  Raises if absent.
 
     PyTorch-ROCm bundles its own HIP/HSA runtime.  It must be the first one loaded into the process: libort_hip.so then
@@ -236,6 +236,8 @@ def load_library(path: Optional[str] = None, no_torch: Optional[bool] = None) ->
         "ort_set_precision": (C.c_int, [vp, i32]),
     }
     for name, (res, args) in sig.items():
+        if older_build and not hasattr(lib, name):     # development (tools/abbench.py): an A/B against a build of an earlier round
+            continue
         fn = getattr(lib, name)          # AttributeError if the library lacks a symbol
         fn.restype, fn.argtypes = res, args
     if lib.ort_abi_version() != ABI_VERSION:

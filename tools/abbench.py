@@ -39,7 +39,7 @@ def main():
     osys = OpticalSystem.from_settings(s)
     ctxs = []
     for p in args.libs.split(","):
-        lib = capi.load_library(os.path.abspath(p))
+        lib = capi.load_library(os.path.abspath(p), older_build=True)
         c = Ctx(lib, osys)
         c.set_timing(True)
         c.reserve(args.rays)

@@ -34,6 +34,12 @@ def measure(name, settings_kw, n, reps, resident=False, precision=0, variant=1):
         bundle = torch.empty((6, n), dtype=torch.float64, device="cuda:0") if resident else None
         for phase in (1, 2):
             ms, ems = [], []
+            if not resident:
+                # every row at steady clocks: the rows differ in how long their set-up idles the GPU, and the first ~30 ms of
+                # work after an idle period run at lower clocks (tools/rampbench.py) — ~40 ms of untimed launches first
+                for k in range(max(4, min(120, int(1.2e9 // max(n, 1))))):
+                    c.trace(phase, 0, n, SEED)
+                c.synchronize()
             for k in range(reps + 2):
                 c.reset()
                 if resident:
@@ -66,7 +72,7 @@ def main():
     if not args.only:
         # the generic walk needs the development knob in the environment before the library loads: child process
         from opticalraytrace_amd import capi
-        print(f"# library build {capi.build_id()}; mean kernel time of {args.reps} launches behind 2 warm-up launches")
+        print(f"# library build {capi.build_id()}; mean kernel time of {args.reps} launches (one at a time, a wait behind each) behind ~40 ms of untimed launches of the same kind")
         for tag, env in (("main", {}), ("generic", {"ORT_DEV_NO_PROGRAMS": "1"})):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rays", str(args.rays), "--reps", str(args.reps),
                                 "--only", tag], env={**os.environ, **env})
@@ -102,10 +108,12 @@ def main():
     measure("isors, fp32", dict(bottle_file="clearBottle-small.params", light_source="isors", isors_offset=0.5e-3), n, reps, precision=1)
     measure("image, fp32", dict(bottle_file="clearBottle-large.params", light_source="image", image_source="synthetic-source.dat"), n, reps, precision=1)
     measure("scattering bottle (contents + wall)", dict(bottle_file="scatterBottle-both.params"), n // 10, reps)
-    # the variants that leave the programs: strict libm emitters (generic queued walk), 53-bit draws (lockstep kernel)
+    # the reference's own bits in front of the surfaces: strict libm emitters and 53-bit draws — since round 5 template flags of
+    # the surface programs in exact fp64 (fp32 on the 53-bit stream: the lockstep kernel)
     measure("strict libm emitters (variant 1|64)", large, n, reps, variant=1 | 64)
     measure("53-bit draws (variant 1|32)", large, n, reps, variant=1 | 32)
-    measure("53-bit draws, fp32", large, n, reps, precision=1, variant=1 | 32)
+    measure("strict emitters on 53-bit draws (1|32|64)", large, n, reps, variant=1 | 32 | 64)
+    measure("53-bit draws, fp32 (lockstep kernel)", large, n, reps, precision=1, variant=1 | 32)
     return 0
 
 
