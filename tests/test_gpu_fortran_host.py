@@ -25,6 +25,10 @@ program fortran_host
     type(c_ptr) :: ctx
     integer(c_int32_t) :: image(-200:200, -200:200, 2)      ! src/main.f90:35
     integer(c_int64_t) :: counters(8), nphotons
+    type(ort_system) :: systems(2)
+    type(c_ptr) :: d_img(2), d_cnt(2)
+    integer(c_int32_t) :: image2(-200:200, -200:200, 2)
+    integer(c_int64_t) :: counters2(8)
     integer :: u
     open(newunit=u, file="system.bin", access="stream", form="unformatted", status="old")
     read(u) sys
@@ -41,6 +45,17 @@ program fortran_host
     print '(A,8(1X,I0))', 'counters', counters
     print '(A,1X,I0,1X,I0)', 'layer_sums', sum(int(image(:, :, 1), c_int64_t)), sum(int(image(:, :, 2), c_int64_t))
     print '(A,1X,I0)', 'centre_bin_point', image(0, 0, 2)
+    ! a BATCH from the Fortran host (ort_trace_batch, runner.py's loops): two settings files — here twice the same system —
+    ! traced in one launch per loop, both into the context's own accumulators: every bin and counter must come out doubled
+    systems(1) = sys; systems(2) = sys
+    if (ort_reset(ctx) /= 0) error stop "ort_reset"
+    if (ort_device_image(ctx, d_img(1)) /= 0) error stop "ort_device_image"
+    if (ort_device_counters(ctx, d_cnt(1)) /= 0) error stop "ort_device_counters"
+    d_img(2) = d_img(1); d_cnt(2) = d_cnt(1)
+    if (ort_trace_batch(ctx, 2_c_int, systems, 1_c_int, 0_c_int64_t, nphotons, 123456789_c_int64_t, d_img, d_cnt) /= 0) error stop "batch ring"
+    if (ort_trace_batch(ctx, 2_c_int, systems, 2_c_int, 0_c_int64_t, nphotons, 123456789_c_int64_t, d_img, d_cnt) /= 0) error stop "batch point"
+    if (ort_read(ctx, image2, counters2) /= 0) error stop "ort_read"
+    print '(A,1X,L1,1X,L1)', 'batch_doubles', all(image2 == 2 * image), all(counters2 == 2 * counters)
     if (ort_destroy(ctx) /= 0) error stop "ort_destroy"
 end program
 """
@@ -73,3 +88,4 @@ def test_fortran_program_drives_the_gpu_path(tmp_path, hip_library):
     assert [int(v) for v in lines["layer_sums"]] == [int(img[0].sum()), int(img[1].sum())]
     assert int(lines["centre_bin_point"][0]) == int(img[1, 200, 200])
     assert int(img[1].sum()) > 100000
+    assert lines["batch_doubles"] == ["T", "T"], lines["batch_doubles"]      # ort_trace_batch from Fortran: two simulations, one launch per loop
