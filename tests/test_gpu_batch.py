@@ -133,3 +133,57 @@ def test_trace_batch_arguments(hip_library):
             assert np.array_equal(got[0], want) and np.array_equal(got[1], want), (prec, variant, got, want)
             assert "batch" not in ctx.last_kernel_name()
         ctx.set_kernel_variant(1); ctx.set_precision(0)
+
+
+def test_trace_batch_ragged_sizes(hip_library):
+    """Partial batches, a single ray, a range that starts behind 2^33: multi-system launches == one by one, images and counters."""
+    import torch
+    from opticalraytrace_amd.capi import Context, pack_systems
+    systems = [make_system(name)[1] for name in ("large", "ellipse", "small_iris_after")]
+    packed = pack_systems(systems)
+    images = torch.zeros((3, 2, 401, 401), dtype=torch.int32, device="cuda")
+    counters = torch.zeros((3, 8), dtype=torch.int64, device="cuda")
+    with Context(systems[0]) as ctx:
+        for n, first in ((1, 0), (63, 5), (64, 0), (65, 1 << 33), (129, 7), (4097, 3), (65472 * 4 + 1, 11)):
+            want = _one_by_one(ctx, systems, n, first)
+            images.zero_(); counters.zero_()
+            torch.cuda.synchronize()
+            for phase in (1, 2):
+                ctx.trace_batch(packed, phase, first, n, SEED, [images[i].data_ptr() for i in range(3)], [counters[i].data_ptr() for i in range(3)])
+                assert "trace_batch_kernel<" in ctx.last_kernel_name()
+            ctx.synchronize()
+            gi, gc = images.cpu().numpy(), counters.cpu().numpy().astype(np.uint64)
+            for i, (wimg, wcnt) in enumerate(want):
+                assert np.array_equal(gc[i], wcnt) and np.array_equal(gi[i], wimg), (n, first, i, gc[i], wcnt)
+
+
+_RANGE_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from conftest import make_system
+from opticalraytrace_amd.capi import Context
+_, osys = make_system("large")
+n = int(sys.argv[3])
+with Context(osys) as c:
+    c.trace(1, 3, n, 123456789); c.trace(2, 3, n, 123456789)
+    img, cnt = c.read()
+np.savez(sys.argv[2], img=img, cnt=cnt)
+"""
+
+
+def test_longest_wave_ranges_keep_their_16_bit_queue_indices(hip_library, tmp_path):
+    """The queued program kernels keep a queued ray as 16 bits relative to its wave's range; plan_ranges holds a range below
+    65 472 rays.  With the grid squeezed to two workgroups (development knob) every wave gets a range of exactly that length:
+    the images and counters of both loops equal the default plan's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = []
+    for knobs in ({}, {"ORT_DEV_MAX_BLOCKS": "2"}):
+        out = str(tmp_path / f"r{len(got)}.npz")
+        r = subprocess.run([sys.executable, "-c", _RANGE_CHILD, root, out, str(1_200_003)], env={**os.environ, **knobs}, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(np.load(out))
+    assert np.array_equal(got[0]["img"], got[1]["img"]) and np.array_equal(got[0]["cnt"], got[1]["cnt"])
+    assert int(got[0]["cnt"][5]) > 400_000
