@@ -24,7 +24,8 @@ value = intersections all ranks evaluated (exact int64 device counter) / wall ti
 Order of the legs in one process: CPU baseline (child process, before this process touches
 the GPU), set-up (scratch, code objects, ~50 ms of untimed launches that bring the clocks out
 of idle — see SETTLE_LAUNCHES), then the exact fp64 leg that `value` reports, then the
-informational fp32 and fast-fp64 legs over the same rays.  Every leg: W untimed warm-up steps,
+informational legs over the same rays: the exact path with strict libm emitters / 53-bit draws /
+both (`strict`, `wide`, `strict_wide`), fp32, fast fp64.  Every leg: W untimed warm-up steps,
 then exactly K timed steps between two fences.
 """
 import argparse
