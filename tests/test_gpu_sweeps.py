@@ -159,26 +159,30 @@ def test_batched_sweep_equals_one_by_one(hip_library, tmp_path):
     from opticalraytrace_amd.sweeps import Sweep
     n = 60_000
     out = {}
-    for mode, batched in (("batched", True), ("single", False)):
-        sw = Sweep(nphotons=n, data_dir=str(tmp_path / mode), batched=batched)
+    # batched = through ort_trace_batch (multi-system launches: one launch per surface program and loop over the whole batch),
+    # queued = the same batch one simulation after the other on the context, single = one run_settings at a time
+    for mode, batched, multi in (("batched", True, True), ("queued", True, False), ("single", False, False)):
+        sw = Sweep(nphotons=n, data_dir=str(tmp_path / mode), batched=batched, multi_system=multi)
         try:
             sw.lens_experiment()
             sw.iris_experiment(bottles=[("clearBottle-small.params", True)])     # images written (make_images)
         finally:
             sw.close()
         out[mode] = sw.results
-    assert len(out["batched"]) == len(out["single"]) == 75 + 11
-    for (na, sa, ra), (nb, sb, rb) in zip(out["batched"], out["single"]):
-        assert na == nb and sa == sb
-        if sa.make_images:
-            assert np.array_equal(ra.image, rb.image), na
-        else:
-            assert ra.image is None, na            # make_images false (src/main.f90:183): nothing of the image comes back
-        assert np.array_equal(ra.counters, rb.counters), na
+    assert len(out["batched"]) == len(out["queued"]) == len(out["single"]) == 75 + 11
+    for mode in ("batched", "queued"):
+        for (na, sa, ra), (nb, sb, rb) in zip(out[mode], out["single"]):
+            assert na == nb and sa == sb
+            if sa.make_images:
+                assert np.array_equal(ra.image, rb.image), (mode, na)
+            else:
+                assert ra.image is None, (mode, na)            # make_images false (src/main.f90:183): nothing of the image comes back
+            assert np.array_equal(ra.counters, rb.counters), (mode, na)
     assert len({r.counters.tobytes() for _, _, r in out["batched"]}) > 60       # the systems really differ
     assert len({r.image.tobytes() for _, s, r in out["batched"] if s.make_images}) >= 6
-    for folder in ("images-lens", "iris"):
-        a, b = tmp_path / "batched" / folder, tmp_path / "single" / folder
-        assert sorted(os.listdir(a)) == sorted(os.listdir(b))
-        for f in os.listdir(a):
-            assert open(a / f, "rb").read() == open(b / f, "rb").read(), f
+    for mode in ("batched", "queued"):
+        for folder in ("images-lens", "iris"):
+            a, b = tmp_path / mode / folder, tmp_path / "single" / folder
+            assert sorted(os.listdir(a)) == sorted(os.listdir(b))
+            for f in os.listdir(a):
+                assert open(a / f, "rb").read() == open(b / f, "rb").read(), (mode, f)
