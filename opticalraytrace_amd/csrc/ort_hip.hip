@@ -216,11 +216,26 @@ uint64_t chunk_rays()
 // 0.5 %.  Small launches keep equal ranges.  Scheduling only: results do not depend on it.
 // (The fp32 kernels fit 8 workgroups per CU; more long workgroups gained 3 % while the point program was bound by its image
 // atomics and lose 12 % in the ring loop now that it is not — profiles/r04/headsweep.log, hb.log: one plan for all.)
+// Round 5 (profiles/r05/tailbatch_sweep.log, plansweep.log): the LENGTH of a short range has to grow with the launch where a
+// ray is cheap — the ring loop, whose segment 0 counts 69 % of the rays without emitting them: a wave with 6 batches holds
+// ~120 candidates, runs its passes on partly filled wavefronts and pays the kernel's prologue for them.  `light` = the launch
+// culls (1: fp64 arithmetics, 2: fp32, whose rays are cheaper still): 6 batches up to ~6e6 (fp32: 2.4e6) rays, then one more
+// per 1e6 (4e5) rays, at most 32 — ring1e8 0.720 -> 0.666 ms, 2^27 rays 0.952 -> 0.874 (fp32 0.578 -> 0.472); the point loop
+// (every ray emitted, 6.3 surface solves) is indifferent above 2e7 rays (12 batches: -0.5 %) and wants 6 at 1e7.
 constexpr int kHeadBlocks = 1280, kHeadPercent = 86, kTailBatches = 6;
-int plan_ranges(TraceArgs &a)
+int tail_batches_for(uint64_t n, int light)
 {
-    static const int head_blocks = env_int("ORT_DEV_HEAD_BLOCKS", kHeadBlocks), head_pct = env_int("ORT_DEV_HEAD_PERCENT", kHeadPercent),
-                     tail_batches = env_int("ORT_DEV_TAIL_BATCHES", kTailBatches);
+    static const int forced = env_int("ORT_DEV_TAIL_BATCHES", 0);          // development knob
+    if (forced > 0) return forced;
+    if (light == 0) return n > 16000000ull ? 2 * kTailBatches : kTailBatches;
+    const uint64_t per = light == 2 ? 400000ull : 1000000ull;
+    const uint64_t tb = n / per;
+    return (int)(tb < (uint64_t)kTailBatches ? (uint64_t)kTailBatches : (tb > 32 ? 32 : tb));
+}
+int plan_ranges(TraceArgs &a, int light = 0)
+{
+    static const int head_blocks = env_int("ORT_DEV_HEAD_BLOCKS", kHeadBlocks), head_pct = env_int("ORT_DEV_HEAD_PERCENT", kHeadPercent);
+    const int tail_batches = tail_batches_for(a.n_rays, light);
     const uint64_t n = a.n_rays, per_block = 64ull * kWavesPerBlock;
     if (n < (uint64_t)head_blocks * per_block * 4 || head_pct >= 100) {       // equal ranges
         int grid = grid_for(n);
@@ -240,6 +255,8 @@ int plan_ranges(TraceArgs &a)
     }
     const uint64_t hw = (uint64_t)head_blocks * kWavesPerBlock;
     a.head_blocks = (uint32_t)head_blocks;
+    // (an absolute cap on the rays of the short workgroups instead of a share was measured and is worse at every launch
+    // size: profiles/r05/tailsweep.log)
     a.head_chunk = ((n / 100 * (uint64_t)head_pct / hw) + 63) & ~63ull;
     if (a.head_chunk > kMaxRange) a.head_chunk = kMaxRange;          // (2^27 rays over 1 280 workgroups: 22 592)
     a.head_rays = a.head_chunk * hw < n ? a.head_chunk * hw : n;
@@ -1065,7 +1082,10 @@ static int launch_trace(ort_ctx *c, int mode, TraceArgs &a0, int evk)
         a.first_ray = a0.first_ray + off;
         if (a.pos_dir_in) a.pos_dir_in += off;              // same component stride (in_stride)
         // queued: every wave walks 64-aligned contiguous ranges (plan_ranges); lockstep: grid-stride
-        int grid = queued ? plan_ranges(a) : grid_for(a.n_rays);
+        // (what a ray of this launch costs: the ring programs' segment 0 counts most of them without emitting them)
+        const bool culls = a.phase == 1 && c->prog[0] != PROG_GENERIC && c->emitter[0] == ORT_EMIT_RING && mode == MODE_FUSED &&
+                           (c->precision == 1 ? a.cull_wordf : a.cull_word) != 0xffffffffu;
+        int grid = queued ? plan_ranges(a, culls ? (c->precision == 1 ? 2 : 1) : 0) : grid_for(a.n_rays);
         if (queued && c->exp_which >= 2 && exp_applies(c, mode, a)) { const int rc = plan_pull(c, a, &grid); if (rc) return rc; }
         if (deferring && mode == MODE_FUSED) {
             // fused launches share the re-run list of their group; the literal re-run comes when the
@@ -1157,6 +1177,43 @@ constexpr uint64_t kBatchListMax = 1ull << 28;        // re-run list entries of 
 constexpr int kBatchTargetBlocks = 256 * 6 * 4;       // workgroups of a launch: four rounds of six per CU
 constexpr int kBatchRedoBlocks = 4;                   // workgroups per simulation of the batched re-run (normally they read a zero count and return)
 
+// Ray ranges of ONE simulation of a multi-system launch of `cnt` simulations of a.n_rays rays each: as plan_ranges cuts a launch
+// of its own, with the long workgroups shared out — 1 280 of them in the whole launch (at least one per simulation), 86 % of a
+// simulation's rays in them, the rest in short ranges whose length follows the launch's TOTAL size (tail_batches_for).  The
+// dispatch order is simulation-fastest (trace_batch_kernel: blockIdx.x), so the long workgroups of all simulations start first
+// and the launch drains on short ones.  (Round 5's first plan — equal ranges, 6 144 workgroups — left the 75 ring loops of the
+// lens experiment at half the rate of one large launch: 6 150 equal workgroups are four full rounds of the chip and six left over.)
+// Returns the workgroups per simulation (gridDim.y).
+static int plan_batch(TraceArgs &a, int cnt, int light)
+{
+    const uint64_t n = a.n_rays, per_block = 64ull * kWavesPerBlock;
+    uint64_t hb = ((uint64_t)kHeadBlocks + cnt / 2) / cnt;
+    if (hb < 1) hb = 1;
+    const uint64_t batches = (n + 63) / 64, blocks_most = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (n < hb * per_block * 4) {                            // small simulations: equal ranges, the launch aims at kBatchTargetBlocks workgroups
+        uint64_t by = ((uint64_t)kBatchTargetBlocks + cnt - 1) / cnt;
+        if (by > blocks_most) by = blocks_most;
+        if (by < 1) by = 1;
+        const uint64_t nwaves = by * kWavesPerBlock;
+        a.head_blocks = (uint32_t)by; a.head_rays = n;
+        a.head_chunk = (((n + nwaves - 1) / nwaves) + 63) & ~63ull;       // (< kMaxRange: n < 4 hb per_block)
+        a.tail_chunk = 64;
+        return (int)by;
+    }
+    const uint64_t hw = hb * kWavesPerBlock;
+    a.head_blocks = (uint32_t)hb;
+    a.head_chunk = ((n / 100 * (uint64_t)kHeadPercent / hw) + 63) & ~63ull;
+    if (a.head_chunk > kMaxRange) {                           // (one long workgroup per simulation and > 3e5 rays in it: more of them)
+        hb = (n / 100 * (uint64_t)kHeadPercent + kMaxRange * kWavesPerBlock - 1) / (kMaxRange * kWavesPerBlock);
+        a.head_blocks = (uint32_t)hb;
+        a.head_chunk = kMaxRange;
+    }
+    a.head_rays = a.head_chunk * (uint64_t)a.head_blocks * kWavesPerBlock < n ? a.head_chunk * (uint64_t)a.head_blocks * kWavesPerBlock : n;
+    a.tail_chunk = 64ull * (uint64_t)tail_batches_for(n * (uint64_t)cnt, light);
+    const uint64_t rest = n - a.head_rays, tb = a.tail_chunk * kWavesPerBlock;
+    return (int)(a.head_blocks + (rest + tb - 1) / tb);
+}
+
 static int reserve_batch(ort_ctx *c, int n_sys, uint64_t list_stride)
 {
     if (n_sys > c->bat_cap) {
@@ -1209,7 +1266,7 @@ int ort_trace_batch(ort_ctx *c, int n, const ort_system *systems, int phase, uin
     const int p = phase - 1;
     const bool ctx_ok = c->precision == 0 && (c->variant & ~4) == 1 && n_rays <= kBatchRaysMax && !c->exp_which;
     // the program of every simulation (PROG_GENERIC: it is traced one by one), batched ones in the order of their programs
-    int *prog = (int *)malloc((size_t)n * 2 * sizeof(int)), *order = prog + n;
+    int *prog = (int *)malloc((size_t)n * 3 * sizeof(int)), *order = prog + n, *grid_y = prog + 2 * n;    // grid_y[k]: workgroups per simulation of the group that starts at order[k]
     if (!prog) return fail(ORT_E_NOMEM, "host allocation failed");
     int nb = 0;
     for (int i = 0; i < n; ++i) {
@@ -1254,25 +1311,18 @@ int ort_trace_batch(ort_ctx *c, int n, const ort_system *systems, int phase, uin
                 const RingCull cull = phase == 1 ? ring_cull_of(sys, prog[i]) : RingCull{HUGE_VAL, HUGE_VALF, 0xffffffffu, 0xffffffffu, ~0ull};
                 a.cull_word = cull.word; a.cull_wordf = cull.wordf; a.cull_wide = cull.wide;
             }
-            // equal, 64-aligned ranges over bx workgroups per simulation; every launch aims at kBatchTargetBlocks workgroups
+            // the ray ranges of a simulation's workgroups: plan_batch, one plan per group (launch) of simulations
             for (int g0 = 0; g0 < m;) {
                 int g1 = g0;
                 while (g1 < m && prog[order[at + g1]] == prog[order[at + g0]]) ++g1;
-                const int cnt = g1 - g0;
-                const uint64_t batches = (n_rays + 63) / 64, blocks_most = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
-                uint64_t bx = ((uint64_t)kBatchTargetBlocks + cnt - 1) / cnt;
-                if (bx > blocks_most) bx = blocks_most;
-                if (bx > (uint64_t)kMaxBlocks) bx = kMaxBlocks;
-                const uint64_t bx_least = (n_rays + kMaxRange * kWavesPerBlock - 1) / (kMaxRange * kWavesPerBlock);   // a wave's range holds < 2^16 rays
-                if (bx < bx_least) bx = bx_least;
-                if (bx < 1) bx = 1;
-                const uint64_t nwaves = bx * kWavesPerBlock;
+                const bool culls = phase == 1 && c->h_bat_args[g0].cull_word != 0xffffffffu;
+                const int by = plan_batch(c->h_bat_args[g0], g1 - g0, culls ? 1 : 0);
                 for (int j = g0; j < g1; ++j) {
                     TraceArgs &a = c->h_bat_args[j];
-                    a.head_blocks = (uint32_t)bx; a.head_rays = n_rays;
-                    a.head_chunk = (((n_rays + nwaves - 1) / nwaves) + 63) & ~63ull;
-                    a.tail_chunk = 64;
+                    const TraceArgs &p0 = c->h_bat_args[g0];
+                    a.head_blocks = p0.head_blocks; a.head_rays = p0.head_rays; a.head_chunk = p0.head_chunk; a.tail_chunk = p0.tail_chunk;
                 }
+                grid_y[at + g0] = by;
                 g0 = g1;
             }
             BATCH_TRY(hipMemcpyAsync(c->d_bat_sys, c->h_bat_sys, (size_t)m * sizeof(DevSystem), hipMemcpyHostToDevice, c->stream));
@@ -1282,7 +1332,7 @@ int ort_trace_batch(ort_ctx *c, int n, const ort_system *systems, int phase, uin
             for (int g0 = 0; g0 < m;) {
                 int g1 = g0;
                 while (g1 < m && prog[order[at + g1]] == prog[order[at + g0]]) ++g1;
-                const LaunchCfg cfg = {(int)c->h_bat_args[g0].head_blocks, c->stream, nullptr, nullptr};
+                const LaunchCfg cfg = {grid_y[at + g0], c->stream, nullptr, nullptr};
                 const char *name = launch_batch(prog[order[at + g0]], cfg, g1 - g0, c->d_bat_args + g0);
                 BATCH_TRY(hipGetLastError());
                 snprintf(c->last_kernel, sizeof c->last_kernel, "%s x %d", name ? name : "(none)", g1 - g0);

@@ -1,6 +1,6 @@
 // ort_k_batch.hip — MULTI-SYSTEM launches (runner.py's experiment loops, :113-261, one process per settings file
 // there): trace_batch_kernel<PROG> traces one loop of every simulation of a group that shares surface program PROG in ONE
-// launch (gridDim.y = simulations; ort_trace.h), trace_batch_rerun_kernel closes the deferral lists of all of them in one
+// launch (gridDim.x = simulations, gridDim.y = workgroups of each; ort_trace.h), trace_batch_rerun_kernel closes the deferral lists of all of them in one
 // more.  Exact fp64, default emitters and ORT-RNG-v2 — the arithmetic and draws of trace_queue_kernel<MODE_FUSED, ..., PROG>,
 // the same body; the image source (one table per context) and everything that is not a surface program go one by one.
 #include "ort_launch.h"
@@ -11,7 +11,7 @@ namespace ortk {
 __global__ __launch_bounds__(kBlock, ORT_MIN_WAVES) void trace_batch_rerun_kernel(const TraceArgs *batch)
 {
     TraceArgs a;
-    load_batch_args(a, batch);
+    load_batch_args(a, batch, blockIdx.y);
     a.listed = 1;
     trace_body<MODE_FUSED, false, double, true, true>(a);
 }
@@ -34,7 +34,7 @@ const char *launch_batch(int prog, const LaunchCfg &cfg, int n_sys, const TraceA
 {
 #define ORT_CASE(P)                                                                                                                        \
     case P:                                                                                                                                \
-        hipExtLaunchKernelGGL((trace_batch_kernel<P>), dim3(cfg.grid, n_sys), dim3(kBlock), 0, cfg.stream, cfg.ev0, cfg.ev1, 0, d_batch);  \
+        hipExtLaunchKernelGGL((trace_batch_kernel<P>), dim3(n_sys, cfg.grid), dim3(kBlock), 0, cfg.stream, cfg.ev0, cfg.ev1, 0, d_batch);  \
         return "trace_batch_kernel<" #P ">";
     switch (prog) {
         ORT_BATCH_PROGRAMS(ORT_CASE)

@@ -847,8 +847,11 @@ __device__ __forceinline__ void trace_queue_body(const TraceArgs &a)
         lo = wid * a.head_chunk; if (lo > a.head_rays) lo = a.head_rays;
         hi = lo + a.head_chunk;  if (hi > a.head_rays) hi = a.head_rays;
     } else {
-        const bool head = blockIdx.x < a.head_blocks;
-        const uint64_t wid = (uint64_t)(head ? blockIdx.x : blockIdx.x - a.head_blocks) * kWavesPerBlock + wave;
+        // BATCH: blockIdx.x is the SIMULATION (the fastest index of the dispatch order: the long workgroups of all simulations
+        // of the launch come first, their short ones last), blockIdx.y the workgroup within it
+        const uint32_t bid = BATCH ? blockIdx.y : blockIdx.x;
+        const bool head = bid < a.head_blocks;
+        const uint64_t wid = (uint64_t)(head ? bid : bid - a.head_blocks) * kWavesPerBlock + wave;
         const uint64_t chunk = head ? a.head_chunk : a.tail_chunk;
         const uint64_t end = head ? a.head_rays : n;
         lo = (head ? 0 : a.head_rays) + wid * chunk; if (lo > end) lo = end;
@@ -1138,16 +1141,17 @@ __global__ __launch_bounds__(kBlock, PROG != PROG_GENERIC ? 4 : ORT_MIN_WAVES) v
 
 // ---------------------------------------------------------------------------
 // Multi-system launches (runner.py:113-261 runs one PROCESS per settings file): ONE launch traces one loop of
-// MANY simulations that share a surface program.  gridDim.y = simulations of the launch, blockIdx.y -> that simulation's
-// TraceArgs in a device table (its own staged system, image, counters, re-run list, ray ranges over blockIdx.x), read through
+// MANY simulations that share a surface program.  gridDim.x = simulations of the launch, blockIdx.x -> that simulation's
+// TraceArgs in a device table (its own staged system, image, counters, re-run list, ray ranges over blockIdx.y — long ranges
+// on its first workgroups, short ones on the rest, as plan_ranges cuts a launch of its own), read through
 // scalar loads like a kernel argument; everything per ray is the fused program kernel's (the same body).  At 1e6 rays a
 // simulation is ~40 us of work inside ~25 us of ramp and drain of a launch of its own: batched, the chip sees one launch of
 // n x 1e6 rays.  The rays a simulation defers go to ITS list; trace_batch_rerun_kernel closes all of them in one launch.
 // ---------------------------------------------------------------------------
 typedef const __attribute__((address_space(4))) TraceArgs *batch_args_t;
-__device__ __forceinline__ void load_batch_args(TraceArgs &a, const TraceArgs *batch)
+__device__ __forceinline__ void load_batch_args(TraceArgs &a, const TraceArgs *batch, uint32_t simulation)
 {
-    const batch_args_t p = (batch_args_t)batch + blockIdx.y;
+    const batch_args_t p = (batch_args_t)batch + simulation;
     __builtin_memcpy(&a, p, sizeof(TraceArgs));
 }
 
@@ -1155,7 +1159,7 @@ template <int PROG>
 __global__ __launch_bounds__(kBlock, 4) void trace_batch_kernel(const TraceArgs *batch)
 {
     TraceArgs a;
-    load_batch_args(a, batch);
+    load_batch_args(a, batch, blockIdx.x);
     trace_queue_body<MODE_FUSED, true, false, double, PROG, false, 0, SCHED_STATIC, false, true>(a);
 }
 
