@@ -222,7 +222,8 @@ uint64_t chunk_rays()
 // culls (1: fp64 arithmetics, 2: fp32, whose rays are cheaper still): 6 batches up to ~6e6 (fp32: 2.4e6) rays, then one more
 // per 1e6 (4e5) rays, at most 32 — ring1e8 0.720 -> 0.666 ms, 2^27 rays 0.952 -> 0.874 (fp32 0.578 -> 0.472); the point loop
 // (every ray emitted, 6.3 surface solves) is indifferent above 2e7 rays (12 batches: -0.5 %) and wants 6 at 1e7.
-constexpr int kHeadBlocks = 1280, kHeadPercent = 86, kTailBatches = 6;
+constexpr int kHeadBlocks = 1280, kHeadPercent = 86, kTailBatches = 6, kEqualBlocks = 1024;
+constexpr uint64_t kTwoLevelRays = 2500000;
 int tail_batches_for(uint64_t n, int light)
 {
     static const int forced = env_int("ORT_DEV_TAIL_BATCHES", 0);          // development knob
@@ -236,9 +237,14 @@ int plan_ranges(TraceArgs &a, int light = 0)
 {
     static const int head_blocks = env_int("ORT_DEV_HEAD_BLOCKS", kHeadBlocks), head_pct = env_int("ORT_DEV_HEAD_PERCENT", kHeadPercent);
     const int tail_batches = tail_batches_for(a.n_rays, light);
-    const uint64_t n = a.n_rays, per_block = 64ull * kWavesPerBlock;
-    if (n < (uint64_t)head_blocks * per_block * 4 || head_pct >= 100) {       // equal ranges
-        int grid = grid_for(n);
+    const uint64_t n = a.n_rays;
+    // Small launches: equal ranges on at most kEqualBlocks workgroups — ONE round of the chip with ranges as long as they
+    // can be (a launch of 1e6 rays is 15 625 batches for 6 144 wave slots): on 3 072 workgroups, two rounds of 128-ray ranges,
+    // the same launch took 0.053 ms in the ring loop and 0.067 in the point loop against 0.034 / 0.056 (profiles/r05/small_launches.log);
+    // the two-level plan takes over where it wins, at ~2.5e6 rays.
+    static const int equal_cap = env_int("ORT_DEV_MAX_BLOCKS", kEqualBlocks);
+    if (n < kTwoLevelRays || head_pct >= 100) {               // equal ranges
+        int grid = equal_cap;
         const uint64_t batches = (n + 63) / 64, blocks = (batches + kWavesPerBlock - 1) / kWavesPerBlock;
         if (blocks < (uint64_t)grid) grid = (int)blocks;
         const uint64_t nwaves = (uint64_t)grid * kWavesPerBlock;
