@@ -187,3 +187,26 @@ def test_longest_wave_ranges_keep_their_16_bit_queue_indices(hip_library, tmp_pa
         got.append(np.load(out))
     assert np.array_equal(got[0]["img"], got[1]["img"]) and np.array_equal(got[0]["cnt"], got[1]["cnt"])
     assert int(got[0]["cnt"][5]) > 400_000
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_launch_sizes_around_the_range_plan_thresholds(hip_library, precision):
+    """plan_ranges changes shape with the launch size — equal ranges on one round of workgroups below 2.5e6 rays, the two-level
+    plan above, longer short ranges in the ring programs as the launch grows (one more batch per 1e6 rays; fp32: per 4e5), 12
+    batches in the point loop above 1.6e7 —: at every border the queued kernels' images and counters equal the lockstep
+    kernel's, which knows no plan."""
+    from opticalraytrace_amd.capi import Context
+    _, osys = make_system("large")
+    with Context(osys) as c:
+        c.set_precision(precision)
+        for n in (2_499_937, 2_500_000, 2_500_065, 6_000_001, 16_000_001, 33_000_003):
+            out = []
+            for variant in (1, 0):
+                c.set_kernel_variant(variant)
+                c.reset()
+                c.trace(1, 7, n, SEED)
+                if n <= 16_000_001:
+                    c.trace(2, 7, n, SEED)
+                out.append(c.read())
+            c.set_kernel_variant(1)
+            assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]), (precision, n, out[0][1], out[1][1])
