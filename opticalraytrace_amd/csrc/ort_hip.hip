@@ -1187,8 +1187,9 @@ constexpr int kBatchRedoBlocks = 4;                   // workgroups per simulati
 // of its own, with the long workgroups shared out — 1 280 of them in the whole launch (at least one per simulation), 86 % of a
 // simulation's rays in them, the rest in short ranges whose length follows the launch's TOTAL size (tail_batches_for).  The
 // dispatch order is simulation-fastest (trace_batch_kernel: blockIdx.x), so the long workgroups of all simulations start first
-// and the launch drains on short ones.  (Round 5's first plan — equal ranges, 6 144 workgroups — left the 75 ring loops of the
-// lens experiment at half the rate of one large launch: 6 150 equal workgroups are four full rounds of the chip and six left over.)
+// and the launch drains on short ones.  (Round 5's first plan — equal ranges on ~6 144 workgroups, simulation-major dispatch —
+// took 6 % longer for the 75 ring loops of the lens experiment and 3 % for 75 point loops; a group of 25 point loops was 4 %
+// faster with it: profiles/r05/batch_probe.log and HISTORY.md.  One plan for single and multi-system launches.)
 // Returns the workgroups per simulation (gridDim.y).
 static int plan_batch(TraceArgs &a, int cnt, int light)
 {
